@@ -1,0 +1,199 @@
+"""Oracle self-consistency: op-for-op graph restatement == closed-form fp64, hand backward == autograd,
+plus the hand-derivable known-answer tests of SURVEY.md section 8 C4.  CPU only."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from ml_function_amd import synth
+from oracle import closed, graph
+
+T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+# ------------------------------------------------------------------ FM
+@pytest.mark.parametrize("B,F,K", [(2, 3, 4), (8, 5, 8), (4, 39, 16), (3, 2, 1)])
+def test_fm_graph_vs_closed(B, F, K):
+    c = synth.fm_case(B, F, K, dist="normal")
+    emb = T(c["emb"]).requires_grad_()
+    lin = T(c["lin"]).requires_grad_()
+    out = graph.fm_layer([emb[:, f:f + 1, :] for f in range(F)], [lin[:, f:f + 1, None] for f in range(F)])
+    assert out.shape == (B, 1, K)
+    assert rel(out.detach()[:, 0], closed.fm_fwd(c["emb"], c["lin"])) < 1e-12
+    out.backward(T(c["g"])[:, None, :])
+    demb, dlin = closed.fm_bwd(c["emb"], c["g"])
+    assert rel(emb.grad, demb) < 1e-12 and rel(lin.grad, dlin) < 1e-12
+
+
+def test_fm_pairs_order_and_bwd():
+    c = synth.fm_case(4, 6, 3, dist="normal")
+    emb = T(c["emb"]).requires_grad_()
+    pairs = graph.inner_layer([emb[:, f:f + 1, :] for f in range(6)], use_add=False)
+    assert len(pairs) == 15
+    got = torch.cat(pairs, 1)
+    assert rel(got.detach(), closed.fm_pairs_fwd(c["emb"])) < 1e-14
+    gp = np.random.default_rng(1).standard_normal(got.shape)
+    got.backward(T(gp))
+    assert rel(emb.grad, closed.fm_pairs_bwd(c["emb"], gp)) < 1e-12
+    # combinations order: (0,1),(0,2)...(4,5)
+    order = list(itertools.combinations(range(6), 2))
+    p7 = closed.fm_pairs_fwd(c["emb"])[:, 7]
+    i, j = order[7]
+    assert np.allclose(p7, c["emb"][:, i].astype(np.float64) * c["emb"][:, j])
+
+
+def test_fm_kat():
+    B, F, K = 3, 7, 5
+    ones = np.ones((B, F, K))
+    lin = np.arange(B * F, dtype=np.float64).reshape(B, F)
+    out = closed.fm_fwd(ones, lin)
+    assert np.array_equal(out, (F * (F - 1) // 2 + lin.sum(1))[:, None] * np.ones((1, K)))
+    one_hot = np.zeros((B, F, K))
+    one_hot[:, 2] = 3.0
+    assert np.array_equal(closed.fm_fwd(one_hot, lin), lin.sum(1)[:, None] * np.ones((1, K)))
+
+
+# ------------------------------------------------------------------ DCN
+@pytest.mark.parametrize("B,D,L", [(2, 5, 1), (8, 24, 3), (4, 1248, 3), (3, 7, 5)])
+def test_dcn_graph_vs_closed(B, D, L):
+    c = synth.dcn_case(B, D, L, dist="normal")
+    x = T(c["x"]).requires_grad_()
+    ws = [T(c["w"][l])[:, None].requires_grad_() for l in range(L)]
+    bs = [T(c["b"][l])[:, None].requires_grad_() for l in range(L)]
+    y = graph.cross_layer(x, ws, bs)
+    assert y.shape == (B, D, 1)
+    yc, _ = closed.dcn_fwd(c["x"], c["w"], c["b"])
+    assert rel(y.detach()[..., 0], yc) < 1e-12
+    y.backward(T(c["g"])[..., None])
+    dx, dw, db = closed.dcn_bwd(c["x"], c["w"], c["b"], c["g"])
+    assert rel(x.grad, dx) < 1e-11
+    assert rel(torch.stack([w.grad[:, 0] for w in ws]), dw) < 1e-11
+    assert rel(torch.stack([b.grad[:, 0] for b in bs]), db) < 1e-11
+
+
+def test_dcn_kat():
+    B, D, L = 4, 6, 3
+    c = synth.dcn_case(B, D, L)
+    y, _ = closed.dcn_fwd(c["x"], np.zeros((L, D)), c["b"])
+    assert rel(y, c["x"].astype(np.float64) + c["b"].astype(np.float64).sum(0)) < 1e-15
+    y1, _ = closed.dcn_fwd(c["x"], c["w"][:1], c["b"][:1])
+    x = c["x"].astype(np.float64)
+    assert rel(y1, x * (x @ c["w"][0].astype(np.float64))[:, None] + x + c["b"][0]) < 1e-15
+
+
+# ------------------------------------------------------------------ CIN
+@pytest.mark.parametrize("B,F,K,conv", [(2, 3, 4, [5]), (4, 5, 8, [6, 7]), (2, 39, 16, [16, 8, 8]), (3, 4, 2, [3, 3, 3, 3])])
+@pytest.mark.parametrize("output_dim", [1, 2])
+def test_cin_graph_vs_closed(B, F, K, conv, output_dim):
+    c = synth.cin_case(B, F, K, conv, dist="normal", output_dim=output_dim)
+    x = T(c["x"]).requires_grad_()
+    Ws = [T(w).requires_grad_() for w in c["Ws"]]
+    bs = [T(b).requires_grad_() for b in c["bs"]]
+    dw, db = T(c["dense_w"]).requires_grad_(), T(c["dense_b"]).requires_grad_()
+    out = graph.cin(x, Ws, bs, dw, db, output_dim=output_dim)
+    assert out.shape == ((B, 1) if output_dim == 1 else (B, len(conv) * K))
+    oc, maps, _ = closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"], output_dim, return_maps=True)
+    assert rel(out.detach(), oc) < 1e-12
+    for m_g, m_c in zip(graph.cin_feature_maps(x.detach(), [w.detach() for w in Ws], [b.detach() for b in bs]), maps):
+        assert rel(m_g, m_c) < 1e-12
+    out.backward(T(c["g"]))
+    dx, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"], output_dim)
+    assert rel(x.grad, dx) < 1e-11
+    for a, b_ in zip(Ws, dWs):
+        assert rel(a.grad, b_) < 1e-11
+    for a, b_ in zip(bs, dbs):
+        assert rel(a.grad, b_) < 1e-11
+    if output_dim == 1:
+        assert rel(dw.grad, ddw) < 1e-11 and rel(db.grad, ddb) < 1e-11
+
+
+def test_cin_kat_ones():
+    """X=1, W=1, bias=0: x1 = F^2, p1 = H1 F^2; x2 = H1 F^3, p2 = H2 H1 F^3; x3 = H1 H2 F^4, p3 = H3 H1 H2 F^4."""
+    B, F, K = 2, 3, 4
+    H1, H2, H3 = 2, 5, 3
+    Ws = [np.ones((F * F, H1)), np.ones((H1 * F, H2)), np.ones((H2 * F, H3))]
+    bs = [np.zeros(H1), np.zeros(H2), np.zeros(H3)]
+    P = closed.cin_fwd(np.ones((B, F, K)), Ws, bs, output_dim=2)
+    exp = np.concatenate([np.full((B, K), H1 * F ** 2), np.full((B, K), H2 * H1 * F ** 3),
+                          np.full((B, K), H3 * H1 * H2 * F ** 4)], -1)
+    assert np.array_equal(P, exp)
+    Pg = graph.cin(torch.ones(B, F, K, dtype=torch.float64), [T(w) for w in Ws], [T(b) for b in bs], output_dim=2)
+    assert np.array_equal(Pg.numpy(), exp)
+
+
+def test_cin_channel_order():
+    """c = h*F + f: a W with a single 1 at (h*F+f, n) must give x1[b,n,k] = x[b,h,k]*x[b,f,k]."""
+    B, F, K, H = 2, 4, 3, 2
+    x = np.random.default_rng(0).standard_normal((B, F, K))
+    h, f, n = 1, 3, 1
+    W = np.zeros((F * F, H))
+    W[h * F + f, n] = 1.0
+    m = graph.cin_feature_maps(T(x), [T(W)], [T(np.zeros(H))])[0].numpy()
+    assert np.allclose(m[:, n, :], x[:, h, :] * x[:, f, :]) and np.all(m[:, 0, :] == 0)
+
+
+# ------------------------------------------------------------------ AutoInt
+@pytest.mark.parametrize("B,F,K,H,A", [(2, 3, 4, 2, 4), (3, 7, 8, 3, 8), (2, 39, 16, 4, 16)])
+@pytest.mark.parametrize("use_res,use_ln", [(True, True), (False, True), (True, False)])
+def test_attn_graph_vs_closed(B, F, K, H, A, use_res, use_ln):
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    names = ["x", "Wq", "Wk", "Wr", "gamma", "beta"]
+    t = {n: T(c[n]).requires_grad_() for n in names}
+    y = graph.autoint_interacting(t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"], use_res=use_res, use_ln=use_ln)
+    assert y.shape == (H, B, F, A)
+    yc = closed.attn_fwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], c["beta"], use_res=use_res, use_ln=use_ln)
+    assert rel(y.detach(), yc) < 1e-12
+    y.backward(T(c["dy"]))
+    dx, dWq, dWk, dWr, dg, db = closed.attn_bwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], c["beta"], c["dy"],
+                                                use_res=use_res, use_ln=use_ln)
+    assert rel(t["x"].grad, dx) < 1e-10
+    assert rel(t["Wq"].grad, dWq) < 1e-10 and rel(t["Wk"].grad, dWk) < 1e-10
+    if use_res:
+        assert rel(t["Wr"].grad, dWr) < 1e-10
+    if use_ln:
+        assert rel(t["gamma"].grad, dg) < 1e-10 and rel(t["beta"].grad, db) < 1e-10
+    flat = graph.autoint_flatten(y.detach())
+    assert flat.shape == (B, H * F * A)
+    assert torch.equal(flat[:, F * A:2 * F * A], y.detach()[1].reshape(B, F * A))
+
+
+def test_attn_kat():
+    B, F, K, H, A = 2, 5, 4, 2, 4
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    # Wq = 0 -> s = sigmoid(0) = 0.5 -> av = 0.5 * sum_f v
+    _, sv = closed.attn_fwd(c["x"], np.zeros_like(c["Wq"]), c["Wk"], c["Wr"], c["gamma"], c["beta"], return_saved=True)
+    assert rel(sv["av"], 0.5 * np.repeat(sv["kk"].sum(2, keepdims=True), F, 2)) < 1e-14
+    # LN of constant rows -> beta ; with res off and relu: max(beta,0)
+    y = closed.attn_fwd(np.zeros((B, F, K)), c["Wq"], c["Wk"], c["Wr"], c["gamma"], c["beta"], use_res=False)
+    assert rel(y, np.broadcast_to(np.maximum(c["beta"].astype(np.float64), 0), y.shape)) < 1e-14
+    # mask plumbing of ProductAttentionLayer (not used by AutoInt): mask_mod=1 right-multiplies the scores
+    q = T(np.random.default_rng(0).standard_normal((1, 2, 3, 4)))
+    m = torch.eye(3, dtype=torch.float64)
+    assert torch.allclose(graph.product_attention(q, q, q, mask=m, mask_mod=1), graph.product_attention(q, q, q))
+
+
+# ------------------------------------------------------------------ field-index work
+def test_label_encode_lexicographic():
+    idx, classes = closed.label_encode([10, 2, None, "a", 2, 10])
+    assert classes == ["-1", "10", "2", "a"]
+    assert idx.tolist() == [1, 2, 0, 3, 2, 1]
+
+
+def test_embed_gather_scatter():
+    rng = np.random.default_rng(3)
+    tables = [rng.standard_normal((v, 4)).astype(np.float32) for v in (5, 9, 2)]
+    idx = np.stack([rng.integers(0, v, 16) for v in (5, 9, 2)], 1)
+    e = closed.embed_gather(tables, idx)
+    assert e.dtype == np.float32 and e.shape == (16, 3, 4)
+    assert np.array_equal(e[7, 1], tables[1][idx[7, 1]])
+    g = rng.standard_normal((16, 3, 4))
+    d = closed.embed_scatter_add(idx, g, [5, 9, 2])
+    assert np.allclose(d[2].sum(0), g[:, 2].sum(0))
+    got = graph.sparse_embed([torch.tensor(t) for t in tables], [torch.tensor(idx[:, f:f + 1]) for f in range(3)])
+    assert got[0].shape == (16, 1, 4) and np.array_equal(torch.cat(got, 1).numpy(), e)
