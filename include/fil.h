@@ -1,0 +1,126 @@
+/*
+ * fil.h -- C ABI of libfil_hip.so: the MI355X (gfx950) feature-interaction hot path.
+ *
+ * The reference (TIXhjq/ML_Function) is 100% Python/TF2 and has NO native code, so there is no
+ * existing FFI to mirror; each entry point below replaces the TF op group that the cited reference
+ * lines execute per batch (paths relative to /root/reference/kon/model/ctr_model/layer/).  The
+ * Python layer classes in ml_function_amd/layers bind these through ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda storage), row-major contiguous;
+ *   - the caller allocates and owns every buffer, including workspaces (sizes from *_workspace_bytes);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no entry point synchronises, allocates or frees (graph-capture safe);
+ *   - reductions use a fixed two-stage order: repeated calls on the same inputs are bit-identical;
+ *   - return value: 0 on success, negative fil_status on error; fil_last_error() gives the message
+ *     of the last failing call on the calling thread.
+ */
+#ifndef FIL_H_
+#define FIL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  FIL_OK = 0,
+  FIL_ERR_ARG = -1,         /* NULL pointer / non-positive dim / inconsistent arguments */
+  FIL_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed */
+  FIL_ERR_WORKSPACE = -3,   /* workspace smaller than *_workspace_bytes() */
+  FIL_ERR_UNSUPPORTED = -4  /* shape outside the compiled kernel menu (message says which limit) */
+} fil_status;
+
+typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
+
+int fil_version(void);                 /* 10000*major + 100*minor + patch */
+const char* fil_last_error(void);      /* thread-local, never NULL */
+
+/* ---------------------------------------------------------------------------------------------
+ * A1  FM second order -- replaces InnerLayer.call + FmLayer.call
+ *     interactive_layer/interactive_layer.py:59-66,161-170 (C(F,2) tf.multiply + Add + Add).
+ *   emb [B,F,K], lin [B,F] or NULL, out [B,K]:  out[b,k] = sum_{i<j} e_i e_j + sum_f lin[b,f].
+ *   dtype selects the storage type of emb/out/g/demb (accumulation is always fp32); lin/dlin are fp32.
+ *   bwd: demb[b,f,k] = g[b,k] (S[b,k] - e[b,f,k]);  dlin[b,f] = sum_k g[b,k]  (dlin may be NULL).
+ */
+int fil_fm_fwd(const void* emb, const float* lin, void* out, int B, int F, int K, int dtype, void* stream);
+int fil_fm_bwd(const void* emb, const void* g, void* demb, float* dlin, int B, int F, int K, int dtype, void* stream);
+
+/* N3  InnerLayer(use_add=False) pair list (PNN/AFM input), interactive_layer.py:61:
+ *   pairs [B, F(F-1)/2, K] in itertools.combinations order; bwd: demb from gpairs. fp32 only. */
+int fil_fm_pairs_fwd(const float* emb, float* pairs, int B, int F, int K, void* stream);
+int fil_fm_pairs_bwd(const float* emb, const float* gpairs, float* demb, int B, int F, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A2  DCN cross network -- replaces CrossLayer.call, interactive_layer.py:275-282, all L layers fused.
+ *   x [B,D], w [L,D], b [L,D] (the reference's L tensors [D,1] stacked), y [B,D], s [B,L] (saved dots).
+ *   bwd: g [B,D] -> dx [B,D], dw [L,D], db [L,D].  Limits: D <= 4096, L <= 8.
+ */
+int fil_dcn_fwd(const float* x, const float* w, const float* b, float* y, float* s, int B, int D, int L, void* stream);
+size_t fil_dcn_bwd_workspace_bytes(int B, int D, int L);
+int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, const float* g, float* dx, float* dw,
+                float* db, int B, int D, int L, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3  xDeepFM CIN (north star) -- replaces CIN.call, interactive_layer.py:310-327
+ *     (BatchMatMul outer product, 2 transposes, Conv1D 1x1, reduce_sum pooling, Concat, Dense(1)).
+ *   x [B,F,K]; W[l] [H_{l-1}*F, H_l] with channel c = h*F+f (H_0 = F); bias[l] [H_l];
+ *   dense_w [L*K], dense_b [1] (ignored when output_dim != 1).
+ *   fwd outputs: out [B] (output_dim==1; may be NULL otherwise), pooled [B, L*K] (always written),
+ *                saved = feature maps x^1..x^{L-1}, each [B,H_l,K], packed back to back
+ *                (fil_cin_saved_bytes; needed by bwd; the last layer's map is never materialised).
+ *   bwd: g = dL/dout [B] (output_dim==1) or dL/dpooled [B,L*K];
+ *        writes dx [B,F,K], dW[l], dbias[l], ddense_w [L*K], ddense_b [1] (dense grads only if output_dim==1).
+ *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 products, parity mode).
+ *   Limits: H_l <= 256, L <= 8.
+ */
+size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
+size_t fil_cin_fwd_workspace_bytes(int B, int F, int K, int L, const int* H);
+size_t fil_cin_bwd_workspace_bytes(int B, int F, int K, int L, const int* H);
+int fil_cin_fwd(const float* x, const float* const* W, const float* const* bias, const float* dense_w,
+                const float* dense_b, float* out, float* pooled, float* saved, int B, int F, int K, int L,
+                const int* H, int output_dim, int mode, void* workspace, size_t workspace_bytes, void* stream);
+int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias, const float* dense_w,
+                const float* pooled, const float* saved, const float* g, float* dx, float* const* dW,
+                float* const* dbias, float* ddense_w, float* ddense_b, int B, int F, int K, int L, const int* H,
+                int output_dim, int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4  AutoInt interacting layer -- replaces MultHeadAttentionLayer.call + ProductAttentionLayer.call
+ *     (behavior_layer/behavior_layer.py:292-311,356-377) and DnnLayer's Add + ReLU
+ *     (core_layer/core_layer.py:204-216), fused; the [H,B,F,F] score tensor is never materialised.
+ *   x [B,F,K]; Wq, Wk, Wr [K,H,A] (V is projected with Wk, as the reference does; Wr may be NULL = use_res off);
+ *   gamma, beta [A] (NULL = use_ln off); eps = 1e-3 for Keras parity; scale = 1/sqrt(A) (use_scale) or 1.
+ *   y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale * q k^T) k)).
+ *   bwd: dy [H,B,F,A] -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
+ *   Limits: K <= 64, A in {8,16,32}, H*A <= 256.
+ */
+size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
+size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A);
+int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
+                 const float* beta, float* y, int B, int F, int K, int H, int A, float scale, float eps,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
+                 const float* beta, const float* dy, float* dx, float* dWq, float* dWk, float* dWr, float* dgamma,
+                 float* dbeta, int B, int F, int K, int H, int A, float scale, float eps, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,
+ *     interactive_layer.py:225-242, emitting the packed [B,F,K] layout directly (bit-exact row copies).
+ *   table: all F tables concatenated [sum_f V_f, K]; offsets [F] = first row of field f (int64);
+ *   idx [B,F] (int64, per-field local ids, 0 <= idx < V_f).  out [B,F,K].
+ *   scatter_add: dtable[offsets[f]+idx[b,f], :] += g[b,f,:]  (fp32 atomics; dtable must be pre-zeroed).
+ */
+int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* idx, float* out, int B, int F, int K,
+                     void* stream);
+int fil_embed_scatter_add(const int64_t* offsets, const int64_t* idx, const float* g, float* dtable, int B, int F,
+                          int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIL_H_ */

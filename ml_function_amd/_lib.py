@@ -1,0 +1,100 @@
+"""ctypes binding of libfil_hip.so (include/fil.h).  No CPU fallback: if the library is missing or a call
+fails, the product path raises."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfil_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "fil.h")
+
+FIL_F32, FIL_BF16 = 0, 1
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_Z = _c.c_size_t
+_F = _c.c_float
+
+# name -> (restype, argtypes); mirrors include/fil.h one to one
+SIGNATURES = {
+    "fil_version": (_I, []),
+    "fil_last_error": (_c.c_char_p, []),
+    "fil_fm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "fil_fm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fil_fm_pairs_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "fil_fm_pairs_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "fil_dcn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fil_dcn_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
+    "fil_dcn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "fil_cin_saved_bytes": (_Z, [_I, _I, _I, _I, _P]),
+    "fil_cin_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _P]),
+    "fil_cin_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _P]),
+    "fil_cin_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
+    "fil_cin_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
+    "fil_attn_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "fil_attn_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "fil_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _Z, _P]),
+    "fil_attn_bwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _F, _F, _P, _Z, _P]),
+    "fil_embed_gather": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "fil_embed_scatter_add": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+}
+
+
+class FilError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def header_symbols():
+    """Names of every function declared in include/fil.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fil_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Loads libfil_hip.so (raises FilError if it has not been built: python -m ml_function_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FilError("libfil_hip.so not found at %s -- build it with `python -m ml_function_amd.build` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing:
+        raise FilError("libfil_hip.so at %s does not export %s -- rebuild it (python -m ml_function_amd.build --force)"
+                       % (LIB_PATH, ", ".join(missing)))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fil_last_error().decode("utf-8", "replace")
+        raise FilError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

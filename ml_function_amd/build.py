@@ -1,0 +1,66 @@
+"""Builds ml_function_amd/libfil_hip.so (gfx950) from csrc/*.hip with hipcc.  In-tree, no JIT cache.
+
+    python -m ml_function_amd.build [--force]
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libfil_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "fil.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_m = _deps_mtime()
+    jobs = []
+    objs = []
+    for src in _sources():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr))
+        return o
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

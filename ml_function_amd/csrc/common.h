@@ -1,0 +1,69 @@
+// Shared host/device helpers for libfil_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/fil.h"
+
+namespace fil {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define FIL_CHECK_ARG(cond)                                                              \
+  do {                                                                                   \
+    if (!(cond)) return ::fil::fail(FIL_ERR_ARG, "%s: bad argument: %s", __func__, #cond); \
+  } while (0)
+
+#define FIL_CHECK_LAUNCH()                                                                          \
+  do {                                                                                              \
+    hipError_t e__ = hipGetLastError();                                                             \
+    if (e__ != hipSuccess)                                                                          \
+      return ::fil::fail(FIL_ERR_HIP, "%s: kernel launch failed: %s", __func__, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Carves consecutive 256-byte aligned regions out of a caller-provided workspace.
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t n) {
+    T* r = reinterpret_cast<T*>(base + off);
+    off += align_up(n * sizeof(T), 256);
+    return r;
+  }
+};
+
+#ifdef __HIPCC__
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Sum over the 32 lanes of each wave half (lanes 0-31 and 32-63 reduce independently).
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = half_wave_sum(v);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Row of a 32x32 MFMA C/D tile held in accumulator register r of a lane in wave half `half`.
+__device__ __forceinline__ constexpr int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+#endif
+
+}  // namespace fil

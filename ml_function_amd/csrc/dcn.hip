@@ -1,0 +1,302 @@
+// A2  DCN cross network, all L layers fused, for gfx950.
+//
+// Replaces CrossLayer.call of the reference (interactive_layer.py:275-282): per layer one [B,1,D]x[D,1]
+// K.dot, one K.batch_dot and two adds, each streaming [B,D] through memory.  Here one wavefront owns one
+// sample: its D floats live in the wave's registers (NPL per lane, 16-byte coalesced loads), the L dot
+// products are wave reductions, w/b are staged once per workgroup in LDS, and x is read once and y
+// written once (fwd: 2*D*4 bytes per sample; bwd: read x,g, write dx: 3*D*4 bytes per sample).
+// Backward recomputes x_l from x0 and the saved dots s_l (bit-identical to forward), accumulates dw/db per
+// lane in registers across the wave's samples, and reduces them in a fixed order:
+// registers -> LDS (waves of a block) -> partial[block] -> dcn_reduce_kernel.  No atomics.
+#include "common.h"
+
+namespace fil {
+
+constexpr int kDcnThreads = 256;  // 4 waves per workgroup (1 per SIMD), one sample per wave at a time;
+                                  // kernels that stay under 256 VGPRs co-reside 2 workgroups per CU
+constexpr int kDcnWaves = kDcnThreads / kWave;
+
+// Lane-owned element layout: chunk c = lane + 64*u (u < NPL/VEC) covers elements [c*VEC, c*VEC+VEC).
+template <int NPL, int VEC>
+__device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int lane, float (&v)[NPL]) {
+#pragma unroll
+  for (int u = 0; u < NPL / VEC; ++u) {
+    const int d = (lane + kWave * u) * VEC;
+    if constexpr (VEC == 4) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d < D) t = *reinterpret_cast<const float4*>(p + d);
+      v[u * 4 + 0] = t.x; v[u * 4 + 1] = t.y; v[u * 4 + 2] = t.z; v[u * 4 + 3] = t.w;
+    } else {
+      v[u] = d < D ? p[d] : 0.f;
+    }
+  }
+}
+
+template <int NPL, int VEC>
+__device__ __forceinline__ void row_store(float* __restrict__ p, int D, int lane, const float (&v)[NPL]) {
+#pragma unroll
+  for (int u = 0; u < NPL / VEC; ++u) {
+    const int d = (lane + kWave * u) * VEC;
+    if (d < D) {
+      if constexpr (VEC == 4) *reinterpret_cast<float4*>(p + d) = make_float4(v[u * 4], v[u * 4 + 1], v[u * 4 + 2], v[u * 4 + 3]);
+      else p[d] = v[u];
+    }
+  }
+}
+
+// Parameter row l (w or b) from the LDS copy staged at kernel start.
+template <int NPL, int VEC>
+__device__ __forceinline__ void param_load(const float* p, int D, int lane, float (&v)[NPL]) {
+  row_load<NPL, VEC>(p, D, lane, v);
+}
+
+template <int NPL, int VEC>
+__global__ __launch_bounds__(kDcnThreads) void dcn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float* __restrict__ y,
+                                                              float* __restrict__ s, int B, int D, int L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  for (int i = threadIdx.x; i < L * D; i += kDcnThreads) {
+    smem[i] = w[i];
+    smem[L * D + i] = b[i];
+  }
+  __syncthreads();
+  const float* ws = smem;
+  const float* bs = smem + L * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = blockIdx.x * kDcnWaves + wave; n < B; n += gridDim.x * kDcnWaves) {
+    float x0[NPL], xl[NPL];
+    row_load<NPL, VEC>(x + (long)n * D, D, lane, x0);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) xl[i] = x0[i];
+    for (int l = 0; l < L; ++l) {
+      float wl[NPL], bl[NPL];
+      param_load<NPL, VEC>(ws + l * D, D, lane, wl);
+      param_load<NPL, VEC>(bs + l * D, D, lane, bl);
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) dot = fmaf(xl[i], wl[i], dot);
+      dot = wave_sum(dot);
+      if (lane == 0) s[(long)n * L + l] = dot;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) xl[i] = fmaf(x0[i], dot, xl[i]) + bl[i];
+    }
+    row_store<NPL, VEC>(y + (long)n * D, D, lane, xl);
+  }
+}
+
+template <int NPL, int VEC, int LL>
+__global__ __launch_bounds__(kDcnThreads) void dcn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, const float* __restrict__ s,
+                                                              const float* __restrict__ g, float* __restrict__ dx,
+                                                              float* __restrict__ partial, int B, int D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  for (int i = threadIdx.x; i < LL * D; i += kDcnThreads) {
+    smem[i] = w[i];
+    smem[LL * D + i] = b[i];
+  }
+  __syncthreads();
+  const float* ws = smem;
+  const float* bs = smem + LL * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dwacc[LL][NPL], dbacc[LL][NPL];
+#pragma unroll
+  for (int l = 0; l < LL; ++l)
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) dwacc[l][i] = dbacc[l][i] = 0.f;
+
+  for (int n = blockIdx.x * kDcnWaves + wave; n < B; n += gridDim.x * kDcnWaves) {
+    float x0[NPL], gx[NPL], dx0[NPL], sv[LL];
+    row_load<NPL, VEC>(x + (long)n * D, D, lane, x0);
+    row_load<NPL, VEC>(g + (long)n * D, D, lane, gx);
+#pragma unroll
+    for (int l = 0; l < LL; ++l) sv[l] = s[(long)n * LL + l];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) dx0[i] = 0.f;
+#pragma unroll
+    for (int l = LL - 1; l >= 0; --l) {
+      // x_l recomputed from x0 with the saved dots (same operations as forward -> same bits)
+      float xl[NPL];
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) xl[i] = x0[i];
+#pragma unroll
+      for (int t = 0; t < l; ++t) {
+        float bl[NPL];
+        param_load<NPL, VEC>(bs + t * D, D, lane, bl);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) xl[i] = fmaf(x0[i], sv[t], xl[i]) + bl[i];
+      }
+      float ds = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        dbacc[l][i] += gx[i];
+        ds = fmaf(gx[i], x0[i], ds);
+      }
+      ds = wave_sum(ds);
+      float wl[NPL];
+      param_load<NPL, VEC>(ws + l * D, D, lane, wl);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        dx0[i] = fmaf(gx[i], sv[l], dx0[i]);
+        dwacc[l][i] = fmaf(xl[i], ds, dwacc[l][i]);
+        gx[i] = fmaf(wl[i], ds, gx[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) dx0[i] += gx[i];
+    row_store<NPL, VEC>(dx + (long)n * D, D, lane, dx0);
+  }
+
+  // block reduction of the per-wave accumulators, fixed wave order, through LDS (one [waves][D] slab at a time)
+  __syncthreads();  // everyone is done with the staged params
+  float* red = smem;  // needs kDcnWaves*D floats (host sizes the dynamic LDS for max(params, this))
+  float* pout = partial + (long)blockIdx.x * 2 * LL * D;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int l = 0; l < LL; ++l) {
+      if (which == 0) row_store<NPL, VEC>(red + wave * D, D, lane, dwacc[l]);
+      else row_store<NPL, VEC>(red + wave * D, D, lane, dbacc[l]);
+      __syncthreads();
+      for (int d = threadIdx.x; d < D; d += kDcnThreads) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < kDcnWaves; ++wv) t += red[wv * D + d];
+        pout[(which * LL + l) * D + d] = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// out[i] = sum over `parts` partials (fixed order); n = elements per partial.
+__global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                         float* __restrict__ db, int parts, int LD) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * LD) return;
+  float t = 0.f;
+  for (int p = 0; p < parts; ++p) t += partial[(long)p * 2 * LD + i];
+  if (i < LD) dw[i] = t;
+  else db[i - LD] = t;
+}
+
+static int dcn_grid(int B) { return std::max(1, std::min(cdiv(B, kDcnWaves), 512)); }
+
+static int pick_npl(int D, bool vec) {
+  const int menu[] = {8, 20, 32, 64};
+  for (int npl : menu)
+    if ((long)npl * kWave >= D && (!vec || npl % 4 == 0)) return npl;
+  return -1;
+}
+
+template <typename KernelT>
+static void allow_lds(KernelT kernel, size_t sh) {
+  if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+}
+
+template <int NPL, int VEC>
+static void launch_fwd(int grid, size_t sh, hipStream_t st, const float* x, const float* w, const float* b, float* y,
+                       float* s, int B, int D, int L) {
+  allow_lds(dcn_fwd_kernel<NPL, VEC>, sh);
+  hipLaunchKernelGGL((dcn_fwd_kernel<NPL, VEC>), dim3(grid), dim3(kDcnThreads), sh, st, x, w, b, y, s, B, D, L);
+}
+
+template <int NPL, int VEC, int LL>
+static void launch_bwd_l(int grid, size_t sh, hipStream_t st, const float* x, const float* w, const float* b,
+                         const float* s, const float* g, float* dx, float* partial, int B, int D) {
+  allow_lds(dcn_bwd_kernel<NPL, VEC, LL>, sh);
+  hipLaunchKernelGGL((dcn_bwd_kernel<NPL, VEC, LL>), dim3(grid), dim3(kDcnThreads), sh, st, x, w, b, s, g, dx, partial, B, D);
+}
+
+template <int NPL, int VEC>
+static int launch_bwd(int L, int grid, size_t sh, hipStream_t st, const float* x, const float* w, const float* b,
+                      const float* s, const float* g, float* dx, float* partial, int B, int D) {
+  switch (L) {
+#define FIL_CASE(LL) case LL: launch_bwd_l<NPL, VEC, LL>(grid, sh, st, x, w, b, s, g, dx, partial, B, D); return 0;
+    FIL_CASE(1) FIL_CASE(2) FIL_CASE(3) FIL_CASE(4) FIL_CASE(5) FIL_CASE(6)
+#undef FIL_CASE
+  }
+  return -1;
+}
+
+constexpr size_t kDcnLdsLimit = 160 * 1024;  // whole LDS of one CU
+
+}  // namespace fil
+
+using namespace fil;
+
+#define FIL_DCN_DISPATCH(NPLV, CALL_VEC, CALL_SCALAR)                \
+  switch (NPLV) {                                                    \
+    case 8: if (vec) { CALL_VEC(8); } else { CALL_SCALAR(8); } break;   \
+    case 20: if (vec) { CALL_VEC(20); } else { CALL_SCALAR(20); } break; \
+    case 32: if (vec) { CALL_VEC(32); } else { CALL_SCALAR(32); } break; \
+    case 64: if (vec) { CALL_VEC(64); } else { CALL_SCALAR(64); } break; \
+  }
+
+extern "C" int fil_dcn_fwd(const float* x, const float* w, const float* b, float* y, float* s, int B, int D, int L,
+                           void* stream) {
+  FIL_CHECK_ARG(B >= 0 && D >= 1 && L >= 1);
+  if (L > 6) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: L=%d > 6", L);
+  if (D > 4096) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: D=%d > 4096", D);
+  if (B == 0) return FIL_OK;
+  FIL_CHECK_ARG(x && w && b && y && s);
+  const bool vec = (D % 4 == 0);
+  const int npl = pick_npl(D, vec);
+  const size_t psz = (size_t)2 * L * D * sizeof(float);
+  if (psz > kDcnLdsLimit) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: 2*L*D*4 = %zu bytes of w,b exceed the 160 KiB LDS", psz);
+  const int grid = dcn_grid(B);
+  hipStream_t st = (hipStream_t)stream;
+#define FWD_VEC(N) launch_fwd<N, 4>(grid, psz, st, x, w, b, y, s, B, D, L)
+#define FWD_SCALAR(N) launch_fwd<N, 1>(grid, psz, st, x, w, b, y, s, B, D, L)
+  FIL_DCN_DISPATCH(npl, FWD_VEC, FWD_SCALAR)
+#undef FWD_VEC
+#undef FWD_SCALAR
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" size_t fil_dcn_bwd_workspace_bytes(int B, int D, int L) {
+  if (B <= 0 || D <= 0 || L <= 0) return 0;
+  return align_up((size_t)dcn_grid(B) * 2 * L * D * sizeof(float), 256);
+}
+
+extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, const float* g, float* dx,
+                           float* dw, float* db, int B, int D, int L, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  FIL_CHECK_ARG(B >= 0 && D >= 1 && L >= 1);
+  if (L > 6) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: L=%d > 6", L);
+  if (D > 4096) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: D=%d > 4096", D);
+  FIL_CHECK_ARG(dw && db);
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    (void)hipMemsetAsync(dw, 0, (size_t)L * D * sizeof(float), st);
+    (void)hipMemsetAsync(db, 0, (size_t)L * D * sizeof(float), st);
+    return FIL_OK;
+  }
+  FIL_CHECK_ARG(x && w && b && s && g && dx);
+  if (workspace == nullptr || workspace_bytes < fil_dcn_bwd_workspace_bytes(B, D, L))
+    return fail(FIL_ERR_WORKSPACE, "fil_dcn_bwd: workspace %zu < %zu bytes", workspace_bytes,
+                fil_dcn_bwd_workspace_bytes(B, D, L));
+  const bool vec = (D % 4 == 0);
+  const int npl = pick_npl(D, vec);
+  // per-lane accumulators are 2*L*NPL registers (+5*NPL of sample state): stay inside the 512-register file
+  if (2 * L * npl + 5 * npl > 440)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: L=%d x D=%d needs %d registers per lane (limit 440)", L, D,
+                2 * L * npl + 5 * npl);
+  const size_t psz = (size_t)2 * L * D * sizeof(float);
+  const size_t red = (size_t)kDcnWaves * D * sizeof(float);
+  const size_t sh = std::max(psz, red);
+  if (sh > kDcnLdsLimit) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: %zu bytes of LDS needed (> 160 KiB)", sh);
+  const int grid = dcn_grid(B);
+  float* partial = static_cast<float*>(workspace);
+  int rc = 0;
+#define BWD_VEC(N) rc = launch_bwd<N, 4>(L, grid, sh, st, x, w, b, s, g, dx, partial, B, D)
+#define BWD_SCALAR(N) rc = launch_bwd<N, 1>(L, grid, sh, st, x, w, b, s, g, dx, partial, B, D)
+  FIL_DCN_DISPATCH(npl, BWD_VEC, BWD_SCALAR)
+#undef BWD_VEC
+#undef BWD_SCALAR
+  if (rc != 0) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: no kernel for L=%d", L);
+  FIL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 256)), dim3(256), 0, st, partial, dw, db, grid, L * D);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}

@@ -1,0 +1,299 @@
+"""torch.autograd.Function wrappers over the C ABI (include/fil.h).
+
+Every function requires CUDA tensors and the HIP library; there is no eager/CPU fallback (the oracle lives
+in oracle/ and is test infrastructure only).  Tensors are made contiguous; dtypes are fp32 unless noted.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FIL_BF16, FIL_F32, FilError, check, int_array, ptr, ptr_array, stream_ptr
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FilError("ml_function_amd runs on the GPU only (got a %s tensor); there is no CPU fallback"
+                           % t.device.type)
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise FilError("expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------------- A1  FM
+class _FmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, lin):
+        _require_cuda(emb, lin)
+        if emb.dtype not in (torch.float32, torch.bfloat16):
+            raise FilError("fm: emb must be float32 or bfloat16, got %s" % emb.dtype)
+        emb = emb.contiguous()
+        lin = None if lin is None else _f32c(lin.float() if lin.dtype != torch.float32 else lin)
+        B, F, K = emb.shape
+        if lin is not None and tuple(lin.shape) != (B, lin.shape[1]):
+            raise FilError("fm: lin must be [B, n_linear]")
+        out = torch.empty((B, K), dtype=emb.dtype, device=emb.device)
+        dt = FIL_F32 if emb.dtype == torch.float32 else FIL_BF16
+        lib = _lib.load()
+        if lin is not None and lin.shape[1] != F:
+            # the reference's Add takes any number of [B,1,1] linear terms; the kernel sums F columns
+            lin_k = torch.zeros((B, F), dtype=torch.float32, device=emb.device)
+            lin_k[:, 0] = lin.sum(1)
+        else:
+            lin_k = lin
+        check(lib.fil_fm_fwd(ptr(emb), ptr(lin_k), ptr(out), B, F, K, dt, stream_ptr()), "fil_fm_fwd")
+        ctx.save_for_backward(emb)
+        ctx.lin_shape = None if lin is None else tuple(lin.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (emb,) = ctx.saved_tensors
+        B, F, K = emb.shape
+        g = g.to(emb.dtype).contiguous()
+        demb = torch.empty_like(emb)
+        dlin_k = None
+        if ctx.lin_shape is not None and ctx.needs_input_grad[1]:
+            dlin_k = torch.empty((B, F), dtype=torch.float32, device=emb.device)
+        dt = FIL_F32 if emb.dtype == torch.float32 else FIL_BF16
+        check(_lib.load().fil_fm_bwd(ptr(emb), ptr(g), ptr(demb), ptr(dlin_k), B, F, K, dt, stream_ptr()), "fil_fm_bwd")
+        dlin = None
+        if dlin_k is not None:
+            n = ctx.lin_shape[1]
+            dlin = dlin_k if n == F else dlin_k[:, :1].expand(B, n).contiguous()
+        return demb, dlin
+
+
+def fm(emb, lin=None):
+    """emb [B,F,K] (fp32/bf16), lin [B,n] fp32 or None -> [B,K]: sum_{i<j} e_i*e_j + sum of linear terms."""
+    return _FmFn.apply(emb, lin)
+
+
+class _FmPairsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb):
+        _require_cuda(emb)
+        emb = _f32c(emb)
+        B, F, K = emb.shape
+        pairs = torch.empty((B, F * (F - 1) // 2, K), dtype=torch.float32, device=emb.device)
+        check(_lib.load().fil_fm_pairs_fwd(ptr(emb), ptr(pairs), B, F, K, stream_ptr()), "fil_fm_pairs_fwd")
+        ctx.save_for_backward(emb)
+        return pairs
+
+    @staticmethod
+    def backward(ctx, gp):
+        (emb,) = ctx.saved_tensors
+        B, F, K = emb.shape
+        demb = torch.empty_like(emb)
+        check(_lib.load().fil_fm_pairs_bwd(ptr(emb), ptr(_f32c(gp)), ptr(demb), B, F, K, stream_ptr()), "fil_fm_pairs_bwd")
+        return demb
+
+
+def fm_pairs(emb):
+    """emb [B,F,K] -> [B, F(F-1)/2, K] pair products in itertools.combinations order."""
+    return _FmPairsFn.apply(emb)
+
+
+# --------------------------------------------------------------------------------------------- A2  DCN
+class _DcnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _require_cuda(x, w, b)
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        B, D = x.shape
+        L = w.shape[0]
+        y = torch.empty_like(x)
+        s = torch.empty((B, L), dtype=torch.float32, device=x.device)
+        check(_lib.load().fil_dcn_fwd(ptr(x), ptr(w), ptr(b), ptr(y), ptr(s), B, D, L, stream_ptr()), "fil_dcn_fwd")
+        ctx.save_for_backward(x, w, b, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b, s = ctx.saved_tensors
+        B, D = x.shape
+        L = w.shape[0]
+        lib = _lib.load()
+        g = _f32c(g)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b)
+        nws = lib.fil_dcn_bwd_workspace_bytes(B, D, L)
+        ws = _workspace(nws, x.device)
+        check(lib.fil_dcn_bwd(ptr(x), ptr(w), ptr(b), ptr(s), ptr(g), ptr(dx), ptr(dw), ptr(db), B, D, L, ptr(ws), nws,
+                              stream_ptr()), "fil_dcn_bwd")
+        return dx, dw, db
+
+
+def dcn_cross(x, w, b):
+    """x [B,D], w,b [L,D] -> x_L [B,D] with x_{l+1} = x0*(x_l.w_l) + x_l + b_l."""
+    return _DcnFn.apply(x, w, b)
+
+
+# --------------------------------------------------------------------------------------------- A3  CIN
+def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0):
+    """Raw forward through the C ABI.  Returns (out [B,1] or None, pooled [B,L*K], saved uint8 buffer)."""
+    lib = _lib.load()
+    B, F, K = x.shape
+    L = len(Ws)
+    H = [int(w.shape[1]) for w in Ws]
+    hp = F
+    for l, w in enumerate(Ws):
+        if tuple(w.shape) != (hp * F, H[l]) or tuple(bs[l].shape) != (H[l],):
+            raise FilError("cin: W[%d] must be [%d,%d] and bias[%d] [%d]" % (l, hp * F, H[l], l, H[l]))
+        hp = H[l]
+    Harr = int_array(H)
+    saved = _workspace(lib.fil_cin_saved_bytes(B, F, K, L, Harr), x.device)
+    nws = lib.fil_cin_fwd_workspace_bytes(B, F, K, L, Harr)
+    if nws == 0 and B > 0:
+        raise FilError("cin: %s" % lib.fil_last_error().decode())
+    ws = _workspace(nws, x.device)
+    pooled = torch.empty((B, L * K), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, 1), dtype=torch.float32, device=x.device) if output_dim == 1 else None
+    check(lib.fil_cin_fwd(ptr(x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(dense_b), ptr(out), ptr(pooled),
+                          ptr(saved), B, F, K, L, Harr, output_dim, mode, ptr(ws), nws, stream_ptr()), "fil_cin_fwd")
+    return out, pooled, saved
+
+
+def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0, grads=None):
+    """Raw backward.  grads (optional): dict with preallocated 'dx','dW'(list),'db'(list),'ddw','ddb' tensors
+    (e.g. views into one flat all-reduce bucket).  Returns the dict."""
+    lib = _lib.load()
+    B, F, K = x.shape
+    L = len(Ws)
+    H = [int(w.shape[1]) for w in Ws]
+    Harr = int_array(H)
+    if grads is None:
+        grads = dict(dx=torch.empty_like(x), dW=[torch.empty_like(w) for w in Ws], db=[torch.empty_like(b) for b in bs],
+                     ddw=torch.empty((L * K, 1), dtype=torch.float32, device=x.device) if output_dim == 1 else None,
+                     ddb=torch.empty((1,), dtype=torch.float32, device=x.device) if output_dim == 1 else None)
+    nws = lib.fil_cin_bwd_workspace_bytes(B, F, K, L, Harr)
+    ws = _workspace(nws, x.device)
+    check(lib.fil_cin_bwd(ptr(x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(pooled), ptr(saved), ptr(g),
+                          ptr(grads["dx"]), ptr_array(grads["dW"]), ptr_array(grads["db"]), ptr(grads["ddw"]),
+                          ptr(grads["ddb"]), B, F, K, L, Harr, output_dim, mode, ptr(ws), nws, stream_ptr()), "fil_cin_bwd")
+    return grads
+
+
+class _CinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dense_w, dense_b, output_dim, mode, *params):
+        L = len(params) // 2
+        Ws = [_f32c(p) for p in params[:L]]
+        bs = [_f32c(p) for p in params[L:]]
+        _require_cuda(x, *Ws, *bs)
+        x = _f32c(x)
+        dense_w = _f32c(dense_w)
+        dense_b = _f32c(dense_b)
+        out, pooled, saved = cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim, mode)
+        ctx.save_for_backward(x, dense_w, pooled, saved, *Ws, *bs)
+        ctx.cfg = (L, output_dim, mode)
+        return out if output_dim == 1 else pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        L, output_dim, mode = ctx.cfg
+        x, dense_w, pooled, saved = ctx.saved_tensors[:4]
+        Ws = list(ctx.saved_tensors[4:4 + L])
+        bs = list(ctx.saved_tensors[4 + L:])
+        gr = cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, _f32c(g), output_dim, mode)
+        return (gr["dx"], gr["ddw"], gr["ddb"], None, None, *gr["dW"], *gr["db"])
+
+
+def cin(x, Ws, bs, dense_w=None, dense_b=None, output_dim=1, mode=0):
+    """x [B,F,K]; Ws[l] [H_{l-1}*F, H_l]; bs[l] [H_l]; dense_w [L*K,1]; dense_b [1] -> [B,1] (or pooled [B,L*K])."""
+    return _CinFn.apply(x, dense_w, dense_b, output_dim, mode, *Ws, *bs)
+
+
+# --------------------------------------------------------------------------------------------- A4  AutoInt
+class _AttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps):
+        _require_cuda(x, Wq, Wk, Wr, gamma, beta)
+        x, Wq, Wk, Wr, gamma, beta = [_f32c(t) for t in (x, Wq, Wk, Wr, gamma, beta)]
+        B, F, K = x.shape
+        _, H, A = Wq.shape
+        lib = _lib.load()
+        y = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
+        nws = lib.fil_attn_fwd_workspace_bytes(B, F, K, H, A)
+        ws = _workspace(nws, x.device)
+        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), B, F, K, H, A,
+                               float(scale), float(eps), ptr(ws), nws, stream_ptr()), "fil_attn_fwd")
+        ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None])
+        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        has_res, has_ln, scale, eps = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        x, Wq, Wk = sv[:3]
+        rest = sv[3:]
+        Wr = rest.pop(0) if has_res else None
+        gamma = rest.pop(0) if has_ln else None
+        beta = rest.pop(0) if has_ln else None
+        B, F, K = x.shape
+        _, H, A = Wq.shape
+        lib = _lib.load()
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        dWq, dWk = torch.empty_like(Wq), torch.empty_like(Wk)
+        dWr = torch.empty_like(Wr) if has_res else None
+        dgamma = torch.empty_like(gamma) if has_ln else None
+        dbeta = torch.empty_like(beta) if has_ln else None
+        nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A)
+        ws = _workspace(nws, x.device)
+        check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dx), ptr(dWq),
+                               ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps, ptr(ws), nws,
+                               stream_ptr()), "fil_attn_bwd")
+        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None
+
+
+def autoint_interact(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3):
+    """x [B,F,K], W* [K,H,A] -> y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale q k^T) k))  (V == K projection)."""
+    A = Wq.shape[-1]
+    scale = (1.0 / (A ** 0.5)) if use_scale else 1.0
+    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, scale, eps)
+
+
+# --------------------------------------------------------------------------------------------- N1  embeddings
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, offsets, idx):
+        _require_cuda(table, offsets, idx)
+        table = _f32c(table)
+        idx = idx.to(torch.int64).contiguous()
+        offsets = offsets.to(torch.int64).contiguous()
+        B, F = idx.shape
+        K = table.shape[1]
+        out = torch.empty((B, F, K), dtype=torch.float32, device=table.device)
+        check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(idx), ptr(out), B, F, K, stream_ptr()),
+              "fil_embed_gather")
+        ctx.save_for_backward(offsets, idx)
+        ctx.table_shape = tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        offsets, idx = ctx.saved_tensors
+        B, F = idx.shape
+        K = ctx.table_shape[1]
+        dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=g.device)
+        check(_lib.load().fil_embed_scatter_add(ptr(offsets), ptr(idx), ptr(_f32c(g)), ptr(dtable), B, F, K, stream_ptr()),
+              "fil_embed_scatter_add")
+        return dtable, None, None
+
+
+def embed_gather(table, offsets, idx):
+    """table [sum V_f, K] (all fields concatenated), offsets [F], idx [B,F] -> packed [B,F,K]."""
+    return _EmbedFn.apply(table, offsets, idx)
