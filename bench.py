@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Headline benchmark: samples/s of xDeepFM-CIN forward+backward (BASELINE.json configs[3]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`).
+A step = CIN forward + backward over one synthetic batch of B=4096 samples per GPU (F=39, K=16, 3x128 feature
+maps, fp32, all parameter and input gradients) + (N > 1) one RCCL all-reduce of the flat parameter-gradient bucket.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement),
+including `roofline` for the dominant kernel (HIP-event timing on the launch stream via fil_profile_begin/_end)
+and `cpu_baseline` (the oracle's op-for-op torch-CPU restatement of the reference TF2 graph, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, F, K = 4096, 39, 16
+CONV = [128, 128, 128]
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def make_inputs(rank, device):
+    from ml_function_amd import synth
+    c = synth.cin_case(B_PER_GPU, F, K, CONV, seed=synth.SEED)            # parameters: identical on every rank
+    d = synth.cin_case(B_PER_GPU, F, K, CONV, seed=synth.SEED + 1 + rank)  # data shard: per rank
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+    return dict(x=t(d["x"]), g=t(d["g"][:, 0]), Ws=[t(w) for w in c["Ws"]], bs=[t(b) for b in c["bs"]],
+                dense_w=t(c["dense_w"]), dense_b=t(c["dense_b"]))
+
+
+def make_bucket(inp, device):
+    """One flat fp32 gradient bucket; dW/db/ddense are views into it (a single all-reduce, no copies)."""
+    sizes = [w.numel() for w in inp["Ws"]] + [b.numel() for b in inp["bs"]] + [inp["dense_w"].numel(), 1]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    views, off = [], 0
+    for n in sizes:
+        views.append(flat[off:off + n])
+        off += n
+    L = len(inp["Ws"])
+    grads = dict(dx=torch.empty_like(inp["x"]),
+                 dW=[v.view_as(w) for v, w in zip(views[:L], inp["Ws"])],
+                 db=views[L:2 * L], ddw=views[2 * L].view(-1, 1), ddb=views[2 * L + 1])
+    return flat, grads
+
+
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(sample_b=512, steps=3):
+    """Reference-graph restatement (oracle/graph.py) on the host CPU, fp32, all cores, bounded sample."""
+    from ml_function_amd import synth
+    from oracle import graph
+    torch.set_num_threads(usable_cpus())
+    c = synth.cin_case(sample_b, F, K, CONV)
+    mk = lambda a: torch.tensor(a, dtype=torch.float32, requires_grad=True)
+    x, Ws, bs = mk(c["x"]), [mk(w) for w in c["Ws"]], [mk(b) for b in c["bs"]]
+    dw, db = mk(c["dense_w"]), mk(c["dense_b"])
+    g = torch.tensor(c["g"])
+    times = []
+    for i in range(steps + 1):
+        for p in [x, dw, db] + Ws + bs:
+            p.grad = None
+        t0 = time.perf_counter()
+        out = graph.cin(x, Ws, bs, dw, db, output_dim=1)
+        out.backward(g)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    return dict(value=sample_b / med, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="B=%d of the same config (F=39,K=16,3x128), %d timed fwd+bwd steps after 1 warm-up, fp32, "
+                       "op-for-op torch-CPU restatement of the reference TF2 graph (TF not installable)" % (sample_b, steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from ml_function_amd import _lib
+    from ml_function_amd import functional as Fn
+    inp = make_inputs(rank, device)
+    flat, grads = make_bucket(inp, device)
+
+    def step():
+        out, pooled, saved = Fn.cin_forward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], inp["dense_b"], 1, 0)
+        Fn.cin_backward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], pooled, saved, inp["g"], 1, 0, grads=grads)
+        if world > 1:
+            dist.all_reduce(flat)  # sum of layer gradients over the data-parallel ranks (RCCL over xGMI)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_end()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B_PER_GPU * args.steps / dt
+        # dominant kernel = largest total time among the MFMA kernels
+        mf = {k: v for k, v in prof.items() if k.startswith(("cin_fwd_l", "cin_bwd_dw_l", "cin_bwd_dz_l"))}
+        dom = max(mf, key=lambda k: mf[k]["total_ms"])
+        d = mf[dom]
+        achieved = d["work"] / (d["avg_ms"] * 1e-3) / 1e12
+        kernels = {k: dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / args.steps,
+                           tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2) if k in mf else None)
+                   for k, v in sorted(prof.items())}
+        gpu_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
+        res = {
+            "metric": "samples/sec fwd+bwd xDeepFM-CIN B=4096,F=39,K=16",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "xDeepFM CIN 3x128 feature maps fwd+bwd, F=39 K=16, B=4096 per GPU, fp32 "
+                                   "(BASELINE.json configs[3])", "global_batch": world * B_PER_GPU,
+                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if world > 1 else 0},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["work"]},
+            "kernels": kernels, "gpu_kernel_ms_per_step": gpu_ms,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

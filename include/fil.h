@@ -39,6 +39,14 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 int fil_version(void);                 /* 10000*major + 100*minor + patch */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
+/* Opt-in per-kernel timing for bench.py's roofline line (off by default).  Between begin and end every major
+ * kernel launch made through this library is bracketed by HIP events recorded ON THE LAUNCH STREAM.
+ * fil_profile_end synchronises those events and writes one text line per kernel name into buf:
+ *   "<name> <launches> <total_ms> <algorithmic work per launch: flops for MFMA kernels, bytes for streaming>\n"
+ * and returns the number of bytes needed (including the NUL).  Not for use under graph capture. */
+int fil_profile_begin(void);
+size_t fil_profile_end(char* buf, size_t cap);
+
 /* ---------------------------------------------------------------------------------------------
  * A1  FM second order -- replaces InnerLayer.call + FmLayer.call
  *     interactive_layer/interactive_layer.py:59-66,161-170 (C(F,2) tf.multiply + Add + Add).

@@ -20,6 +20,8 @@ _F = _c.c_float
 SIGNATURES = {
     "fil_version": (_I, []),
     "fil_last_error": (_c.c_char_p, []),
+    "fil_profile_begin": (_I, []),
+    "fil_profile_end": (_Z, [_c.c_char_p, _Z]),
     "fil_fm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fil_fm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fil_fm_pairs_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -98,3 +100,19 @@ def int_array(vals):
 
 def ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def profile_begin():
+    load().fil_profile_begin()
+
+
+def profile_end():
+    """Returns {kernel name: dict(count, total_ms, avg_ms, work)} for the launches since profile_begin()."""
+    lib = load()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.fil_profile_end(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, count, ms, work = line.split()
+        out[name] = dict(count=int(count), total_ms=float(ms), avg_ms=float(ms) / max(int(count), 1), work=float(work))
+    return out

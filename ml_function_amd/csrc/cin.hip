@@ -583,6 +583,12 @@ static int check_shape(const char* fn, int B, int F, int K, int L, const int* H,
 
 static int chunks_of(int H) { return cdiv(H, 128); }
 
+static const char* kFwdNames[kCinMaxL] = {"cin_fwd_l1", "cin_fwd_l2", "cin_fwd_l3", "cin_fwd_l4", "cin_fwd_l5", "cin_fwd_l6", "cin_fwd_l7", "cin_fwd_l8"};
+static const char* kDwNames[kCinMaxL] = {"cin_bwd_dw_l1", "cin_bwd_dw_l2", "cin_bwd_dw_l3", "cin_bwd_dw_l4", "cin_bwd_dw_l5", "cin_bwd_dw_l6", "cin_bwd_dw_l7", "cin_bwd_dw_l8"};
+static const char* kDzNames[kCinMaxL] = {"cin_bwd_dz_l1", "cin_bwd_dz_l2", "cin_bwd_dz_l3", "cin_bwd_dz_l4", "cin_bwd_dz_l5", "cin_bwd_dz_l6", "cin_bwd_dz_l7", "cin_bwd_dz_l8"};
+// algorithmic flops of one layer GEMM: 2 * M * C * H
+static double gemm_flops(long M, int Hp, int F, int H) { return 2.0 * (double)M * Hp * F * H; }
+
 // number of m-range splits for the dW kernel: fill ~2 workgroups per CU
 static int dw_splits(const CinShape& s, int l) {
   const long C = (long)s.Hp(l) * s.F;
@@ -727,12 +733,18 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       xout = reinterpret_cast<float*>(sv);
       sv += align_up((size_t)B * H[l] * K * sizeof(float), 256);
     }
-    launch_fwd_layer(st, x, xp, W[l], bias[l], xout, part, M, F, K, s.Hp(l), H[l]);
+    {
+      ProfScope ps(kFwdNames[l], st, gemm_flops(M, s.Hp(l), F, H[l]));
+      launch_fwd_layer(st, x, xp, W[l], bias[l], xout, part, M, F, K, s.Hp(l), H[l]);
+    }
     FIL_CHECK_LAUNCH();
     xp = xout;
   }
-  hipLaunchKernelGGL(cin_head_fwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, pa, dense_w, dense_b, pooled,
-                     output_dim == 1 ? out : nullptr, B, K, L);
+  {
+    ProfScope ps("cin_head_fwd", st);
+    hipLaunchKernelGGL(cin_head_fwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, pa, dense_w, dense_b, pooled,
+                       output_dim == 1 ? out : nullptr, B, K, L);
+  }
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
@@ -808,6 +820,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   {
     const long total = (long)B * H[L - 1] * K;
     const int grid = (int)std::min<long>((total + 255) / 256, 4096);
+    ProfScope ps("cin_bcast_g", st, (double)total * sizeof(float));
     hipLaunchKernelGGL(cin_bcast_kernel, dim3(grid), dim3(256), 0, st, dPsrc + (size_t)(L - 1) * K, (int)LK, Gbuf[cur], B, H[L - 1], K);
     FIL_CHECK_LAUNCH();
   }
@@ -817,20 +830,32 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const float* xp = l == 0 ? x : maps[l - 1];
     const float* G = Gbuf[cur];
     // dbias
-    hipLaunchKernelGGL(cin_colsum_kernel, dim3(nblk), dim3(256), 0, st, G, small, B, Hl, K, kHeadChunk);
-    FIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cin_reduce_kernel, dim3(1), dim3(256), 0, st, small, dbias[l], (long)Hl, nblk);
+    {
+      ProfScope ps("cin_dbias", st, (double)B * Hl * K * sizeof(float));
+      hipLaunchKernelGGL(cin_colsum_kernel, dim3(nblk), dim3(256), 0, st, G, small, B, Hl, K, kHeadChunk);
+      hipLaunchKernelGGL(cin_reduce_kernel, dim3(1), dim3(256), 0, st, small, dbias[l], (long)Hl, nblk);
+    }
     FIL_CHECK_LAUNCH();
     // dW
-    const int parts = launch_dw(st, G, x, xp, part, B, F, K, Hp, Hl, dw_splits(s, l));
+    int parts;
+    {
+      ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl));
+      parts = launch_dw(st, G, x, xp, part, B, F, K, Hp, Hl, dw_splits(s, l));
+    }
     FIL_CHECK_LAUNCH();
     const long nW = (long)Hp * F * Hl;
-    hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)std::min<long>((nW + 255) / 256, 2048)), dim3(256), 0, st, part, dW[l], nW, parts);
+    {
+      ProfScope ps("cin_reduce_dw", st, (double)(parts + 1) * nW * sizeof(float));
+      hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)std::min<long>((nW + 255) / 256, 2048)), dim3(256), 0, st, part, dW[l], nW, parts);
+    }
     FIL_CHECK_LAUNCH();
     // dZ -> G^{l-1}, dX
     const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
-    launch_dz(st, G, W[l], x, xp, dPprev, (int)LK, l > 0 ? Gbuf[cur ^ 1] : nullptr, dx, /*accumulate=*/l != L - 1,
-              /*layer1=*/l == 0, M, F, K, Hp, Hl);
+    {
+      ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
+      launch_dz(st, G, W[l], x, xp, dPprev, (int)LK, l > 0 ? Gbuf[cur ^ 1] : nullptr, dx, /*accumulate=*/l != L - 1,
+                /*layer1=*/l == 0, M, F, K, Hp, Hl);
+    }
     FIL_CHECK_LAUNCH();
     cur ^= 1;
   }

@@ -29,6 +29,23 @@ int fail(int code, const char* fmt, ...);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Opt-in per-kernel timing (fil_profile_begin/_end in include/fil.h): when enabled, every major launch is
+// bracketed by a pair of HIP events recorded on the launch stream.  Off by default (zero overhead, capture-safe).
+bool prof_enabled();
+void prof_begin_scope(const char* name, hipStream_t st, double work);
+void prof_end_scope(hipStream_t st);
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  // work = algorithmic flops (MFMA kernels) or bytes (streaming kernels) of this launch, reported back verbatim
+  ProfScope(const char* name, hipStream_t s, double work = 0.0) : st(s), on(prof_enabled()) {
+    if (on) prof_begin_scope(name, st, work);
+  }
+  ~ProfScope() {
+    if (on) prof_end_scope(st);
+  }
+};
+
 // Carves consecutive 256-byte aligned regions out of a caller-provided workspace.
 struct Carver {
   char* base;

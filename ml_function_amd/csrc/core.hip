@@ -1,6 +1,12 @@
 // Error reporting + version for libfil_hip.so.
 #include "common.h"
 
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace fil {
 
 static thread_local char g_err[512] = "";
@@ -20,7 +26,81 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- opt-in kernel timing ------------------------------------------------------------------------
+struct ProfRec {
+  const char* name;
+  double work;
+  hipEvent_t e0, e1;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static size_t g_pool_next = 0;
+
+bool prof_enabled() { return g_prof_on; }
+
+static hipEvent_t pool_event() {
+  if (g_pool_next == g_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    g_pool.push_back(e);
+  }
+  return g_pool[g_pool_next++];
+}
+
+void prof_begin_scope(const char* name, hipStream_t st, double work) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{name, work, pool_event(), pool_event()};
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+}
+
+void prof_end_scope(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
+}
+
 }  // namespace fil
+
+extern "C" int fil_profile_begin(void) {
+  std::lock_guard<std::mutex> lk(fil::g_prof_mu);
+  fil::g_prof.clear();
+  fil::g_pool_next = 0;
+  fil::g_prof_on = true;
+  return FIL_OK;
+}
+
+// Writes one line per kernel name: "name count total_ms work_per_launch\n"; returns bytes needed (incl. NUL).
+extern "C" size_t fil_profile_end(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(fil::g_prof_mu);
+  fil::g_prof_on = false;
+  struct Agg { std::string name; long count; double ms; double work; };
+  std::vector<Agg> aggs;
+  for (auto& r : fil::g_prof) {
+    (void)hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+    Agg* a = nullptr;
+    for (auto& x : aggs) if (x.name == r.name) { a = &x; break; }
+    if (!a) { aggs.push_back(Agg{r.name, 0, 0.0, r.work}); a = &aggs.back(); }
+    a->count += 1;
+    a->ms += ms;
+  }
+  std::string out;
+  char line[256];
+  for (auto& a : aggs) {
+    snprintf(line, sizeof(line), "%s %ld %.6f %.6e\n", a.name.c_str(), a.count, a.ms, a.work);
+    out += line;
+  }
+  fil::g_prof.clear();
+  if (buf && cap > 0) {
+    const size_t n = std::min(cap - 1, out.size());
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}
 
 extern "C" int fil_version(void) { return 100; }  // 0.1.0
 extern "C" const char* fil_last_error(void) { return fil::g_err; }

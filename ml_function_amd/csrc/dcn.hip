@@ -245,6 +245,7 @@ extern "C" int fil_dcn_fwd(const float* x, const float* w, const float* b, float
   if (psz > kDcnLdsLimit) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: 2*L*D*4 = %zu bytes of w,b exceed the 160 KiB LDS", psz);
   const int grid = dcn_grid(B);
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps("dcn_fwd", st, (double)B * 2.0 * D * sizeof(float));
 #define FWD_VEC(N) launch_fwd<N, 4>(grid, psz, st, x, w, b, y, s, B, D, L)
 #define FWD_SCALAR(N) launch_fwd<N, 1>(grid, psz, st, x, w, b, y, s, B, D, L)
   FIL_DCN_DISPATCH(npl, FWD_VEC, FWD_SCALAR)
@@ -289,6 +290,7 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
   const int grid = dcn_grid(B);
   float* partial = static_cast<float*>(workspace);
   int rc = 0;
+  ProfScope ps("dcn_bwd", st, (double)B * 3.0 * D * sizeof(float));
 #define BWD_VEC(N) rc = launch_bwd<N, 4>(L, grid, sh, st, x, w, b, s, g, dx, partial, B, D)
 #define BWD_SCALAR(N) rc = launch_bwd<N, 1>(L, grid, sh, st, x, w, b, s, g, dx, partial, B, D)
   FIL_DCN_DISPATCH(npl, BWD_VEC, BWD_SCALAR)

@@ -208,6 +208,8 @@ extern "C" int fil_fm_fwd(const void* emb, const float* lin, void* out, int B, i
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(emb != nullptr && out != nullptr);
   hipStream_t st = (hipStream_t)stream;
+  const double esz = dtype == FIL_F32 ? 4.0 : 2.0;
+  ProfScope ps("fm_fwd", st, (double)B * ((double)F * K * esz + K * esz + (lin ? F * 4.0 : 0.0)));
   if (dtype == FIL_F32) launch_fm<float>(true, emb, lin, out, nullptr, B, F, K, st);
   else launch_fm<__hip_bfloat16>(true, emb, lin, out, nullptr, B, F, K, st);
   FIL_CHECK_LAUNCH();
@@ -221,6 +223,8 @@ extern "C" int fil_fm_bwd(const void* emb, const void* g, void* demb, float* dli
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(emb != nullptr && g != nullptr && demb != nullptr);
   hipStream_t st = (hipStream_t)stream;
+  const double esz = dtype == FIL_F32 ? 4.0 : 2.0;
+  ProfScope ps("fm_bwd", st, (double)B * (2.0 * F * K * esz + K * esz + (dlin ? F * 4.0 : 0.0)));
   if (dtype == FIL_F32) launch_fm<float>(false, emb, g, demb, dlin, B, F, K, st);
   else launch_fm<__hip_bfloat16>(false, emb, g, demb, dlin, B, F, K, st);
   FIL_CHECK_LAUNCH();
