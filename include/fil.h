@@ -102,19 +102,23 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *     (core_layer/core_layer.py:204-216), fused; the [H,B,F,F] score tensor is never materialised.
  *   x [B,F,K]; Wq, Wk, Wr [K,H,A] (V is projected with Wk, as the reference does; Wr may be NULL = use_res off);
  *   gamma, beta [A] (NULL = use_ln off); eps = 1e-3 for Keras parity; scale = 1/sqrt(A) (use_scale) or 1.
- *   y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale * q k^T) k)).
- *   bwd: dy [H,B,F,A] -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
- *   Limits: K <= 64, A in {8,16,32}, H*A <= 256.
+ *   fuse_relu != 0 (the DnnLayer(res_unit=1, other_dense=[layer]) wrapper AutoInt uses):
+ *       y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale * q k^T) k)),  res_out ignored.
+ *   fuse_relu == 0 (MultHeadAttentionLayer.call as a stand-alone layer, which returns [atten_v, res]):
+ *       y = LN(sigmoid(scale * q k^T) k),  res_out [H,B,F,A] = x Wr (may be NULL).
+ *   bwd: dy [H,B,F,A] (and, when fuse_relu == 0 and Wr != NULL, dres_in [H,B,F,A] = gradient of res_out)
+ *        -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
+ *   Limits: K <= 64, A <= 16, F <= 512 (and the LDS footprint <= 160 KiB).
  */
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A);
 int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                 const float* beta, float* y, int B, int F, int K, int H, int A, float scale, float eps,
-                 void* workspace, size_t workspace_bytes, void* stream);
+                 const float* beta, float* y, float* res_out, int B, int F, int K, int H, int A, float scale,
+                 float eps, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
 int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                 const float* beta, const float* dy, float* dx, float* dWq, float* dWk, float* dWr, float* dgamma,
-                 float* dbeta, int B, int F, int K, int H, int A, float scale, float eps, void* workspace,
-                 size_t workspace_bytes, void* stream);
+                 const float* beta, const float* dy, const float* dres_in, float* dx, float* dWq, float* dWk,
+                 float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H, int A, float scale, float eps,
+                 int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,

@@ -168,6 +168,101 @@ __global__ __launch_bounds__(kDcnThreads) void dcn_bwd_kernel(const float* __res
   }
 }
 
+// ---- generic backward for shapes whose per-lane accumulators do not fit the register file ---------------
+// The backward recurrence only needs per-sample SCALARS besides elementwise work:
+//   gx_l = g + sum_{t>l} w_t ds_t   =>   ds_l = g.x0 + sum_{t>l} ds_t (w_t.x0)
+// pass 1 (wave per sample): a0 = g.x0, c_t = w_t.x0, then the scalar recurrence -> ds[n,l]
+// pass 2 (thread per column d, loop over a chunk of samples): everything is elementwise given s[n,:], ds[n,:];
+//         dw/db accumulate in 2*L registers per column; chunk partials are reduced by dcn_reduce_kernel.
+constexpr int kDcnMaxL = 6;
+
+__global__ __launch_bounds__(256) void dcn_bwd_scalars_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ g, float* __restrict__ ds, int B, int D,
+                                                              int L) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+    float acc[kDcnMaxL + 1];
+#pragma unroll
+    for (int i = 0; i <= kDcnMaxL; ++i) acc[i] = 0.f;
+    const float* xr = x + (long)n * D;
+    const float* gr = g + (long)n * D;
+    for (int d = lane; d < D; d += 64) {
+      const float xv = xr[d];
+      acc[0] = fmaf(gr[d], xv, acc[0]);
+#pragma unroll
+      for (int t = 0; t < kDcnMaxL; ++t)
+        if (t < L) acc[t + 1] = fmaf(w[(long)t * D + d], xv, acc[t + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i <= kDcnMaxL; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+      float dsv[kDcnMaxL];
+#pragma unroll
+      for (int l = kDcnMaxL - 1; l >= 0; --l) {
+        if (l < L) {
+          float t = acc[0];
+#pragma unroll
+          for (int u = l + 1; u < kDcnMaxL; ++u)
+            if (u < L) t = fmaf(dsv[u], acc[u + 1], t);
+          dsv[l] = t;
+          ds[(long)n * L + l] = t;
+        } else {
+          dsv[l] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, const float* __restrict__ s,
+                                                           const float* __restrict__ ds, const float* __restrict__ g,
+                                                           float* __restrict__ dx, float* __restrict__ partial, int B, int D, int L,
+                                                           int nchunk) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_lo = blockIdx.y * nchunk, n_hi = min(B, n_lo + nchunk);
+  float wl[kDcnMaxL], bl[kDcnMaxL], dwacc[kDcnMaxL], dbacc[kDcnMaxL];
+#pragma unroll
+  for (int l = 0; l < kDcnMaxL; ++l) {
+    wl[l] = (d < D && l < L) ? w[(long)l * D + d] : 0.f;
+    bl[l] = (d < D && l < L) ? b[(long)l * D + d] : 0.f;
+    dwacc[l] = dbacc[l] = 0.f;
+  }
+  if (d < D) {
+    for (int n = n_lo; n < n_hi; ++n) {
+      const float x0 = x[(long)n * D + d];
+      float gx = g[(long)n * D + d];
+      float xl[kDcnMaxL];
+      float cur = x0;
+#pragma unroll
+      for (int l = 0; l < kDcnMaxL; ++l) {
+        xl[l] = cur;
+        if (l < L) cur = fmaf(x0, s[(long)n * L + l], cur) + bl[l];
+      }
+      float dx0 = 0.f;
+#pragma unroll
+      for (int l = kDcnMaxL - 1; l >= 0; --l) {
+        if (l < L) {
+          const float dsl = ds[(long)n * L + l];
+          dbacc[l] += gx;
+          dx0 = fmaf(gx, s[(long)n * L + l], dx0);
+          dwacc[l] = fmaf(xl[l], dsl, dwacc[l]);
+          gx = fmaf(wl[l], dsl, gx);
+        }
+      }
+      dx[(long)n * D + d] = dx0 + gx;
+    }
+    float* pout = partial + (long)blockIdx.y * 2 * L * D;
+#pragma unroll
+    for (int l = 0; l < kDcnMaxL; ++l) {
+      if (l < L) {
+        pout[(long)l * D + d] = dwacc[l];
+        pout[(long)(L + l) * D + d] = dbacc[l];
+      }
+    }
+  }
+}
+
 // out[i] = sum over `parts` partials (fixed order); n = elements per partial.
 __global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                          float* __restrict__ db, int parts, int LD) {
@@ -255,9 +350,17 @@ extern "C" int fil_dcn_fwd(const float* x, const float* w, const float* b, float
   return FIL_OK;
 }
 
+static bool dcn_register_path(int D, int L) {
+  const int npl = pick_npl(D, D % 4 == 0);
+  // per-lane accumulators are 2*L*NPL registers (+5*NPL of sample state): stay inside the 512-register file
+  return npl > 0 && 2 * L * npl + 5 * npl <= 440 && std::max((size_t)2 * L * D, (size_t)kDcnWaves * D) * sizeof(float) <= kDcnLdsLimit;
+}
+static int dcn_generic_chunks(int B) { return std::max(1, std::min(cdiv(B, 32), 64)); }
+
 extern "C" size_t fil_dcn_bwd_workspace_bytes(int B, int D, int L) {
   if (B <= 0 || D <= 0 || L <= 0) return 0;
-  return align_up((size_t)dcn_grid(B) * 2 * L * D * sizeof(float), 256);
+  if (dcn_register_path(D, L)) return align_up((size_t)dcn_grid(B) * 2 * L * D * sizeof(float), 256);
+  return align_up((size_t)B * L * sizeof(float), 256) + align_up((size_t)dcn_generic_chunks(B) * 2 * L * D * sizeof(float), 256);
 }
 
 extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, const float* g, float* dx,
@@ -277,12 +380,25 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
   if (workspace == nullptr || workspace_bytes < fil_dcn_bwd_workspace_bytes(B, D, L))
     return fail(FIL_ERR_WORKSPACE, "fil_dcn_bwd: workspace %zu < %zu bytes", workspace_bytes,
                 fil_dcn_bwd_workspace_bytes(B, D, L));
+  if (!dcn_register_path(D, L)) {
+    // generic two-pass backward (any D, L <= 6): scalars per sample, then column-wise accumulation
+    Carver wsc(workspace);
+    float* dsbuf = wsc.take<float>((size_t)B * L);
+    float* partial = wsc.take<float>((size_t)dcn_generic_chunks(B) * 2 * L * D);
+    ProfScope ps("dcn_bwd_generic", st, (double)B * 5.0 * D * sizeof(float));
+    hipLaunchKernelGGL(dcn_bwd_scalars_kernel, dim3(std::min(cdiv(B, 4), 2048)), dim3(256), 0, st, x, w, g, dsbuf, B, D, L);
+    FIL_CHECK_LAUNCH();
+    const int chunks = dcn_generic_chunks(B);
+    const int nchunk = cdiv(B, chunks);
+    const dim3 grid(cdiv(D, 256), cdiv(B, nchunk));
+    hipLaunchKernelGGL(dcn_bwd_cols_kernel, grid, dim3(256), 0, st, x, w, b, s, dsbuf, g, dx, partial, B, D, L, nchunk);
+    FIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 256)), dim3(256), 0, st, partial, dw, db, (int)grid.y, L * D);
+    FIL_CHECK_LAUNCH();
+    return FIL_OK;
+  }
   const bool vec = (D % 4 == 0);
   const int npl = pick_npl(D, vec);
-  // per-lane accumulators are 2*L*NPL registers (+5*NPL of sample state): stay inside the 512-register file
-  if (2 * L * npl + 5 * npl > 440)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: L=%d x D=%d needs %d registers per lane (limit 440)", L, D,
-                2 * L * npl + 5 * npl);
   const size_t psz = (size_t)2 * L * D * sizeof(float);
   const size_t red = (size_t)kDcnWaves * D * sizeof(float);
   const size_t sh = std::max(psz, red);

@@ -217,25 +217,32 @@ def cin(x, Ws, bs, dense_w=None, dense_b=None, output_dim=1, mode=0):
 
 # --------------------------------------------------------------------------------------------- A4  AutoInt
 class _AttnFn(torch.autograd.Function):
+    """fuse_relu=True: returns y = relu(res + LN(av)); fuse_relu=False: returns (LN(av), res)."""
+
     @staticmethod
-    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps):
+    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps, fuse_relu):
         _require_cuda(x, Wq, Wk, Wr, gamma, beta)
         x, Wq, Wk, Wr, gamma, beta = [_f32c(t) for t in (x, Wq, Wk, Wr, gamma, beta)]
         B, F, K = x.shape
         _, H, A = Wq.shape
         lib = _lib.load()
         y = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
-        nws = lib.fil_attn_fwd_workspace_bytes(B, F, K, H, A)
-        ws = _workspace(nws, x.device)
-        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), B, F, K, H, A,
-                               float(scale), float(eps), ptr(ws), nws, stream_ptr()), "fil_attn_fwd")
+        res = None
+        if not fuse_relu and Wr is not None:
+            res = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
+        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), B, F, K, H, A,
+                               float(scale), float(eps), int(bool(fuse_relu)), None, 0, stream_ptr()), "fil_attn_fwd")
         ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None])
-        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps))
-        return y
+        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu))
+        if fuse_relu:
+            return y
+        if res is None:
+            return y, None
+        return y, res
 
     @staticmethod
-    def backward(ctx, dy):
-        has_res, has_ln, scale, eps = ctx.cfg
+    def backward(ctx, dy, dres=None):
+        has_res, has_ln, scale, eps, fuse_relu = ctx.cfg
         sv = list(ctx.saved_tensors)
         x, Wq, Wk = sv[:3]
         rest = sv[3:]
@@ -245,7 +252,10 @@ class _AttnFn(torch.autograd.Function):
         B, F, K = x.shape
         _, H, A = Wq.shape
         lib = _lib.load()
-        dy = _f32c(dy)
+        dy = _f32c(dy) if dy is not None else torch.zeros((H, B, F, A), dtype=torch.float32, device=x.device)
+        dres_in = None
+        if not fuse_relu and has_res:
+            dres_in = _f32c(dres) if dres is not None else torch.zeros((H, B, F, A), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
         dWq, dWk = torch.empty_like(Wq), torch.empty_like(Wk)
         dWr = torch.empty_like(Wr) if has_res else None
@@ -253,17 +263,24 @@ class _AttnFn(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if has_ln else None
         nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A)
         ws = _workspace(nws, x.device)
-        check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dx), ptr(dWq),
-                               ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps, ptr(ws), nws,
-                               stream_ptr()), "fil_attn_bwd")
-        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None
+        check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(dx),
+                               ptr(dWq), ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps,
+                               int(fuse_relu), ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
+        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None
+
+
+def _attn_scale(Wq, use_scale):
+    return (1.0 / (Wq.shape[-1] ** 0.5)) if use_scale else 1.0
 
 
 def autoint_interact(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3):
     """x [B,F,K], W* [K,H,A] -> y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale q k^T) k))  (V == K projection)."""
-    A = Wq.shape[-1]
-    scale = (1.0 / (A ** 0.5)) if use_scale else 1.0
-    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, scale, eps)
+    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, True)
+
+
+def mult_head_attention(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3):
+    """Stand-alone MultHeadAttentionLayer: returns (atten_v [H,B,F,A] = LN(sigmoid(scale q k^T) k), res = x Wr or None)."""
+    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, False)
 
 
 # --------------------------------------------------------------------------------------------- N1  embeddings
