@@ -1,0 +1,73 @@
+"""Data parallelism for the interaction layers: one process per GPU, batch rows sharded, ONE collective per step.
+
+Every layer on the hot path is independent across the batch axis, so rank r takes rows
+[r*B/N, (r+1)*B/N) of the inputs and of the upstream gradient, parameters are replicated, and the only exchange is
+a sum all-reduce of the dense parameter gradients (RCCL over xGMI through torch.distributed's "nccl" backend;
+"gloo" in the CPU tests).  Gradients are written by the kernels straight into one flat fp32 bucket, so the
+all-reduce is a single call with no packing copies (CIN at the north-star shape: 1,473,073 floats = 5.9 MB).
+The reference has no distributed code at all; this module is net-new.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, rank, world):
+    """Contiguous, balanced row range of `rank`: sizes differ by at most one row."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_rows(t, rank=None, world=None):
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    lo, hi = shard_bounds(t.shape[0], rank, world)
+    return t[lo:hi]
+
+
+class GradBucket:
+    """One flat fp32 buffer holding the gradients of `params` back to back; .views[i] aliases params[i]'s slot."""
+
+    def __init__(self, shapes, device):
+        self.shapes = [tuple(s) for s in shapes]
+        sizes = [int(torch.Size(s).numel()) for s in self.shapes]
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        self.views = []
+        off = 0
+        for s, n in zip(self.shapes, sizes):
+            self.views.append(self.flat[off:off + n].view(s))
+            off += n
+
+    @classmethod
+    def for_params(cls, params):
+        params = list(params)
+        return cls([p.shape for p in params], params[0].device)
+
+    def nbytes(self):
+        return self.flat.numel() * 4
+
+    def all_reduce(self, group=None, async_op=False):
+        """Sum over the data-parallel ranks (gradients of a summed loss add up; divide by world for a mean loss)."""
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return None
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    def copy_from_grads(self, params):
+        for v, p in zip(self.views, params):
+            v.copy_(p.grad if p.grad is not None else torch.zeros_like(v))
+
+    def assign_to_grads(self, params):
+        for v, p in zip(self.views, params):
+            p.grad = v
+
+
+def allreduce_module_grads(module, group=None):
+    """Bucketed all-reduce of the gradients of every parameter of `module` (after backward)."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return None
+    bucket = GradBucket.for_params(params)
+    bucket.copy_from_grads(params)
+    bucket.all_reduce(group)
+    bucket.assign_to_grads(params)
+    return bucket

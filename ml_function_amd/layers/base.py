@@ -1,0 +1,102 @@
+"""Keras-style layer protocol on torch.nn.Module.
+
+The reference's only "plugin API" is the tf.keras.layers.Layer protocol: ``__init__`` stores
+hyper-parameters, ``build(input_shape)`` runs lazily on the first call and creates weights with
+``add_weight(name, shape, initializer)``, ``call(inputs, **kwargs)`` is pure.  This base class reproduces that
+lifecycle so the re-hosted layers keep the reference's constructor kwargs, weight names and call signatures.
+"""
+import math
+
+import torch
+
+
+def shape_of(inputs):
+    """Keras-like input_shape: a tuple for a tensor, a list of shapes for a list of tensors (nested lists allowed)."""
+    if isinstance(inputs, (list, tuple)):
+        return [shape_of(t) for t in inputs]
+    return tuple(inputs.shape)
+
+
+def first_tensor(inputs):
+    if isinstance(inputs, (list, tuple)):
+        for t in inputs:
+            r = first_tensor(t)
+            if r is not None:
+                return r
+        return None
+    return inputs
+
+
+def glorot_uniform_(tensor, seed=None):
+    """Keras glorot_uniform: U(-l, l), l = sqrt(6 / (fan_in + fan_out)); rank>2 uses the receptive-field rule.
+    (TF's RNG stream cannot be matched; parity tests pass explicit weights.)"""
+    shape = tuple(tensor.shape)
+    if len(shape) < 1:
+        fan_in = fan_out = 1
+    elif len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = 1
+        for d in shape[:-2]:
+            rf *= d
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    gen = None
+    if seed is not None:
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(int(seed))
+    with torch.no_grad():
+        vals = (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * lim
+        tensor.copy_(vals.to(tensor.device))
+    return tensor
+
+
+class Layer(torch.nn.Module):
+    """tf.keras.layers.Layer lifecycle: lazy build() on first __call__, weights via add_weight()."""
+
+    def __init__(self, name=None, **kwargs):
+        super().__init__()
+        if kwargs:
+            raise TypeError("unexpected keyword arguments: %s" % sorted(kwargs))
+        self.built = False
+        self.layer_name = name
+        self._build_device = None
+
+    # -- Keras protocol -------------------------------------------------------------------------------------
+    def build(self, input_shape):
+        self.built = True
+
+    def call(self, inputs, **kwargs):
+        raise NotImplementedError
+
+    def add_weight(self, name, shape, initializer="glorot_uniform", trainable=True, seed=None):
+        shape = tuple(int(s) for s in shape)
+        p = torch.nn.Parameter(torch.empty(shape, dtype=torch.float32, device=self._build_device), requires_grad=trainable)
+        if callable(initializer):
+            initializer(p)
+        elif initializer in ("zeros", "zero"):
+            torch.nn.init.zeros_(p)
+        elif initializer in ("ones", "one"):
+            torch.nn.init.ones_(p)
+        elif initializer == "glorot_uniform":
+            glorot_uniform_(p, seed=seed)
+        elif initializer == "random_normal":
+            torch.nn.init.normal_(p, mean=0.0, std=0.05)  # Keras RandomNormal default stddev
+        else:
+            raise ValueError("unknown initializer %r" % (initializer,))
+        self.register_parameter(name, p)
+        return p
+
+    # -- torch glue -----------------------------------------------------------------------------------------
+    def forward(self, inputs, **kwargs):
+        if not self.built:
+            t = first_tensor(inputs)
+            self._build_device = t.device if t is not None else None
+            self.build(shape_of(inputs))
+            self.built = True
+        return self.call(inputs, **kwargs)
+
+    def compute_mask(self, inputs, mask=None):
+        return mask

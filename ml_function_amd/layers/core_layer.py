@@ -1,0 +1,215 @@
+"""Glue layers around the interaction kernels: the re-host of the reference's core_layer.py
+(StackLayer :32, ScoreLayer :58, MergeScoreLayer :86, HiddenLayer :102, ResActivateLayer :131, DnnLayer :159).
+Dense layers are plain GEMMs and go through torch (hipBLASLt); the AutoInt wrapper path of DnnLayer dispatches to
+the fused attention kernel."""
+import torch
+
+from .base import Layer, glorot_uniform_
+from .behavior_layer import MultHeadAttentionLayer
+from .interactive_layer import InnerLayer
+
+
+def keras_add(tensors):
+    """tf.keras.layers.Add: left-to-right sum; raises ValueError when shapes are not broadcast-compatible or an
+    element is not a tensor (DnnLayer relies on that to skip the residual, core_layer.py:211-214)."""
+    out = None
+    for t in tensors:
+        if not torch.is_tensor(t):
+            raise ValueError("Add expects tensors")
+        if out is None:
+            out = t
+            continue
+        try:
+            torch.broadcast_shapes(out.shape, t.shape)
+        except RuntimeError as e:
+            raise ValueError(str(e))
+        out = out + t
+    if out is None:
+        raise ValueError("Add of an empty list")
+    return out
+
+
+class Dense(Layer):
+    """tf.keras.layers.Dense(units, activation=None): kernel [in, units] glorot_uniform, bias [units]."""
+
+    def __init__(self, units, activation=None, seed=None, bias_initializer="zeros"):
+        super().__init__()
+        self.units = units
+        self.activation = activation
+        self.seed = seed
+        self.bias_initializer = bias_initializer
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight("kernel", [input_shape[-1], self.units], "glorot_uniform", seed=self.seed)
+        self.bias = self.add_weight("bias", [self.units], self.bias_initializer, seed=self.seed)
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        y = torch.matmul(inputs, self.kernel) + self.bias
+        if self.activation == "softmax":
+            y = torch.softmax(y, dim=-1)
+        elif self.activation == "sigmoid":
+            y = torch.sigmoid(y)
+        elif self.activation is not None:
+            y = self.activation(y)
+        return y
+
+
+class StackLayer(Layer):
+    """Flatten each input (use_flat) and concatenate along `axis` (default last); a single input passes through."""
+
+    def __init__(self, use_flat=True, axis=None):
+        super().__init__()
+        self.use_flat = use_flat
+        self.axis = axis if axis else -1  # the reference treats axis=None/0 as the Concatenate default (-1)
+
+    def call(self, inputs, **kwargs):
+        if self.use_flat:
+            inputs = [t.reshape(t.shape[0], -1) for t in inputs]
+        if len(inputs) == 1:
+            return inputs[0]
+        return torch.cat(list(inputs), dim=self.axis)
+
+
+class ScoreLayer(Layer):
+    def __init__(self, use_add=False, use_inner=False, use_global=False, seed=2020):
+        super().__init__()
+        self.use_add = use_add
+        self.use_inner = use_inner
+        self.inner = InnerLayer(use_inner=True)
+        self.use_global = use_global
+        self.seed = seed
+
+    def build(self, input_shape):
+        if self.use_global:
+            self.global_bias = self.add_weight("global_bias", (1,), "glorot_uniform", seed=self.seed)
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        if self.use_add:
+            inputs = keras_add(list(inputs))
+            if self.use_global:
+                inputs = keras_add([inputs, self.global_bias])
+        if self.use_inner:
+            inputs = self.inner(inputs)
+        return torch.sigmoid(inputs)
+
+
+class MergeScoreLayer(Layer):
+    def __init__(self, use_merge: bool = True, output_dim=2):
+        super().__init__()
+        self.concat = StackLayer()
+        self.dense = Dense(units=output_dim, activation="softmax")
+        self.use_merge = use_merge
+
+    def call(self, inputs, **kwargs):
+        if self.use_merge:
+            inputs = self.concat(inputs)
+        return self.dense(inputs)
+
+
+class HiddenLayer(Layer):
+    """Dense(hidden_units) with glorot_uniform(seed) kernel AND bias (core_layer.py:111-116), optional BatchNorm;
+    call returns (x, inputs).  other_dense replaces the Dense (e.g. by a MultHeadAttentionLayer)."""
+
+    def __init__(self, hidden_units: int, use_bn: bool = True, seed=2020, l2_reg=0, other_dense=None):
+        super().__init__()
+        self.dense = other_dense if other_dense else Dense(hidden_units, seed=seed, bias_initializer="glorot_uniform")
+        self.use_bn = use_bn
+        self.l2_reg = l2_reg
+        self.bn = None
+
+    def call(self, inputs, **kwargs):
+        x = self.dense(inputs)
+        if self.use_bn:
+            if self.bn is None:
+                self.bn = torch.nn.BatchNorm1d(x.shape[-1], eps=1e-3, momentum=0.01).to(x.device)
+            x = self.bn(x)
+        return x, inputs
+
+
+class ResActivateLayer(Layer):
+    def __init__(self, use_bn, use_ln, hidden_activate):
+        super().__init__()
+        self.use_bn = use_bn
+        self.use_ln = use_ln
+        self.active = hidden_activate
+        self.bn = None
+        self.ln = None
+
+    def call(self, inputs, **kwargs):
+        if self.use_bn:
+            if self.bn is None:
+                self.bn = torch.nn.BatchNorm1d(inputs.shape[-1], eps=1e-3, momentum=0.01).to(inputs.device)
+            inputs = self.bn(inputs)
+        if self.use_ln:
+            if self.ln is None:
+                self.ln = torch.nn.LayerNorm(inputs.shape[-1], eps=1e-3).to(inputs.device)
+            inputs = self.ln(inputs)
+        return self.active(inputs)
+
+
+class DnnLayer(Layer):
+    """DnnLayer (core_layer.py:159-226): a stack of hidden layers with a residual Add every `res_unit` layers
+    (skipped when the shapes do not broadcast, :211-214), an activation block per layer and an optional logit head.
+
+    AutoInt builds DnnLayer(res_unit=1, other_dense=[MultHeadAttentionLayer]): that path is one fused HIP kernel
+    (projection, sigmoid attention, LayerNorm, residual add, ReLU)."""
+
+    def __init__(self, hidden_units: list = None, l2_reg=0, hidden_activate=None, use_bn: bool = False, res_unit=1,
+                 output_dim=-1, seed=2020, other_dense=None, use_ln: bool = False, use_flatten=False, **kwargs):
+        super().__init__(**kwargs)
+        if hidden_activate is None:
+            hidden_activate = torch.nn.ReLU()
+        self.hidden_list = other_dense
+        if not other_dense:
+            self.hidden_list = [HiddenLayer(hidden_units=dim, use_bn=False, other_dense=other_dense) for dim in hidden_units]
+        self.hidden_modules = torch.nn.ModuleList(self.hidden_list)
+        self.hidden_activate = hidden_activate
+        self.activate = torch.nn.ModuleList(
+            [ResActivateLayer(use_bn=use_bn, use_ln=use_ln, hidden_activate=hidden_activate) for _ in self.hidden_list])
+        self.seed = 2020
+        self.output_dim = output_dim
+        self.res_unit = res_unit
+        self.use_bn = use_bn
+        self.use_ln = use_ln
+        if output_dim != -1:
+            self.logit_layer = Dense(units=output_dim, seed=seed, bias_initializer="glorot_uniform")
+        self.use_flatten = use_flatten
+
+    def _fusable(self):
+        return (len(self.hidden_list) == 1 and isinstance(self.hidden_list[0], MultHeadAttentionLayer)
+                and self.res_unit == 1 and not self.use_bn and not self.use_ln
+                and isinstance(self.hidden_activate, torch.nn.ReLU) and not self.hidden_list[0].head_concat
+                and self.hidden_list[0].attention_head_dim > 1)
+
+    def call(self, inputs, **kwargs):
+        x = inputs
+        if self._fusable():
+            layer = self.hidden_list[0]
+            if not layer.built:
+                layer._build_device = x.device
+                layer.build(tuple(x.shape))
+                layer.built = True
+            x = layer.fused_relu(x)
+        else:
+            res = [[], []]
+            for idx_, hidden_layer in enumerate(self.hidden_list):
+                x, ori = hidden_layer(x)
+                if idx_ == 0:
+                    res = [ori, x]
+                if (idx_ + 1) % self.res_unit != 0 or self.res_unit == 1:
+                    res[-1] = x
+                if (idx_ + 1) % self.res_unit == 0:
+                    try:
+                        x = keras_add(res)
+                    except ValueError:
+                        x = res[-1]
+                x = self.activate[idx_](x)
+                if (idx_ + 1) % self.res_unit == 0:
+                    res[0] = x
+        if self.use_flatten:
+            x = x.reshape(x.shape[0], -1)
+        if self.output_dim != -1:
+            x = self.logit_layer(x)
+        return x

@@ -1,0 +1,199 @@
+"""Feature-interaction layers: the MI355X re-host of the reference's
+kon/model/ctr_model/layer/interactive_layer/interactive_layer.py (InnerLayer :34, FmLayer :145, SparseEmbed :189,
+CrossLayer :250, CIN :285).  Same constructor kwargs, weight names, call signatures and output shapes; the
+per-batch arithmetic runs in the HIP kernels behind include/fil.h (no CPU fallback).
+
+Packed [B,F,K] is the native layout; the reference's Python lists of F tensors [B,1,K] are accepted and stacked.
+"""
+import torch
+
+from .. import functional as Fn
+from .base import Layer, glorot_uniform_
+
+
+def pack_fields(inputs):
+    """list of F tensors [B,1,K] (or [B,K]) -> [B,F,K]; a packed tensor passes through."""
+    if isinstance(inputs, (list, tuple)):
+        ts = [t if t.dim() == 3 else t.unsqueeze(1) for t in inputs]
+        return ts[0] if len(ts) == 1 else torch.cat(ts, dim=1)
+    return inputs
+
+
+def pack_linear(inputs, batch):
+    """list of tensors [B,1,1] / [B,1] / [B] (or a packed [B,n(,1)]) -> [B,n]; empty list -> None."""
+    if isinstance(inputs, (list, tuple)):
+        if len(inputs) == 0:
+            return None
+        return torch.cat([t.reshape(batch, -1) for t in inputs], dim=1)
+    return inputs.reshape(batch, -1)
+
+
+class InnerLayer(Layer):
+    """InnerLayer (interactive_layer.py:34-66): pairwise products of the field embeddings.
+
+    call(list of F [B,1,K]) -> list of C(F,2) tensors [B,1,K] in itertools.combinations order, or their sum
+    [B,1,K] when use_add.  use_inner=False reads an attribute the reference never defines (``self.dot``, :56,63),
+    so it raises AttributeError there; the same error is raised here.
+    """
+
+    def __init__(self, use_inner: bool = True, mod=1, seed=2020, perm=None, use_add=False):
+        super().__init__()
+        self.use_inner = use_inner
+        self.mod = mod
+        self.seed = seed
+        self.perm = perm
+        self.use_add = use_add
+
+    def call(self, inputs, **kwargs):
+        if not self.use_inner:
+            raise AttributeError("'InnerLayer' object has no attribute 'dot' (the reference's use_inner=False branch "
+                                 "reads self.dot, which is commented out at interactive_layer.py:56)")
+        emb = pack_fields(inputs)
+        if self.use_add:
+            return Fn.fm(emb, None).unsqueeze(1)
+        pairs = Fn.fm_pairs(emb)
+        return list(pairs.split(1, dim=1))
+
+
+class FmLayer(Layer):
+    """FmLayer (interactive_layer.py:145-170): call([cross_embed, linear_embed]) -> [B,1,K] =
+    sum_{i<j} e_i*e_j + the broadcast sum of the linear terms (no reduction over K)."""
+
+    def __init__(self, use_inner: bool = True, mod=1, use_add=True, **kwargs):
+        super().__init__(**kwargs)
+        self.cross = InnerLayer(use_inner=use_inner, mod=mod, use_add=use_add)
+        self.use_add = use_add
+
+    def call(self, inputs, **kwargs):
+        cross_embed, linear_embed = inputs
+        if not self.use_add:
+            # reference: Add([list_of_pairs] + linear) -> Keras raises on the nested list
+            raise ValueError("FmLayer(use_add=False): the reference passes a nested list to keras Add and fails")
+        if not self.cross.use_inner:
+            return self.cross(cross_embed)  # raises like the reference
+        emb = pack_fields(cross_embed)
+        lin = pack_linear(linear_embed, emb.shape[0])
+        return Fn.fm(emb, lin).unsqueeze(1)
+
+
+class CrossLayer(Layer):
+    """DCN cross network (interactive_layer.py:250-282).  build creates outer_weight_i / outer_bias_i [D,1]
+    (glorot_uniform(seed) / zeros); call(x [B,D]) -> [B,D,1] (not squeezed, like the reference)."""
+
+    def __init__(self, cross_hidden=3, seed=2020, **kwargs):
+        super().__init__(**kwargs)
+        self.cross_hidden = cross_hidden
+        self.seed = seed
+
+    def build(self, input_shape):
+        d = input_shape[-1]
+        self.kernel = [self.add_weight("outer_weight_{}".format(i), [d, 1], "glorot_uniform", seed=self.seed)
+                       for i in range(self.cross_hidden)]
+        self.bias = [self.add_weight("outer_bias_{}".format(i), [d, 1], "zeros") for i in range(self.cross_hidden)]
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        w = torch.cat([k.t() for k in self.kernel], dim=0)  # [L,D]
+        b = torch.cat([k.t() for k in self.bias], dim=0)
+        return Fn.dcn_cross(inputs, w, b).unsqueeze(-1)
+
+
+class CIN(Layer):
+    """xDeepFM compressed interaction network (interactive_layer.py:285-327).
+
+    build creates one Conv1D(size, 1) per entry of conv_size (kernel [1, H_{l-1}*F, H_l] glorot_uniform, bias [H_l]
+    zeros; channel c = h*F+f) and, when output_dim == 1, the Dense(1) head (kernel [L*K,1], bias [1]).
+    call(x [B,F,K]) -> [B,1] (or the pooled concat [B, L*K] when output_dim != 1).  The sum-pool is over the
+    feature-map axis (reference :322)."""
+
+    def __init__(self, conv_size=None, output_dim=1, mode=0):
+        super().__init__()
+        if conv_size is None:
+            conv_size = [200, 200, 200]
+        self.conv_size = list(conv_size)
+        self.output_dim = output_dim
+        self.mode = mode
+
+    def build(self, input_shape):
+        _, f, k = input_shape
+        self.conv_kernels, self.conv_biases = [], []
+        hp = f
+        for l, h in enumerate(self.conv_size):
+            self.conv_kernels.append(self.add_weight("hidden_conv_{}_kernel".format(l), [1, hp * f, h], "glorot_uniform"))
+            self.conv_biases.append(self.add_weight("hidden_conv_{}_bias".format(l), [h], "zeros"))
+            hp = h
+        if self.output_dim == 1:
+            self.logit_kernel = self.add_weight("logit_layer_kernel", [len(self.conv_size) * k, 1], "glorot_uniform")
+            self.logit_bias = self.add_weight("logit_layer_bias", [1], "zeros")
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        x = pack_fields(inputs)
+        Ws = [w[0] for w in self.conv_kernels]
+        if self.output_dim == 1:
+            return Fn.cin(x, Ws, self.conv_biases, self.logit_kernel, self.logit_bias, output_dim=1, mode=self.mode)
+        return Fn.cin(x, Ws, self.conv_biases, None, None, output_dim=self.output_dim, mode=self.mode)
+
+
+class SparseEmbed(Layer):
+    """SparseEmbed (interactive_layer.py:189-247): one embedding table per sparse field.
+
+    sparse_info: list of descriptors with .fea_name, .word_size and .cross_unit (embedding dim; .linear_unit when
+    is_linear), as the reference's sparseFea namedtuple (data_prepare.py:59).  All tables live in one concatenated
+    parameter so that one kernel launch gathers the packed [B,F,K] block (bit-exact row copies).
+    call(list of F integer tensors [B,1] or a packed [B,F]) -> the reference's list of F tensors [B,1,K]
+    (views of the packed block; ``packed=True`` returns the block itself), flattened / summed like the reference
+    when use_flatten / use_add.
+    """
+
+    def __init__(self, sparse_info: list, is_linear=False, use_flatten=True, use_add=False, seed=2020, support_masking=True,
+                 mask_zero=False, packed=False):
+        super().__init__()
+        self.sparse_info = sparse_info
+        self.is_linear = is_linear
+        self.use_flatten = use_flatten
+        self.use_add = use_add
+        self.seed = seed
+        self.supports_masking = support_masking
+        self.mask_zero = mask_zero
+        self.packed = packed
+
+    def build(self, input_shape):
+        dims = {int(i.linear_unit if self.is_linear else i.cross_unit) for i in self.sparse_info}
+        if len(dims) != 1 or 0 in dims:
+            raise ValueError("SparseEmbed on the HIP path needs one common non-zero embedding dim, got %s" % sorted(dims))
+        k = dims.pop()
+        sizes = [int(i.word_size) for i in self.sparse_info]
+        self.embeddings = self.add_weight("embeddings", [sum(sizes), k], "zeros")
+        off = 0
+        offsets = []
+        for n, v in enumerate(sizes):
+            # each table is initialised like its own Keras Embedding (glorot_uniform(seed) over [V_f, K];
+            # linear tables use Keras' default 'uniform' = U(-0.05, 0.05))
+            if self.is_linear:
+                with torch.no_grad():
+                    self.embeddings[off:off + v].uniform_(-0.05, 0.05)
+            else:
+                glorot_uniform_(self.embeddings.data[off:off + v], seed=self.seed)
+            offsets.append(off)
+            off += v
+        self.register_buffer("offsets", torch.tensor(offsets, dtype=torch.int64, device=self._build_device))
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        idx = torch.cat([t.reshape(t.shape[0], 1) for t in inputs], dim=1) if isinstance(inputs, (list, tuple)) else inputs
+        block = Fn.embed_gather(self.embeddings, self.offsets, idx.to(torch.int64))  # [B,F,K]
+        if self.packed:
+            return block
+        embed_list = list(block.split(1, dim=1))  # F x [B,1,K]
+        if self.use_flatten:
+            embed_list = [e.reshape(e.shape[0], -1) for e in embed_list]
+        if self.use_add:
+            out = embed_list[0]
+            for e in embed_list[1:]:
+                out = out + e
+            embed_list = out
+        if self.mask_zero:
+            masks = [(idx[:, f:f + 1] != 0) for f in range(idx.shape[1])]
+            return embed_list, masks
+        return embed_list
