@@ -82,7 +82,9 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *                (fil_cin_saved_bytes; needed by bwd; the last layer's map is never materialised).
  *   bwd: g = dL/dout [B] (output_dim==1) or dL/dpooled [B,L*K];
  *        writes dx [B,F,K], dW[l], dbias[l], ddense_w [L*K], ddense_b [1] (dense grads only if output_dim==1).
- *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 products, parity mode).
+ *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) with the last layer contracted against
+ *             sum_n W_L[c,n] (its feature map is only ever sum-pooled, so this is the same function at 1/H_L of the flops);
+ *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
  *   Limits: H_l <= 256, L <= 8.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
