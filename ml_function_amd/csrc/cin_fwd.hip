@@ -1,0 +1,24 @@
+// Instantiations + dispatch of cin_fwd3_kernel<MB, JT>.
+#include "cin_kernels.h"
+#include "cin_launch.h"
+
+namespace fil {
+
+template <int MB, int JT>
+static void fwd3(hipStream_t st, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf, const float* bias,
+                 float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H) {
+  hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H);
+}
+
+void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
+                     const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H) {
+#define FIL_F3(JTV)                                                                                  \
+  case JTV:                                                                                          \
+    if (MB == 2) fwd3<2, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H);  \
+    else fwd3<1, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H);          \
+    break;
+  switch (JT) { FIL_F3(4) FIL_F3(8) FIL_F3(12) FIL_F3(16) FIL_F3(20) FIL_F3(24) FIL_F3(28) FIL_F3(32) }
+#undef FIL_F3
+}
+
+}  // namespace fil

@@ -1,0 +1,718 @@
+// A3  xDeepFM CIN forward + backward for gfx950 (fp32 MFMA, v_mfma_f32_32x32x2_f32): device kernels.
+//
+// Replaces CIN.call of the reference (interactive_layer.py:310-327).  Per layer the reference materialises
+// the outer product Z[b,k,c=h*F+f] = x^{l-1}[b,h,k] * x[b,f,k] (0.4-1.3 GB at the north-star shape),
+// transposes it twice and runs a 1x1 Conv1D = GEMM [B*K, C] x [C, H].  Here Z never exists: every kernel is
+// an implicit GEMM whose Z operand is regenerated in registers from the two small per-row vectors.
+//
+// GEMM view: rows m = b*K + k (M = B*K), reduction c = (h,f) (C = Hp*F), columns n (H).
+//   fwd   cin_fwd3_kernel   X^l[m,n]  = sum_c Z[m,c] W[c,n] + bias[n]         (A = Z generated, B = W streamed)
+//   bwd   cin_dw3_kernel    dW[c,n]   = sum_m Z[m,c] G[m,n]                   (A = Z^T generated, B = G streamed)
+//   bwd   cin_dz3_kernel    dZ[c,m]   = sum_n W[c,n] G[m,n], consumed in registers:
+//                           G^{l-1}[m,h] = sum_f dZ[(h,f),m] x[m,f];  dX[m,f] += sum_h dZ[(h,f),m] x^{l-1}[m,h]
+// The reduction order of a GEMM is free, so each kernel picks the order that makes its generated operand
+// lane-local.  All three are MFMA-bound: fp32 MFMA issues one 32x32x2 tile per 64 cycles per SIMD.
+//
+// MFMA 32x32x2 f32 operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; accumulator register r of lane l holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+#pragma once
+#include "common.h"
+
+namespace fil {
+
+constexpr int kCinThreads = 256;  // 4 waves per workgroup, one per SIMD
+constexpr int kCinMaxL = 8;
+constexpr int kCinMaxH = 256;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Makes the compiler wait HERE for any pending load of v (an empty asm that "uses" the register), so that no
+// s_waitcnt vmcnt(0) is placed later inside an MFMA loop, where it would also drain the prefetch just issued.
+__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
+
+// #################################################################################################
+// v3 kernels: m-major internal layouts + LDS-free streaming GEMMs.
+//
+// Internal tensors are "m-major": row m = b*K + k.   xT [M][F];  feature maps / their gradients [M][HS] with
+// HS = 128*ceil(H/128) (columns >= H are zero).  These are the natural operand/result layouts of the MFMA tiles:
+// a lane that owns column j of a 32x32 tile is given the 4 consecutive feature maps n = 4j..4j+3 of a 128-column
+// chunk (one per accumulator block), so every B operand fetch / result store is one aligned 16-byte access.
+// W is re-packed per call into zero-padded, step-ordered copies (2.6 MB, a few microseconds) so that every wave
+// streams its operands from L2 with a register prefetch queue: no LDS staging, no workgroup barriers.
+// The x fragment of a row lives in registers, which needs a compile-time step count per h: JT = ceil(F/2) rounded
+// up to a multiple of 4 (menu 4..32; the padding steps multiply by zero).
+// #################################################################################################
+constexpr int kQDepthMax = 10;
+
+// x [B,F,K] -> xT [M][F]   (one workgroup per sample, transposed through LDS)
+static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [F][K+1]
+  const long b = blockIdx.x;
+  const float* src = x + b * F * K;
+  for (int i = threadIdx.x; i < F * K; i += 256) smem[(i / K) * (K + 1) + (i % K)] = src[i];
+  __syncthreads();
+  float* dst = xT + b * K * F;
+  for (int i = threadIdx.x; i < F * K; i += 256) dst[i] = smem[(i % F) * (K + 1) + (i / F)];
+}
+
+// dx [B,F,K] = dxT [M][F] (+ addT [M][F])
+static __global__ __launch_bounds__(256) void cin_transpose_out_kernel(const float* __restrict__ dxT, const float* __restrict__ addT,
+                                                                float* __restrict__ dx, int F, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][F+1]
+  const long b = blockIdx.x;
+  const float* src = dxT + b * K * F;
+  const float* src2 = addT != nullptr ? addT + b * K * F : nullptr;
+  for (int i = threadIdx.x; i < F * K; i += 256) smem[(i / F) * (F + 1) + (i % F)] = src[i] + (src2 ? src2[i] : 0.f);
+  __syncthreads();
+  float* dst = dx + b * F * K;
+  for (int i = threadIdx.x; i < F * K; i += 256) dst[i] = smem[(i % K) * (F + 1) + (i / K)];
+}
+
+// Wf[chunk][h][fp < 2*JT][128] = W[(h*F + fp)*H + chunk*128 + col]  (zero rows fp >= F, zero columns n >= H)
+static __global__ __launch_bounds__(256) void cin_pack_wf_kernel(const float* __restrict__ W, float* __restrict__ Wf, int Hp, int F, int H,
+                                                          int JT2, int chunks) {
+  const long total = (long)chunks * Hp * JT2 * 128;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i & 127);
+    long t = i >> 7;
+    const int fp = (int)(t % JT2);
+    t /= JT2;
+    const int h = (int)(t % Hp), chunk = (int)(t / Hp);
+    const int n = chunk * 128 + col;
+    Wf[i] = (fp < F && n < H) ? W[((long)h * F + fp) * H + n] : 0.f;
+  }
+}
+
+// Forward layer, streaming form.  Wave = 32*MB rows x 128 columns (one chunk); step (h, j): half 0 / 1 take
+// f = 2j / 2j+1; the W row pair of step s = h*JT + j is Wf row 2s+half, so the B-operand stream is linear.
+// x^{l-1}[m,h] is one dword per h (prefetched); the queue holds DEPTH steps of B operands (16 B per lane each).
+template <int MB, int JT>
+__global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+                                                          const float* __restrict__ Wf, const float* __restrict__ bias,
+                                                          float* __restrict__ xoutT, int HS, float* __restrict__ pool_part, int M,
+                                                          int F, int Hp, int H) {
+  // queue depth: the largest divisor of JT not above kQDepthMax (slot j % DEPTH must mean the same step in every h)
+  constexpr int DEPTH = JT <= kQDepthMax ? JT : (JT % 10 == 0 ? 10 : (JT % 8 == 0 ? 8 : (JT % 7 == 0 ? 7 : (JT % 6 == 0 ? 6 : 4))));
+  static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int chunk = blockIdx.y;
+  const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
+  if (wrow0 >= M) return;  // whole wave past the end (no barriers in this kernel)
+  long mq[MB];
+  bool vq[MB];
+  float xr[MB][JT];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = wrow0 + mb * 32 + r;
+    vq[mb] = m < M;
+    mq[mb] = vq[mb] ? m : M - 1;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int f = 2 * j + half;
+      xr[mb][j] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+    }
+  }
+  f32x16 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  const float4* wbase = reinterpret_cast<const float4*>(Wf + (long)chunk * Hp * (2 * JT) * 128) + (half * 32 + r);
+  float4 q[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) q[d] = wbase[(long)(2 * d) * 32];
+  const float* xprow[MB];
+  float xpv[MB], xpn[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    xprow[mb] = xpT + mq[mb] * xps;
+    xpv[mb] = xprow[mb][0];
+    xpn[mb] = 0.f;
+  }
+#pragma unroll 1
+  for (int h = 0; h < Hp; ++h) {
+    const bool more = h + 1 < Hp;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      if (more) xpn[mb] = xprow[mb][h + 1];
+    const float4* wh = wbase + (long)h * (2 * JT) * 32;
+    const float4* whn = wbase + (long)(more ? h + 1 : h) * (2 * JT) * 32;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const float4 w = q[j % DEPTH];
+      const int jn = j + DEPTH;  // refill this slot with the operand of step j + DEPTH (possibly in the next h)
+      q[j % DEPTH] = jn < JT ? wh[(long)(2 * jn) * 32] : whn[(long)(2 * (jn - JT)) * 32];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float a = xpv[mb] * xr[mb][j];
+        acc[mb][0] = mfma32(a, w.x, acc[mb][0]);
+        acc[mb][1] = mfma32(a, w.y, acc[mb][1]);
+        acc[mb][2] = mfma32(a, w.z, acc[mb][2]);
+        acc[mb][3] = mfma32(a, w.w, acc[mb][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the refill load here (the scheduler would sink it to its use)
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) xpv[mb] = xpn[mb];
+  }
+
+  // ---- epilogue: + bias, store [M][HS] (lane r owns columns 4r..4r+3 of the chunk), sum-pool over columns
+  float bv[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = chunk * 128 + 4 * r + nb;
+    bv[nb] = n < H ? bias[n] : 0.f;
+  }
+  const float bsum = half_wave_sum(bv[0] + bv[1] + bv[2] + bv[3]);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = wrow0 + mb * 32 + mfma32_row(reg, half);
+      const float v0 = acc[mb][0][reg], v1 = acc[mb][1][reg], v2 = acc[mb][2][reg], v3 = acc[mb][3][reg];
+      if (xoutT != nullptr && m < M)
+        *reinterpret_cast<float4*>(xoutT + (long)m * HS + chunk * 128 + 4 * r) = make_float4(v0 + bv[0], v1 + bv[1], v2 + bv[2], v3 + bv[3]);
+      const float p = half_wave_sum((v0 + v1) + (v2 + v3)) + bsum;
+      if (r == 0 && m < M) pool_part[(long)chunk * M + m] = p;
+    }
+  }
+}
+
+// Wz[(t*32 + i)*NCOL + col]: W rows in the "slot" order of the dZ kernel.  Tile row i <-> (slot 16t + rr, parity hf),
+// rr = (i&3) + 4*(i>>3), hf = (i>>2)&1;  slot -> (h, j) = (slot / JT, slot % JT), f = 2j + hf;  zero when out of range.
+static __global__ __launch_bounds__(256) void cin_pack_wz_kernel(const float* __restrict__ W, float* __restrict__ Wz, int Hp, int F, int H,
+                                                          int JT, int NCOL, int tiles) {
+  const long total = (long)tiles * 32 * NCOL;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % NCOL);
+    const long row = idx / NCOL;
+    const int i = (int)(row & 31);
+    const long t = row >> 5;
+    const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
+    const long slot = 16 * t + rr;
+    const int h = (int)(slot / JT), j = (int)(slot - (long)h * JT);
+    const int f = 2 * j + hf;
+    Wz[idx] = (h < Hp && f < F && col < H) ? W[((long)h * F + f) * H + col] : 0.f;
+  }
+}
+
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+
+// Backward data path, streaming form.  Wave = 32*MB rows m (on the lanes).  dZ^T tile = Wz tile (32 slot rows,
+// A operand streamed from L2: 16 bytes per 4 steps) x G^T (B operand: the lane's G row, NHMAX registers per 32 rows).
+// Slot order (see cin_pack_wz_kernel) makes accumulator register rr of tile t the channel (h, f = 2j+half) with
+// 16t+rr = h*JT + j, so with a compile-time JT the whole contraction is register-only:
+//   gx       += dZ * x[m,f]            -> G^{l-1}[m,h] when the h is complete (halves added with one shuffle)
+//   dxacc[j] += dZ * x^{l-1}[m,h]      -> dX[m, 2j+half]
+// The (tile, register) -> (h, j) pattern repeats every P = JT/gcd(16,JT) tiles = HPP = 16P/JT values of h.
+template <int MB, int JT, int NHMAX>
+__global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
+                                                         const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+                                                         const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
+                                                         int HSp, float* __restrict__ gx0T, float* __restrict__ dxT, int accumulate,
+                                                         int M, int F, int Hp, int H, int periods) {
+  // Per-lane scratch in LDS, laid out [mb][j][tid] (lane-minor -> conflict-free, immediate offsets): the lane's x
+  // fragment and its dX accumulators.  Every address is touched by exactly one lane: no barriers, no atomics.
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NCOL = 2 * NHMAX;
+  constexpr int NQ = NHMAX / 4;
+  constexpr int P = JT / gcd_c(16, JT);
+  constexpr int HPP = 16 * P / JT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
+  if (wrow0 >= M) return;
+  float* xs = smem + tid;                       // xs[(mb*JT + j)*256]
+  float* dxs = smem + MB * JT * 256 + tid;      // dxs[(mb*JT + j)*256]
+  long mq[MB];
+  bool vq[MB];
+  float greg[MB][NHMAX], dpp[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = wrow0 + mb * 32 + r;
+    vq[mb] = m < M;
+    mq[mb] = vq[mb] ? m : M - 1;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int f = 2 * j + half;
+      xs[(mb * JT + j) * 256] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+      dxs[(mb * JT + j) * 256] = 0.f;
+    }
+    const float* grow = gT + mq[mb] * HS + half * NHMAX;
+#pragma unroll
+    for (int s = 0; s < NHMAX; ++s) greg[mb][s] = (vq[mb] && half * NHMAX + s < H) ? grow[s] : 0.f;
+    dpp[mb] = 0.f;
+    if (dPprev != nullptr && vq[mb]) {
+      const long bb = mq[mb] / K;
+      dpp[mb] = dPprev[bb * ldp + (mq[mb] - bb * K)];
+    }
+  }
+  const float4* wz = reinterpret_cast<const float4*>(Wz) + ((long)r * NCOL + half * NHMAX) / 4;
+  constexpr long kTileStride = 32L * NCOL / 4;  // float4 per tile
+  float4 q[NQ];
+#pragma unroll
+  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[s4];
+  float gx[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) gx[mb] = 0.f;
+
+#pragma unroll 1
+  for (int per = 0; per < periods; ++per) {
+    const int hbase = per * HPP;
+    float xpv[MB][HPP], gout[MB][HPP];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xpv[mb][hl] = (vq[mb] && hbase + hl < Hp) ? xpT[mq[mb] * xps + hbase + hl] : 0.f;
+#pragma unroll
+    for (int tp = 0; tp < P; ++tp) {
+      // the stream is allocated one tile past the last period, so the refill never leaves the buffer
+      const float4* wnext = wz + ((long)per * P + tp + 1) * kTileStride;
+      f32x16 d[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[mb][i] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < NQ; ++s4) {
+        const float4 w = q[s4];
+        q[s4] = wnext[s4];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          d[mb] = mfma32(w.x, greg[mb][4 * s4 + 0], d[mb]);
+          d[mb] = mfma32(w.y, greg[mb][4 * s4 + 1], d[mb]);
+          d[mb] = mfma32(w.z, greg[mb][4 * s4 + 2], d[mb]);
+          d[mb] = mfma32(w.w, greg[mb][4 * s4 + 3], d[mb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int sp = 16 * tp + rr;
+        const int hl = sp / JT, j = sp % JT;  // compile-time after unrolling
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float dz = d[mb][rr];
+          gx[mb] = fmaf(dz, xs[(mb * JT + j) * 256], gx[mb]);
+          dxs[(mb * JT + j) * 256] = fmaf(dz, xpv[mb][hl], dxs[(mb * JT + j) * 256]);
+          if (j == JT - 1) {
+            gout[mb][hl] = gx[mb] + __shfl_xor(gx[mb], 32);
+            gx[mb] = 0.f;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // consume each dZ value where it is produced (keeps live ranges short)
+      }
+    }
+    // ---- G^{l-1}[m, hbase .. hbase+HPP)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      if (half == 0 && vq[mb]) {
+#pragma unroll
+        for (int hl = 0; hl < HPP; ++hl) {
+          const int h = hbase + hl;
+          if (h < Hp) {
+            if (gx0T != nullptr) gx0T[mq[mb] * F + h] = gout[mb][hl];
+            else GprevT[mq[mb] * HSp + h] = gout[mb][hl] + dpp[mb];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    if (vq[mb]) {
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int f = 2 * j + half;
+        if (f < F) {
+          float* p = dxT + mq[mb] * F + f;
+          const float v = dxs[(mb * JT + j) * 256];
+          *p = accumulate ? *p + v : v;
+        }
+      }
+    }
+  }
+}
+
+// Backward weight path, streaming form: dW[c,n] = sum_m Z[m,c] G[m,n].  Wave = 32*MB channel rows (on the lanes as
+// A-operand rows) x one 128-column chunk; the reduction runs over m (two rows per step, one per wave half) with all
+// three operands streamed from L2 through a DEPTH-step register queue:
+//   A[c][m] = x^{l-1}[m,h_c] * x[m,f_c]   (two dword gathers: 32 consecutive f -> one 128-byte segment; <= 3 distinct h)
+//   B[m][n] = G[m, 4r..4r+3]              (one aligned 16-byte load)
+// xT == nullptr stands for a single all-ones field (used for the last layer's rank-one weight gradient).
+constexpr int kDwDepth = 8;
+
+template <int MB, bool XONES, int DEPTH = kDwDepth>
+__global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ xT,
+                                                         const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
+                                                         int Hp, int H, int rows_per_split) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int C = Hp * F;
+  const int chunk = blockIdx.z;
+  const int c0 = (blockIdx.x * 4 + wave) * (32 * MB);
+  if (c0 >= C) return;
+  // per-lane column offsets (32-bit element offsets from uniform bases keep the address math to a few VALU ops per step;
+  // the host guarantees M*max(HS, F, xps) < 2^31)
+  int fo[MB], ho[MB];
+  bool cv[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int c = c0 + mb * 32 + r;
+    cv[mb] = c < C;
+    const int cc = cv[mb] ? c : C - 1;
+    ho[mb] = cc / F;
+    fo[mb] = cc - ho[mb] * F;
+  }
+  const int go = chunk * 128 + 4 * r;
+  const int m_lo = blockIdx.y * rows_per_split;
+  const int m_hi = min(M, m_lo + rows_per_split);
+  const int steps = (m_hi - m_lo + 1) >> 1;
+  const int groups = (steps + DEPTH - 1) / DEPTH;
+  const int mlane = m_lo + half;
+
+  f32x16 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  float4 qg[DEPTH];
+  float qx[DEPTH][MB], qp[DEPTH][MB];
+  auto fetch = [&](int s, float4& g4, float (&xv)[MB], float (&pv)[MB]) {
+    const int m = min(mlane + 2 * s, M - 1);  // rows past the split are clamped here and multiplied by zero below
+    g4 = *reinterpret_cast<const float4*>(gT + (m * HS + go));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      if constexpr (XONES) xv[mb] = 1.f;
+      else xv[mb] = xT[m * F + fo[mb]];
+      pv[mb] = xpT[m * xps + ho[mb]];
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) fetch(d, qg[d], qx[d], qp[d]);
+#pragma unroll 1
+  for (int g = 0; g < groups; ++g) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int s = g * DEPTH + d;
+      const float4 g4 = qg[d];
+      float a[MB];
+      const bool live = mlane + 2 * s < m_hi;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a[mb] = (live && cv[mb]) ? qx[d][mb] * qp[d][mb] : 0.f;
+      fetch(s + DEPTH, qg[d], qx[d], qp[d]);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        acc[mb][0] = mfma32(a[mb], g4.x, acc[mb][0]);
+        acc[mb][1] = mfma32(a[mb], g4.y, acc[mb][1]);
+        acc[mb][2] = mfma32(a[mb], g4.z, acc[mb][2]);
+        acc[mb][3] = mfma32(a[mb], g4.w, acc[mb][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* pout = part + (long)blockIdx.y * C * H;
+  const bool vec = (H & 3) == 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int c = c0 + mb * 32 + mfma32_row(reg, half);
+      if (c < C) {
+        const int n = chunk * 128 + 4 * r;
+        float* dst = pout + (long)c * H + n;
+        if (vec && n + 3 < H) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[mb][0][reg], acc[mb][1][reg], acc[mb][2][reg], acc[mb][3][reg]);
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+            if (n + nb < H) dst[nb] = acc[mb][nb][reg];
+        }
+      }
+    }
+  }
+}
+
+// part[blk][n] = sum over a chunk of rows of gT[m][n]   (thread <-> n: coalesced; fixed order)
+static __global__ __launch_bounds__(256) void cin_colsum3_kernel(const float* __restrict__ gT, int HS, float* __restrict__ part, int M, int H,
+                                                          int rows_per_block) {
+  const int n = threadIdx.x;
+  if (n >= H) return;
+  const long m_lo = (long)blockIdx.x * rows_per_block, m_hi = min((long)M, m_lo + rows_per_block);
+  float t0 = 0.f, t1 = 0.f;
+  long m = m_lo;
+  for (; m + 1 < m_hi; m += 2) {
+    t0 += gT[m * HS + n];
+    t1 += gT[(m + 1) * HS + n];
+  }
+  if (m < m_hi) t0 += gT[m * HS + n];
+  part[(long)blockIdx.x * H + n] = t0 + t1;
+}
+
+// gT[m][n] = dP[b*ldp + k] for n < H (general path for the top layer: the pooled gradient broadcast over feature maps)
+static __global__ __launch_bounds__(256) void cin_bcast3_kernel(const float* __restrict__ dP, int ldp, int K, float* __restrict__ gT, int HS,
+                                                         int M, int H) {
+  const long total = (long)M * HS;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / HS;
+    const int n = (int)(i - m * HS);
+    const long b = m / K;
+    gT[i] = n < H ? dP[b * ldp + (m - b * K)] : 0.f;
+  }
+}
+
+// yT[m][0..128) = xT[m][f] * dP[m] for f < F, zero beyond (right-hand side of the last layer's rank-one dW)
+static __global__ __launch_bounds__(256) void cin_scale_rows3_kernel(const float* __restrict__ xT, const float* __restrict__ dP, int ldp, int K,
+                                                              float* __restrict__ yT, int M, int F) {
+  const long total = (long)M * 128;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i >> 7;
+    const int f = (int)(i & 127);
+    const long b = m / K;
+    yT[i] = f < F ? xT[m * F + f] * dP[b * ldp + (m - b * K)] : 0.f;
+  }
+}
+
+// out[i] = sum_{p < parts} part[p*n + i]   (fixed order).  One workgroup per 64 outputs; the 4 waves take every 4th
+// partial (coalesced over i), then the 4 wave sums are added in wave order -> many loads in flight, fixed order.
+static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+                                                         int parts) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (i < n) {
+    int p = wave;
+    for (; p + 12 < parts; p += 16) {
+      t0 += part[(long)p * n + i];
+      t1 += part[(long)(p + 4) * n + i];
+      t2 += part[(long)(p + 8) * n + i];
+      t3 += part[(long)(p + 12) * n + i];
+    }
+    for (; p < parts; p += 4) t0 += part[(long)p * n + i];
+  }
+  red[wave][lane] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (wave == 0 && i < n) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// part[blk] = sum over a chunk of samples of dP[b*ldp + k], k < K  (dbias of the last layer: same value for every n)
+static __global__ __launch_bounds__(256) void cin_slice_sum_kernel(const float* __restrict__ dP, int ldp, float* __restrict__ part, int B,
+                                                            int K, int bchunk) {
+  __shared__ float red[256];
+  const int b_lo = blockIdx.x * bchunk, b_hi = min(B, b_lo + bchunk);
+  float t = 0.f;
+  const int total = (b_hi - b_lo) * K;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int b = b_lo + i / K, k = i % K;
+    t += dP[(long)b * ldp + k];
+  }
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// dbias[n] = sum_p part[p] for every n < H
+static __global__ __launch_bounds__(256) void cin_fill_sum_kernel(const float* __restrict__ part, int parts, float* __restrict__ dbias, int H) {
+  float t = 0.f;
+  for (int p = 0; p < parts; ++p) t += part[p];
+  for (int n = threadIdx.x; n < H; n += 256) dbias[n] = t;
+}
+
+// =================================================================================================
+// Last-layer shortcut.  The last feature map x^L is only ever sum-pooled over its feature-map axis n
+// (reference :322), so with wsum[c] = sum_n W_L[c,n]:
+//   p_L[m]            = sum_c Z[m,c] wsum[c] + sum_n bias[n]
+//   G^L[m,n]          = dP_L[m] for every n  =>  dZ_L[m,c] = dP_L[m] wsum[c],  dW_L[c,n] = sum_m Z[m,c] dP_L[m] (all n),
+//                       dbias_L[n] = sum_m dP_L[m]
+// i.e. two [M x F] x [F x Hp] / [M x Hp] x [Hp x F] products instead of [M x Hp*F] x [Hp*F x H] GEMMs: 1/H of the
+// flops, run by small VALU kernels (one thread per row m, wsum broadcast from LDS).  Results are those of the
+// general kernels up to fp32 rounding; fil_cin_* mode 1 forces the general path for validation.
+constexpr int kLastFMax = 64;  // F <= 64
+
+static __global__ __launch_bounds__(256) void cin_wsum_kernel(const float* __restrict__ W, float* __restrict__ wsum, int C, int H) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  float t = 0.f;
+  if (row < C)
+    for (int n = l; n < H; n += 32) t += W[(long)row * H + n];
+  t = half_wave_sum(t);
+  if (row < C && l == 0) wsum[row] = t;
+}
+
+// stages wsum as [Hp][FP4] (FP4 = F rounded up to 4, zero padded) so rows can be read 16 bytes at a time
+__device__ __forceinline__ void stage_wsum(const float* __restrict__ wsum, float* ws, int Hp, int F, int FP4) {
+  for (int idx = threadIdx.x; idx < Hp * FP4; idx += blockDim.x) {
+    const int h = idx / FP4, f = idx - h * FP4;
+    ws[idx] = f < F ? wsum[h * F + f] : 0.f;
+  }
+}
+
+// One row m is shared by 4 lanes (hq = lane>>4 takes h = hq, hq+4, ...): a wave covers 16 consecutive rows (k
+// contiguous -> 64-byte segments of x^{L-1}[b,h,:]), a workgroup 64 rows; partial sums are folded with two shuffles.
+constexpr int kLastRows = 64;
+
+static __global__ __launch_bounds__(256) void cin_last_fwd_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+                                                           const float* __restrict__ wsum, const float* __restrict__ bias,
+                                                           float* __restrict__ pool, int M, int F, int Hp, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int FP4 = (F + 3) & ~3;
+  stage_wsum(wsum, smem, Hp, F, FP4);
+  float bsum = 0.f;
+  for (int n = 0; n < H; ++n) bsum += bias[n];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * kLastRows + wave * 16 + (lane & 15), hq = lane >> 4;
+  const bool valid = m < M;
+  const long mm = valid ? m : 0;
+  float xr[kLastFMax];
+#pragma unroll
+  for (int f = 0; f < kLastFMax; ++f) xr[f] = (valid && f < F) ? xT[mm * F + f] : 0.f;
+  const float* xprow = xpT + mm * xps;
+  float p = 0.f;
+  for (int h = hq; h < Hp; h += 4) {
+    const float4* wrow = reinterpret_cast<const float4*>(smem + h * FP4);
+    float t = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < kLastFMax / 4; ++f4) {
+      if (4 * f4 < F) {
+        const float4 w = wrow[f4];
+        t = fmaf(xr[4 * f4], w.x, t);
+        t = fmaf(xr[4 * f4 + 1], w.y, t);
+        t = fmaf(xr[4 * f4 + 2], w.z, t);
+        t = fmaf(xr[4 * f4 + 3], w.w, t);
+      }
+    }
+    p = fmaf(valid ? xprow[h] : 0.f, t, p);
+  }
+  p += __shfl_xor(p, 16);
+  p += __shfl_xor(p, 32);
+  if (valid && hq == 0) pool[m] = p + bsum;
+}
+
+// Gprev[m,h] = dP[m] * sum_f x[m,f] wsum[h,f] (+ dPprev[m]);  dX[m,f] = dP[m] * sum_h x^{L-1}[m,h] wsum[h,f]
+// layer1 (L == 1, x^{L-1} == x): both terms go to dX (the first one through a small LDS tile).
+static __global__ __launch_bounds__(256) void cin_last_bwd_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+                                                           const float* __restrict__ wsum, const float* __restrict__ dP, int ldp,
+                                                           const float* __restrict__ dPprev, float* __restrict__ GprevT, int HSp,
+                                                           float* __restrict__ dxT, int layer1, int M, int F, int K, int Hp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int FP4 = (F + 3) & ~3;
+  float* ts = smem + Hp * FP4;  // [kLastRows][kLastFMax + 1], layer1 only
+  stage_wsum(wsum, smem, Hp, F, FP4);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rowl = wave * 16 + (lane & 15), hq = lane >> 4;
+  const int m = blockIdx.x * kLastRows + rowl;
+  const bool valid = m < M;
+  const long mm = valid ? m : 0;
+  const int b = (int)(mm / K), k = (int)(mm - (long)b * K);
+  float xr[kLastFMax], u[kLastFMax];
+#pragma unroll
+  for (int f = 0; f < kLastFMax; ++f) {
+    xr[f] = (valid && f < F) ? xT[mm * F + f] : 0.f;
+    u[f] = 0.f;
+  }
+  const float dp = valid ? dP[(long)b * ldp + k] : 0.f;
+  const float dpp = (valid && dPprev != nullptr) ? dPprev[(long)b * ldp + k] : 0.f;
+  const float* xprow = xpT + mm * xps;
+  for (int h = hq; h < Hp; h += 4) {
+    const float4* wrow = reinterpret_cast<const float4*>(smem + h * FP4);
+    const float xph = valid ? xprow[h] : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < kLastFMax / 4; ++f4) {
+      if (4 * f4 < F) {
+        const float4 w = wrow[f4];
+        t = fmaf(xr[4 * f4], w.x, t);
+        t = fmaf(xr[4 * f4 + 1], w.y, t);
+        t = fmaf(xr[4 * f4 + 2], w.z, t);
+        t = fmaf(xr[4 * f4 + 3], w.w, t);
+        u[4 * f4] = fmaf(xph, w.x, u[4 * f4]);
+        u[4 * f4 + 1] = fmaf(xph, w.y, u[4 * f4 + 1]);
+        u[4 * f4 + 2] = fmaf(xph, w.z, u[4 * f4 + 2]);
+        u[4 * f4 + 3] = fmaf(xph, w.w, u[4 * f4 + 3]);
+      }
+    }
+    if (layer1) ts[rowl * (kLastFMax + 1) + h] = t;
+    else if (valid) GprevT[mm * HSp + h] = fmaf(dp, t, dpp);
+  }
+  if (layer1) __syncthreads();
+#pragma unroll
+  for (int f = 0; f < kLastFMax; ++f) {
+    if (f < F) {
+      float v = u[f];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (layer1) v += ts[rowl * (kLastFMax + 1) + f];  // Hp == F: the x^{0} role of x
+      if (valid && hq == 0) dxT[mm * F + f] = dp * v;
+    }
+  }
+}
+
+// dW[c,n] = v[c] for every n
+static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* __restrict__ v, float* __restrict__ dW, long C, int H) {
+  const long total = C * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dW[i] = v[i / H];
+}
+
+struct PoolArgs {
+  const float* part[kCinMaxL];  // [chunks][M] per layer
+  int chunks[kCinMaxL];
+};
+
+// pooled[b, l*K+k] = sum_chunk part_l[chunk][b*K+k];  out[b] = pooled[b,:] . dense_w + dense_b
+static __global__ __launch_bounds__(256) void cin_head_fwd_kernel(PoolArgs pa, const float* __restrict__ dense_w,
+                                                           const float* __restrict__ dense_b, float* __restrict__ pooled,
+                                                           float* __restrict__ out, int B, int K, int L) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const long M = (long)B * K;
+  float o = 0.f;
+  for (int l = 0; l < L; ++l) {
+    for (int k = 0; k < K; ++k) {
+      float v = 0.f;
+      for (int ch = 0; ch < pa.chunks[l]; ++ch) v += pa.part[l][(long)ch * M + (long)b * K + k];
+      pooled[(long)b * L * K + l * K + k] = v;
+      if (out != nullptr) o = fmaf(v, dense_w[l * K + k], o);
+    }
+  }
+  if (out != nullptr) out[b] = o + dense_b[0];
+}
+
+// output_dim == 1: dP[b,j] = g[b] * dense_w[j];  partial[blk][j] = sum_{b in blk} g[b]*pooled[b,j]  (j < LK),
+// partial[blk][LK] = sum g[b].   One thread per j, blocks over chunks of b.
+static __global__ __launch_bounds__(256) void cin_head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dense_w,
+                                                           const float* __restrict__ pooled, float* __restrict__ dP,
+                                                           float* __restrict__ part, int B, int LK, int bchunk) {
+  const int j = threadIdx.x;
+  if (j > LK) return;
+  const int b_lo = blockIdx.x * bchunk, b_hi = min(B, b_lo + bchunk);
+  const float wj = j < LK ? dense_w[j] : 0.f;
+  float t = 0.f;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const float gb = g[b];
+    if (j < LK) {
+      dP[(long)b * LK + j] = gb * wj;
+      t = fmaf(gb, pooled[(long)b * LK + j], t);
+    } else {
+      t += gb;
+    }
+  }
+  part[(long)blockIdx.x * (LK + 1) + j] = t;
+}
+
+
+}  // namespace fil

@@ -1,0 +1,22 @@
+// Launchers of the templated CIN GEMM kernels (instantiated in separate translation units so they compile in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fil {
+
+// JT = steps per h of the streaming kernels: ceil(F/2) rounded up to a multiple of 4 (menu 4..32, F <= 64)
+inline int cin_jt_of(int F) { return ((F + 1) / 2 + 3) / 4 * 4; }
+
+void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
+                     const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H);
+
+void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
+                    const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,
+                    int accumulate, int M, int F, int Hp, int H, int periods);
+
+// tiles per period / h per period of the dZ kernel for a given JT (mirrors the constexprs in cin_dz3_kernel)
+inline int cin_gcd(int a, int b) { return b == 0 ? a : cin_gcd(b, a % b); }
+inline int cin_dz_tiles_per_period(int JT) { return JT / cin_gcd(16, JT); }
+inline int cin_dz_h_per_period(int JT) { return 16 * cin_dz_tiles_per_period(JT) / JT; }
+
+}  // namespace fil
