@@ -261,15 +261,48 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   float gx[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) gx[mb] = 0.f;
+  // destination of the completed G^{l-1}[m,h] values (selected once: keeps the tile loop free of invariant branches)
+  float* gdst[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) gdst[mb] = gx0T != nullptr ? gx0T + mq[mb] * F : GprevT + mq[mb] * HSp;
+
+  // The 16 slots of tile t are contracted while the MFMA chain of tile t+1 runs (one slot per 4-step group), so the
+  // VALU/LDS epilogue hides behind the matrix pipe: dprev/xprev/hprev describe the tile being contracted.
+  f32x16 dprev[MB];
+  float xprev[MB][HPP], xcur[MB][HPP];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dprev[mb][i] = 0.f;
+#pragma unroll
+    for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl] = 0.f;
+  }
+  int hprev = -HPP;  // h base of the period the previous tile belongs to (the fake tile before the first one stores nothing)
+
+  auto contract_slot = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
+    const int sp = 16 * tp + rr;
+    const int hl = sp / JT, j = sp % JT;  // compile-time after unrolling
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float dz = d[mb][rr];
+      gx[mb] = fmaf(dz, xs[(mb * JT + j) * 256], gx[mb]);
+      dxs[(mb * JT + j) * 256] = fmaf(dz, xpv[mb][hl], dxs[(mb * JT + j) * 256]);
+      if (j == JT - 1) {
+        const float tot = gx[mb] + __shfl_xor(gx[mb], 32);
+        const int h = hb + hl;
+        if (half == 0 && vq[mb] && h >= 0 && h < Hp) gdst[mb][h] = tot + dpp[mb];
+        gx[mb] = 0.f;
+      }
+    }
+  };
 
 #pragma unroll 1
   for (int per = 0; per < periods; ++per) {
     const int hbase = per * HPP;
-    float xpv[MB][HPP], gout[MB][HPP];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int hl = 0; hl < HPP; ++hl) xpv[mb][hl] = (vq[mb] && hbase + hl < Hp) ? xpT[mq[mb] * xps + hbase + hl] : 0.f;
+      for (int hl = 0; hl < HPP; ++hl) xcur[mb][hl] = (vq[mb] && hbase + hl < Hp) ? xpT[mq[mb] * xps + hbase + hl] : 0.f;
 #pragma unroll
     for (int tp = 0; tp < P; ++tp) {
       // the stream is allocated one tile past the last period, so the refill never leaves the buffer
@@ -290,40 +323,26 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
           d[mb] = mfma32(w.z, greg[mb][4 * s4 + 2], d[mb]);
           d[mb] = mfma32(w.w, greg[mb][4 * s4 + 3], d[mb]);
         }
+        // previous tile's slots, spread over this tile's step groups (NQ is 16 or 32; 16 slots per tile)
+        if (s4 < 16) {
+          if (tp == 0) contract_slot(dprev, xprev, hprev, P - 1, s4);
+          else contract_slot(dprev, xcur, hbase, tp - 1, s4);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int sp = 16 * tp + rr;
-        const int hl = sp / JT, j = sp % JT;  // compile-time after unrolling
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const float dz = d[mb][rr];
-          gx[mb] = fmaf(dz, xs[(mb * JT + j) * 256], gx[mb]);
-          dxs[(mb * JT + j) * 256] = fmaf(dz, xpv[mb][hl], dxs[(mb * JT + j) * 256]);
-          if (j == JT - 1) {
-            gout[mb][hl] = gx[mb] + __shfl_xor(gx[mb], 32);
-            gx[mb] = 0.f;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // consume each dZ value where it is produced (keeps live ranges short)
-      }
+      for (int mb = 0; mb < MB; ++mb) dprev[mb] = d[mb];
     }
-    // ---- G^{l-1}[m, hbase .. hbase+HPP)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      if (half == 0 && vq[mb]) {
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int hl = 0; hl < HPP; ++hl) {
-          const int h = hbase + hl;
-          if (h < Hp) {
-            if (gx0T != nullptr) gx0T[mq[mb] * F + h] = gout[mb][hl];
-            else GprevT[mq[mb] * HSp + h] = gout[mb][hl] + dpp[mb];
-          }
-        }
-      }
-    }
+      for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl];
+    hprev = hbase;
   }
+  // the last tile's slots
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) contract_slot(dprev, xprev, hprev, P - 1, rr);
+
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     if (vq[mb]) {
