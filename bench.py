@@ -87,13 +87,80 @@ def cpu_baseline(sample_b=512, steps=3):
                        "op-for-op torch-CPU restatement of the reference TF2 graph (TF not installable)" % (sample_b, steps))
 
 
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
+
+
+def side_benchmark(args):
+    """FM (config 2), DCN (config 3), AutoInt interacting layer (config 5): one GPU, fwd+bwd, same timing protocol."""
+    from ml_function_amd import _lib, synth
+    from ml_function_amd import functional as Fn
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    if args.workload == "fm":
+        B = args.batch or 4096
+        c = synth.fm_case(B, 39, 16)
+        emb, lin, g = t(c["emb"]).requires_grad_(), t(c["lin"]).requires_grad_(), t(c["g"])
+        def step():
+            emb.grad = lin.grad = None
+            Fn.fm(emb, lin).backward(g)
+        name, kernels, bound = "FM 2nd-order fwd+bwd F=39 K=16 fp32 B=%d" % B, ("fm_fwd", "fm_bwd"), "hbm"
+    elif args.workload == "dcn":
+        B = args.batch or 8192
+        c = synth.dcn_case(B, 1248, 3)
+        x, w, b, g = t(c["x"]).requires_grad_(), t(c["w"]).requires_grad_(), t(c["b"]).requires_grad_(), t(c["g"])
+        def step():
+            x.grad = w.grad = b.grad = None
+            Fn.dcn_cross(x, w, b).backward(g)
+        name, kernels, bound = "DCN 3 cross layers fwd+bwd D=1248 fp32 B=%d" % B, ("dcn_fwd", "dcn_bwd"), "hbm"
+    else:
+        B = args.batch or 4096
+        c = synth.attn_case(B, 200, 16, 4, 16)
+        p = {n: t(c[n]).requires_grad_() for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
+        dy = t(c["dy"])
+        def step():
+            for v in p.values():
+                v.grad = None
+            Fn.autoint_interact(p["x"], p["Wq"], p["Wk"], p["Wr"], p["gamma"], p["beta"]).backward(dy)
+        name, bound = "AutoInt interacting layer fwd+bwd F=200 K=16 H=4 A=16 fp32 B=%d" % B, "mfma"
+        kernels = ("attn_fwd", "attn_bwd_pre", "attn_bwd_dq", "attn_bwd_dk", "attn_bwd_proj")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_end()
+    ks = {k: v for k, v in prof.items() if k in kernels}
+    dom = max(ks, key=lambda k: ks[k]["total_ms"])
+    d = ks[dom]
+    rate = d["work"] / (d["avg_ms"] * 1e-3)
+    peak, unit, ach = (PEAK_HBM_GBPS, "GB/s", rate / 1e9) if bound == "hbm" else (PEAK_F32_MFMA_TFLOPS, "TFLOP/s", rate / 1e12)
+    print(json.dumps({
+        "metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": name},
+        "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                     "traffic": None, "avg_launch_ms": d["avg_ms"]},
+        "kernels": {k: dict(avg_ms=round(v["avg_ms"], 4), work=v["work"]) for k, v in sorted(ks.items())},
+        "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint"],
+                    help="cin = the headline benchmark (default); the others are single-GPU side benchmarks of the "
+                         "remaining hot-path rows (BASELINE.json configs 2, 3, 5)")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
     args = ap.parse_args()
+    if args.workload != "cin":
+        return side_benchmark(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
