@@ -517,13 +517,124 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj_kernel(const float
   }
 }
 
-// out[i] = sum_p part[p*n + i]
+// MFMA form of the projection backward (used when NJ*H*NC <= kProjMaxSeg).  A wave walks 16-row tiles of the
+// flattened rows R = B*F; per (j,h) segment it issues
+//   dx_tile [16 x K]  += D_seg [16 x A] W_seg^T [A x K]     (A operand: D rows, 16-byte loads; B: W_seg from LDS)
+//   dW_seg  [K x A]   += x_tile^T [K x 16] D_seg [16 x A]   (A operand: x columns; B: D columns)
+// and keeps the dW accumulators in registers across all its tiles (per-wave partials, reduced afterwards).
+constexpr int kProjMaxSeg = 24;
+
+template <int NC>
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj3_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
+                                                                      const float* __restrict__ Wk, const float* __restrict__ Wr,
+                                                                      const float* __restrict__ dq, const float* __restrict__ dk,
+                                                                      const float* __restrict__ dr, float* __restrict__ dx,
+                                                                      float* __restrict__ wpart, AttnDims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // Wl[NS][16*NC][kRS]
+  const int NJ = dr != nullptr ? 3 : 2;
+  const int NS = NJ * d.H, HA = d.H * d.A, DW = NJ * HA;
+  const long R = (long)d.B * d.F;
+  const float* Wj[3] = {Wq, Wk, Wr};
+  const float* Dj[3] = {dq, dk, dr};
+  for (int idx = threadIdx.x; idx < NS * 16 * NC * 16; idx += kAttnThreads) {
+    const int a = idx & 15, k = (idx >> 4) % (16 * NC), sg = idx / (16 * NC * 16);
+    const int j = sg / d.H, h = sg - j * d.H;
+    smem[(sg * 16 * NC + k) * kRS + a] = (k < d.K && a < d.A) ? Wj[j][((long)k * d.H + h) * d.A + a] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  f32x4 accw[kProjMaxSeg];
+#pragma unroll
+  for (int u = 0; u < kProjMaxSeg; ++u) accw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + 15) / 16;
+  const int wglob = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  for (long tile = wglob; tile < ntiles; tile += nw) {
+    const long r0 = tile * 16;
+    float xa[NC][4];
+#pragma unroll
+    for (int kt = 0; kt < NC; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const long row = r0 + 4 * g + s2;
+        const int k = 16 * kt + li;
+        xa[kt][s2] = (row < R && k < d.K) ? x[row * d.K + k] : 0.f;
+      }
+    f32x4 accx[NC];
+#pragma unroll
+    for (int kt = 0; kt < NC; ++kt) accx[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long rowi = r0 + li;
+#pragma unroll
+    for (int sgk = 0; sgk < kProjMaxSeg / NC; ++sgk) {
+      if (sgk < NS) {
+        const int j = sgk / d.H, h = sgk - j * d.H;
+        const float* Dp = Dj[j] + (long)h * R * d.A;
+        float dv[4], dc[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const int a = 4 * g + s2;
+          dv[s2] = (rowi < R && a < d.A) ? Dp[rowi * d.A + a] : 0.f;
+          const long row = r0 + 4 * g + s2;
+          dc[s2] = (row < R && li < d.A) ? Dp[row * d.A + li] : 0.f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < NC; ++kt) {
+          const float4 wb = *reinterpret_cast<const float4*>(smem + (sgk * 16 * NC + 16 * kt + li) * kRS + 4 * g);
+          accx[kt] = mfma16(dv[0], wb.x, accx[kt]);
+          accx[kt] = mfma16(dv[1], wb.y, accx[kt]);
+          accx[kt] = mfma16(dv[2], wb.z, accx[kt]);
+          accx[kt] = mfma16(dv[3], wb.w, accx[kt]);
+          f32x4& aw = accw[sgk * NC + kt];
+          aw = mfma16(xa[kt][0], dc[0], aw);
+          aw = mfma16(xa[kt][1], dc[1], aw);
+          aw = mfma16(xa[kt][2], dc[2], aw);
+          aw = mfma16(xa[kt][3], dc[3], aw);
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NC; ++kt)
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) {
+        const long row = r0 + 4 * g + r2;
+        const int k = 16 * kt + li;
+        if (row < R && k < d.K) dx[row * d.K + k] = accx[kt][r2];
+      }
+  }
+  float* wp = wpart + (long)wglob * d.K * DW;
+#pragma unroll
+  for (int sgk = 0; sgk < kProjMaxSeg / NC; ++sgk) {
+    if (sgk < NS) {
+#pragma unroll
+      for (int kt = 0; kt < NC; ++kt)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          const int k = 16 * kt + 4 * g + r2;
+          if (k < d.K && li < d.A) wp[(long)k * DW + sgk * d.A + li] = accw[sgk * NC + kt][r2];
+        }
+    }
+  }
+}
+
+// out[i] = sum_p part[p*n + i]  (fixed order): 64 outputs per workgroup, the 4 waves take every 4th partial
 __global__ __launch_bounds__(256) void attn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float t = 0.f;
-  for (int p = 0; p < parts; ++p) t += part[(long)p * n + i];
-  out[i] = t;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (i < n) {
+    int p = wave;
+    for (; p + 12 < parts; p += 16) {
+      t0 += part[(long)p * n + i];
+      t1 += part[(long)(p + 4) * n + i];
+      t2 += part[(long)(p + 8) * n + i];
+      t3 += part[(long)(p + 12) * n + i];
+    }
+    for (; p < parts; p += 4) t0 += part[(long)p * n + i];
+  }
+  red[wave][lane] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (wave == 0 && i < n) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // splits the reduced [NJ][K][HA]-as-[K][DW] buffer into dWq, dWk, dWr ([K][H][A] each)
@@ -538,15 +649,20 @@ __global__ __launch_bounds__(256) void attn_split_dw_kernel(const float* __restr
   dst[(long)k * HA + ha] = red[i];
 }
 
-// dgamma/dbeta: sum the [blocks][2][16] partials
-__global__ __launch_bounds__(64) void attn_reduce_gb_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int blocks, int A) {
-  const int i = threadIdx.x;
-  if (i >= 32) return;
-  const int which = i >> 4, a = i & 15;
+// dgamma/dbeta: sum the [blocks][2][16] partials; one workgroup per output, strided partial sums + fixed-order tree
+__global__ __launch_bounds__(256) void attn_reduce_gb_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int blocks, int A) {
+  __shared__ float red[256];
+  const int which = blockIdx.x >> 4, a = blockIdx.x & 15;
   float t = 0.f;
-  for (int p = 0; p < blocks; ++p) t += part[((long)p * 2 + which) * 16 + a];
-  if (a < A) (which == 0 ? dgamma : dbeta)[a] = t;
+  for (int p = threadIdx.x; p < blocks; p += 256) t += part[((long)p * 2 + which) * 16 + a];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && a < A) (which == 0 ? dgamma : dbeta)[a] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -570,12 +686,15 @@ static int proj_rows_per_block(const AttnDims& d) {
   return (int)rpb;
 }
 static int proj_blocks(const AttnDims& d) { return (int)(((long)d.B * d.F + proj_rows_per_block(d) - 1) / proj_rows_per_block(d)); }
+static bool proj_mfma_ok(const AttnDims& d) { return 3 * d.H * d.NC <= kProjMaxSeg; }
+static int proj3_blocks(const AttnDims& d) { return (int)std::max<long>(1, std::min<long>(((long)d.B * d.F + 63) / 64, 512)); }
+static int proj_parts(const AttnDims& d) { return proj_mfma_ok(d) ? 4 * proj3_blocks(d) : proj_blocks(d); }
 
 static size_t attn_bwd_ws(const AttnDims& d) {
   const size_t act = align_up((size_t)d.H * d.B * d.F * d.A * sizeof(float), 256);
   size_t t = 4 * act;                                                                  // dav, dres, dq, dk
   t += align_up((size_t)d.B * d.H * 2 * 16 * sizeof(float), 256);                       // dgamma/dbeta partials
-  t += align_up((size_t)(proj_blocks(d) + 1) * 3 * d.K * d.H * d.A * sizeof(float), 256);  // dW partials + reduced
+  t += align_up((size_t)(proj_parts(d) + 1) * 3 * d.K * d.H * d.A * sizeof(float), 256);  // dW partials + reduced
   return t;
 }
 
@@ -666,7 +785,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   float* dq = ws.take<float>(nact);
   float* dk = ws.take<float>(nact);
   float* gb_part = ws.take<float>((size_t)B * H * 2 * 16);
-  const int pblocks = proj_blocks(d);
+  const int pblocks = proj_parts(d);
   const int nout = K * NJ * H * A;
   float* wpart = ws.take<float>((size_t)(pblocks + 1) * 3 * K * H * A);
   float* wred = wpart + (size_t)pblocks * nout;
@@ -688,7 +807,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   }
   FIL_CHECK_LAUNCH();
   if (gamma != nullptr) {
-    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(1), dim3(64), 0, st, gb_part, dgamma, dbeta, B * H, A);
+    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, B * H, A);
     FIL_CHECK_LAUNCH();
   }
   {
@@ -714,13 +833,23 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     const float* drsrc = has_res ? (fuse_relu ? dres : dres_in) : nullptr;
     const int DW = NJ * H * A;
     const size_t sh = ((size_t)K * DW + (size_t)kProjTile * (DW + 1) + (size_t)kProjTile * (K + 1)) * sizeof(float);
-    if (sh > 150 * 1024) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: projection tile needs %zu bytes of LDS", sh);
+    if (!proj_mfma_ok(d) && sh > 150 * 1024) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: projection tile needs %zu bytes of LDS", sh);
     ProfScope ps("attn_bwd_proj", st, (double)B * F * 4.0 * K * DW);
-    allow_lds_attn(attn_bwd_proj_kernel, sh);
-    hipLaunchKernelGGL(attn_bwd_proj_kernel, dim3(pblocks), dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, dq, dk, drsrc, dx, wpart, d,
-                       proj_rows_per_block(d));
+    if (proj_mfma_ok(d)) {
+      const size_t sh3 = (size_t)NJ * H * 16 * d.NC * kRS * sizeof(float);
+#define CALL_PROJ3(N)                                                                                                    \
+  allow_lds_attn(attn_bwd_proj3_kernel<N>, sh3);                                                                         \
+  hipLaunchKernelGGL((attn_bwd_proj3_kernel<N>), dim3(proj3_blocks(d)), dim3(kAttnThreads), sh3, st, x, Wq, Wk, Wr, dq, dk, drsrc, \
+                     dx, wpart, d)
+      FIL_ATTN_NC(d.NC, CALL_PROJ3)
+#undef CALL_PROJ3
+    } else {
+      allow_lds_attn(attn_bwd_proj_kernel, sh);
+      hipLaunchKernelGGL(attn_bwd_proj_kernel, dim3(pblocks), dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, dq, dk, drsrc, dx, wpart, d,
+                         proj_rows_per_block(d));
+    }
     FIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, wpart, wred, nout, pblocks);
+    hipLaunchKernelGGL(attn_reduce_kernel, dim3(cdiv(nout, 64)), dim3(256), 0, st, wpart, wred, nout, pblocks);
     FIL_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_split_dw_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, wred, dWq, dWk, dWr, K, H * A, NJ);
     FIL_CHECK_LAUNCH();
