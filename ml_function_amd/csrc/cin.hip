@@ -33,7 +33,7 @@ static int check_shape(const char* fn, int B, int F, int K, int L, const int* H,
   if (B < 0 || F < 1 || K < 1 || L < 1 || H == nullptr) return fail(FIL_ERR_ARG, "%s: bad shape B=%d F=%d K=%d L=%d", fn, B, F, K, L);
   if (L > kCinMaxL) return fail(FIL_ERR_UNSUPPORTED, "%s: L=%d > %d", fn, L, kCinMaxL);
   if (F > 64) return fail(FIL_ERR_UNSUPPORTED, "%s: F=%d > 64 fields", fn, F);
-  if ((long)B * K * 256 >= (1L << 31)) return fail(FIL_ERR_UNSUPPORTED, "%s: B*K = %ld rows exceed the 32-bit offset range of the kernels", fn, (long)B * K);
+  if ((long)B * K * 256 * 4 >= (1L << 31)) return fail(FIL_ERR_UNSUPPORTED, "%s: B*K = %ld rows exceed the 2 GiB buffer-descriptor range of the kernels", fn, (long)B * K);
   s.B = B; s.F = F; s.K = K; s.L = L;
   for (int l = 0; l < L; ++l) {
     if (H[l] < 1) return fail(FIL_ERR_ARG, "%s: H[%d]=%d", fn, l, H[l]);
@@ -69,12 +69,12 @@ struct DwPlan {
 static DwPlan dw_plan(long M, int C, int H) {
   DwPlan p;
   p.chunks = chunks_of(H);
-  // 32 channel rows per wave and ~4 waves per SIMD: the kernel hides its queue refills with thread-level parallelism
-  // (64 rows per wave at one wave per SIMD measured 55 TFLOP/s against 105 for this shape)
+  // 32 channel rows per wave, about two waves per SIMD (measured best: 124 TFLOP/s at the north-star shape;
+  // 64 rows per wave at one wave per SIMD: 67)
   p.MB = env_int("FIL_CIN_DW_MB", 1) == 2 ? 2 : 1;
   const int waves_c = cdiv(C, 32 * p.MB);
   p.blocks_x = cdiv(waves_c, 4);
-  const int target_waves = env_int("FIL_CIN_DW_WAVES", 4096);
+  const int target_waves = env_int("FIL_CIN_DW_WAVES", 2048);
   int splits = std::max(1, (target_waves + (4 * p.blocks_x * p.chunks) / 2) / (4 * p.blocks_x * p.chunks));
   splits = std::min(splits, 256);
   long rps = (M + splits - 1) / splits;

@@ -32,6 +32,19 @@ int main() {
     char buf[128]; snprintf(buf, sizeof buf, "%s MB=%d D=%d splits=%d waves=%d", name, MB, depth, sp, waves_c * sp);
     timeit(buf, [&] { hipLaunchKernelGGL(kern, dim3(bx, sp, 1), dim3(256), 0, 0, g, HS, x, xp, HS, part, M, F, Hp, H, (int)rps); });
   };
+  run(cin_dw3b_kernel<2, false, 8>, 2, 8, 13, "dw3b");
+  run(cin_dw3b_kernel<2, false, 12>, 2, 12, 13, "dw3b");
+  run(cin_dw3b_kernel<1, false, 8>, 1, 8, 26, "dw3b");
+  run(cin_dw3b_kernel<1, false, 8>, 1, 8, 13, "dw3b");
+  run(cin_dw3_kernel<2, true, 8>, 2, 8, 13, "dw3 XONES (no x loads)");
+  run(cin_dw3_kernel<1, true, 8>, 1, 8, 26, "dw3 XONES (no x loads)");
+  if (getenv("PD_MODE") && atoi(getenv("PD_MODE")) == 1) { run(cin_dw3_kernel<2, false, 8>, 2, 8, 13, "dw3"); return 0; }
+  if (getenv("PD_MODE") && atoi(getenv("PD_MODE")) == 2) { run(cin_dw3_kernel<1, false, 8>, 1, 8, 26, "dw3"); return 0; }
+  run(cin_dw3a_kernel<2, false, 8>, 2, 8, 13, "dw3a");
+  run(cin_dw3a_kernel<2, false, 12>, 2, 12, 13, "dw3a");
+  run(cin_dw3a_kernel<1, false, 8>, 1, 8, 13, "dw3a");
+  run(cin_dw3a_kernel<1, false, 16>, 1, 16, 13, "dw3a");
+  run(cin_dw3a_kernel<1, false, 8>, 1, 8, 26, "dw3a");
   run(cin_dw3_kernel<2, false, 8>, 2, 8, 13, "dw3");
   run(cin_dw3_kernel<2, false, 16>, 2, 16, 13, "dw3");
   run(cin_dw3_kernel<2, false, 4>, 2, 4, 13, "dw3");
