@@ -78,14 +78,15 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *   x [B,F,K]; W[l] [H_{l-1}*F, H_l] with channel c = h*F+f (H_0 = F); bias[l] [H_l];
  *   dense_w [L*K], dense_b [1] (ignored when output_dim != 1).
  *   fwd outputs: out [B] (output_dim==1; may be NULL otherwise), pooled [B, L*K] (always written),
- *                saved = feature maps x^1..x^{L-1}, each [B,H_l,K], packed back to back
- *                (fil_cin_saved_bytes; needed by bwd; the last layer's map is never materialised).
+ *                saved = opaque buffer of fil_cin_saved_bytes bytes that bwd needs (internally: x transposed to
+ *                [B*K][F] and the feature maps x^1..x^{L-1} as [B*K][128*ceil(H_l/128)]; the last layer's map is
+ *                never materialised).
  *   bwd: g = dL/dout [B] (output_dim==1) or dL/dpooled [B,L*K];
  *        writes dx [B,F,K], dW[l], dbias[l], ddense_w [L*K], ddense_b [1] (dense grads only if output_dim==1).
  *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) with the last layer contracted against
  *             sum_n W_L[c,n] (its feature map is only ever sum-pooled, so this is the same function at 1/H_L of the flops);
  *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
- *   Limits: H_l <= 256, L <= 8.
+ *   Limits: F <= 64, H_l <= 256, L <= 8, L*K <= 255, B*K < 2^21.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
 size_t fil_cin_fwd_workspace_bytes(int B, int F, int K, int L, const int* H);

@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
     for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl] = 0.f;
   }
   int hprev = -HPP;  // h base of the period the previous tile belongs to (the fake tile before the first one stores nothing)
+  float gout[MB][HPP];
+  const bool gvec = gx0T == nullptr;  // G^{l-1} rows are 512-byte aligned; the layer-1 side buffer [M][F] is not
 
   auto contract_slot = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
     const int sp = 16 * tp + rr;
@@ -288,10 +290,22 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
       gx[mb] = fmaf(dz, xs[(mb * JT + j) * 256], gx[mb]);
       dxs[(mb * JT + j) * 256] = fmaf(dz, xpv[mb][hl], dxs[(mb * JT + j) * 256]);
       if (j == JT - 1) {
-        const float tot = gx[mb] + __shfl_xor(gx[mb], 32);
-        const int h = hb + hl;
-        if (half == 0 && vq[mb] && h >= 0 && h < Hp) gdst[mb][h] = tot + dpp[mb];
+        // h = hb + hl is complete: collect the period's HPP values and store them with one 16/8/4-byte access
+        // (single-dword stores at a row stride turn into one partial-line write each: 7x write amplification)
+        gout[mb][hl] = gx[mb] + __shfl_xor(gx[mb], 32) + dpp[mb];
         gx[mb] = 0.f;
+        if (hl == HPP - 1 && half == 0 && vq[mb] && hb >= 0) {
+          float* dst = gdst[mb] + hb;
+          if (gvec && hb + HPP <= Hp) {
+            if constexpr (HPP == 4) *reinterpret_cast<float4*>(dst) = make_float4(gout[mb][0], gout[mb][1], gout[mb][2], gout[mb][3]);
+            else if constexpr (HPP == 2) *reinterpret_cast<float2*>(dst) = make_float2(gout[mb][0], gout[mb][1]);
+            else dst[0] = gout[mb][0];
+          } else {
+#pragma unroll
+            for (int u = 0; u < HPP; ++u)
+              if (hb + u < Hp) dst[u] = gout[mb][u];
+          }
+        }
       }
     }
   };
