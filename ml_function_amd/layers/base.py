@@ -14,6 +14,8 @@ def shape_of(inputs):
     """Keras-like input_shape: a tuple for a tensor, a list of shapes for a list of tensors (nested lists allowed)."""
     if isinstance(inputs, (list, tuple)):
         return [shape_of(t) for t in inputs]
+    if inputs is None:
+        return None
     return tuple(inputs.shape)
 
 

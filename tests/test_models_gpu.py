@@ -1,0 +1,86 @@
+"""N2/N4: whole models assembled from the re-hosted layers run on the HIP path, match the oracle graph composed the
+same way, and train (Adam + binary cross-entropy, as example/ctr_example/un_seq.py:61-62 does)."""
+import numpy as np
+import pytest
+import torch
+
+from ml_function_amd import models
+from oracle import graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, n_dense, vocab, seed=0):
+    rng = np.random.default_rng(seed)
+    dense = torch.tensor(rng.random((B, n_dense)), dtype=torch.float32, device="cuda")
+    idx = torch.tensor(np.stack([rng.integers(0, v, B) for v in vocab], 1), device="cuda")
+    return dense, idx
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def test_xdeepfm_matches_oracle_composition():
+    vocab = [7, 11, 5, 13, 3, 17]
+    B, K = 33, 8
+    info = models.make_sparse_info(vocab, embed_dim=K)
+    fi = models.FeatureInput(sparseInfo=info, useLinear=True, useAddLinear=True, useFlattenLinear=True)
+    model = models.CTRModel(fi, models.XDeepFM(conv_size=[16, 12], hidden_units=[32, 16])).cuda()
+    dense, idx = _inputs(B, 3, vocab)
+    out = model(dense, idx)
+    assert out.shape == (B, 1) and float(out.detach().min()) > 0 and float(out.detach().max()) < 1
+    # oracle: same parameters, reference graph in float64 on the CPU
+    D = lambda t: t.detach().cpu().double()
+    emb = fi.sparse_embed.embeddings
+    offs = fi.sparse_embed.offsets.cpu()
+    tables = [D(emb)[offs[f]:offs[f] + vocab[f]] for f in range(len(vocab))]
+    sparse_embed = graph.sparse_embed(tables, [idx[:, f:f + 1].cpu() for f in range(len(vocab))])
+    lin_tab = D(fi.linear_embed.embeddings)
+    loff = fi.linear_embed.offsets.cpu()
+    linear = sum(lin_tab[loff[f]:loff[f] + vocab[f]][idx[:, f].cpu()] for f in range(len(vocab)))  # use_add, flattened [B,1]
+    body = model.body
+    cin_out = graph.cin(torch.cat(sparse_embed, 1), [D(w)[0] for w in body.cin.conv_kernels], [D(b) for b in body.cin.conv_biases],
+                        D(body.cin.logit_kernel), D(body.cin.logit_bias))
+    x = graph.stack_layer([D(dense)[:, i:i + 1] for i in range(3)] + sparse_embed)
+    for h in body.dnn.hidden_list:
+        y = x @ D(h.dense.kernel) + D(h.dense.bias)
+        x = torch.relu(x + y) if x.shape == y.shape else torch.relu(y)
+    dnn_out = x @ D(body.dnn.logit_layer.kernel) + D(body.dnn.logit_layer.bias)
+    want = torch.sigmoid(linear + cin_out + dnn_out)
+    assert rel(out, want) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["FM", "DeepFM", "DCN", "XDeepFM", "AutoInt"])
+def test_zoo_models_train(name):
+    torch.manual_seed(0)
+    vocab = [9, 4, 6, 12, 5]
+    B, K = 64, 8
+    info = models.make_sparse_info(vocab, embed_dim=K)
+    single_linear = name == "XDeepFM"
+    fi = models.FeatureInput(sparseInfo=info, useLinear=name in ("FM", "DeepFM", "XDeepFM"), useAddLinear=single_linear,
+                             useFlattenLinear=single_linear)
+    body = {"FM": lambda: models.FM(), "DeepFM": lambda: models.DeepFM(hidden_units=[16, 8]),
+            "DCN": lambda: models.DCN(hidden_units=[16, 8], cross_hidden=2),
+            "XDeepFM": lambda: models.XDeepFM(conv_size=[8, 8], hidden_units=[16, 8]),
+            "AutoInt": lambda: models.AutoInt(attention_dim=8, attention_head_dim=2)}[name]()
+    model = models.CTRModel(fi, body).cuda()
+    dense, idx = _inputs(B, 2, vocab, seed=1)
+    if name in ("FM", "AutoInt"):
+        dense_in = None if name == "AutoInt" else dense
+    else:
+        dense_in = dense
+    y = torch.tensor(np.random.default_rng(2).integers(0, 2, B), dtype=torch.float32, device="cuda")
+    out = model(dense_in, idx)  # builds the lazily created weights
+    opt = torch.optim.Adam(model.parameters(), lr=0.05)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        out = model(dense_in, idx)
+        p = out[:, 1] if out.shape[1] == 2 else out[:, 0]
+        loss = torch.nn.functional.binary_cross_entropy(p.clamp(1e-6, 1 - 1e-6), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] * 0.9, losses[::6]
