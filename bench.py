@@ -148,6 +148,27 @@ def side_benchmark(args):
         "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps}))
 
 
+def pmc_traffic(scope):
+    """HBM bytes per launch of the kernel behind profiler scope `scope`, from the newest committed PMC summary
+    (profiles/r*_pmc_traffic.json, written by tools/pmc_traffic.py from two separate rocprofv3 --pmc passes of this
+    same command; counters cannot be read from inside the timed run).  None when no summary matches."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    m = re.match(r"cin_(fwd|bwd_dz|bwd_dw)_l(\d)$", scope)
+    if not files or not m:
+        return None
+    prefix = {"fwd": "cin_fwd3_kernel", "bwd_dz": "cin_dz3_kernel", "bwd_dw": "cin_dw3_kernel<1,false"}[m.group(1)]
+    with open(files[-1]) as fh:
+        per = json.load(fh)["per_launch"]
+    hits = sorted((v["first_dispatch"], v["hbm_bytes"]) for k, v in per.items() if k.startswith(prefix))
+    if len(hits) != 2:
+        return None
+    # two MFMA layers (l = 1, 2): the forward visits l1 then l2, the backward l2 then l1
+    first_is_l1 = m.group(1) == "fwd"
+    return hits[0 if (m.group(2) == "1") == first_is_l1 else 1][1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,7 +251,7 @@ def main():
                                    "(BASELINE.json configs[3])", "global_batch": world * B_PER_GPU,
                        "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if world > 1 else 0},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                          "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["work"]},
             "kernels": kernels, "gpu_kernel_ms_per_step": gpu_ms,
         }

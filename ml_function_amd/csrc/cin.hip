@@ -66,29 +66,64 @@ static double gemm_flops(long M, int Hp, int F, int H) { return 2.0 * (double)M 
 struct DwPlan {
   int MB, blocks_x, splits, rows_per_split, chunks;
 };
+static int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// Row splits of the dW GEMM, from a launch-time model fitted on MI355X (profiles/r01_dw_split_sweep.txt).
+// Workgroups are dealt evenly over the CUs, at most 3 resident per CU, in rounds of 3*CUs; a round with r resident
+// workgroups per CU spends t(r) = {1.05, 1.39, 1.96} * 1e-4 ms per row of its split (two resident waves per SIMD
+// already cover the MFMA pipe, so a third adds its full share of time); each split also costs one partial [C,H]
+// write + re-read in the reduction (served from the Infinity Cache, about 6 TB/s).  Pick the cheapest split count.
 static DwPlan dw_plan(long M, int C, int H) {
   DwPlan p;
   p.chunks = chunks_of(H);
-  // 32 channel rows per wave, about two waves per SIMD (measured best: 124 TFLOP/s at the north-star shape;
-  // 64 rows per wave at one wave per SIMD: 67)
-  p.MB = env_int("FIL_CIN_DW_MB", 1) == 2 ? 2 : 1;
+  p.MB = env_int("FIL_CIN_DW_MB", 1) == 2 ? 2 : 1;   // 64 rows per wave measured slower (67 vs 122 TFLOP/s)
   const int waves_c = cdiv(C, 32 * p.MB);
   p.blocks_x = cdiv(waves_c, 4);
-  const int target_waves = env_int("FIL_CIN_DW_WAVES", 2048);
-  int splits = std::max(1, (target_waves + (4 * p.blocks_x * p.chunks) / 2) / (4 * p.blocks_x * p.chunks));
-  splits = std::min(splits, 256);
-  long rps = (M + splits - 1) / splits;
-  rps = std::max<long>(2 * kDwDepth, (rps + 2 * kDwDepth - 1) / (2 * kDwDepth) * (2 * kDwDepth));
+  const long tiles = (long)p.blocks_x * p.chunks;
+  const long ncu = cu_count();
+  const long unit = 2 * kDwDepth;
+  auto rows_of = [&](int splits) { return std::max<long>(unit, ((M + splits - 1) / splits + unit - 1) / unit * unit); };
+  int best = env_int("FIL_CIN_DW_SPLITS", 0);
+  if (best <= 0) {
+    static const double t_of[4] = {0.0, 1.05e-4, 1.39e-4, 1.96e-4};
+    double best_ms = -1.0;
+    for (int sp = 1; sp <= 256; ++sp) {
+      const long rps = rows_of(sp);
+      const long real = (M + rps - 1) / rps;           // splits that actually get rows
+      if (real != sp && sp > 1) continue;              // same plan as a smaller sp
+      long wgs = tiles * real;
+      double per_row = 0.0;
+      while (wgs > 0) {
+        const long round = std::min(wgs, 3 * ncu);
+        per_row += t_of[std::min<long>(3, (round + ncu - 1) / ncu)];
+        wgs -= round;
+      }
+      const double ms = (double)rps * per_row * p.MB + (double)real * C * H * 4.0 / 6e9;
+      if (best_ms < 0 || ms < best_ms) best = sp, best_ms = ms;
+      if (rps == unit) break;
+    }
+  }
+  best = std::min(std::max(best, 1), 256);
+  const long rps = rows_of(best);
   p.rows_per_split = (int)rps;
-  p.splits = (int)((M + rps - 1) / rps);
+  p.splits = (int)std::max<long>(1, (M + rps - 1) / rps);
   return p;
 }
 
 static int launch_dw3(hipStream_t st, const DwPlan& p, const float* gT, int HS, const float* xT, const float* xpT, int xps, float* part,
                       long M, int F, int Hp, int H) {
-  const dim3 grid(p.blocks_x, p.splits, p.chunks);
+  const int items = p.blocks_x * p.splits * p.chunks;
+  const dim3 grid((items + 7) / 8 * 8);
 #define FIL_DW3(MBV, ONES) \
-  hipLaunchKernelGGL((cin_dw3_kernel<MBV, ONES>), grid, dim3(kCinThreads), 0, st, gT, HS, xT, xpT, xps, part, (int)M, F, Hp, H, p.rows_per_split)
+  hipLaunchKernelGGL((cin_dw3_kernel<MBV, ONES>), grid, dim3(kCinThreads), 0, st, gT, HS, xT, xpT, xps, part, (int)M, F, Hp, H, p.rows_per_split, \
+                     p.blocks_x, p.chunks, items)
   if (xT == nullptr) {
     if (p.MB == 2) FIL_DW3(2, true); else FIL_DW3(1, true);
   } else {

@@ -393,12 +393,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
 template <int MB, bool XONES, int DEPTH = kDwDepth>
 __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ xT,
                                                           const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
-                                                          int Hp, int H, int rows_per_split) {
+                                                          int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int C = Hp * F;
-  const int chunk = blockIdx.z;
-  const int c0 = (blockIdx.x * 4 + wave) * (32 * MB);
+  // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup i
+  // of XCD i%8 takes item (i%8)*(grid/8) + i/8 of the split-major item list: an XCD then streams only its own
+  // row splits of G / x / x^{l-1} through its L2 instead of all of them (grid is a multiple of 8).
+  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (item >= items) return;
+  const int bx = item % blocks_x;
+  const int chunk = (item / blocks_x) % chunks;
+  const int split = item / (blocks_x * chunks);
+  const int c0 = (bx * 4 + wave) * (32 * MB);
   if (c0 >= C) return;
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(gT, (long)M * HS * 4);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(XONES ? gT : xT, (long)M * F * 4);
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
     fo[mb] = (half * F + (cc - hh * F)) * 4;
   }
   const int go = (half * HS + chunk * 128 + 4 * r) * 4;
-  const int m_lo = blockIdx.y * rows_per_split;
+  const int m_lo = split * rows_per_split;
   const int m_hi = min(M, m_lo + rows_per_split);
   const int steps = (m_hi - m_lo + 1) >> 1;
   const int groups = (steps + DEPTH - 1) / DEPTH;
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float* pout = part + (long)blockIdx.y * C * H;
+  float* pout = part + (long)split * C * H;
   const bool vec = (H & 3) == 0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
