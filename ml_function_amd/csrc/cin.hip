@@ -56,6 +56,9 @@ static int mb_rows(long M) {
   return cdiv((int)std::min<long>(M, 1L << 30), 64) >= 768 ? 2 : 1;
 }
 
+// FIL_CIN_SYM=0 turns the symmetric first-layer kernels off (tuning / A-B knob; results agree to fp32 rounding)
+static bool sym_first_layer() { return env_int("FIL_CIN_SYM", 1) != 0; }
+
 static const char* kFwdNames[kCinMaxL] = {"cin_fwd_l1", "cin_fwd_l2", "cin_fwd_l3", "cin_fwd_l4", "cin_fwd_l5", "cin_fwd_l6", "cin_fwd_l7", "cin_fwd_l8"};
 static const char* kDwNames[kCinMaxL] = {"cin_bwd_dw_l1", "cin_bwd_dw_l2", "cin_bwd_dw_l3", "cin_bwd_dw_l4", "cin_bwd_dw_l5", "cin_bwd_dw_l6", "cin_bwd_dw_l7", "cin_bwd_dw_l8"};
 static const char* kDzNames[kCinMaxL] = {"cin_bwd_dz_l1", "cin_bwd_dz_l2", "cin_bwd_dz_l3", "cin_bwd_dz_l4", "cin_bwd_dz_l5", "cin_bwd_dz_l6", "cin_bwd_dz_l7", "cin_bwd_dz_l8"};
@@ -118,12 +121,12 @@ static DwPlan dw_plan(long M, int C, int H) {
 }
 
 static int launch_dw3(hipStream_t st, const DwPlan& p, const float* gT, int HS, const float* xT, const float* xpT, int xps, float* part,
-                      long M, int F, int Hp, int H) {
+                      long M, int F, int Hp, int H, int symD = 0) {
   const int items = p.blocks_x * p.splits * p.chunks;
   const dim3 grid((items + 7) / 8 * 8);
 #define FIL_DW3(MBV, ONES) \
   hipLaunchKernelGGL((cin_dw3_kernel<MBV, ONES>), grid, dim3(kCinThreads), 0, st, gT, HS, xT, xpT, xps, part, (int)M, F, Hp, H, p.rows_per_split, \
-                     p.blocks_x, p.chunks, items)
+                     p.blocks_x, p.chunks, items, symD)
   if (xT == nullptr) {
     if (p.MB == 2) FIL_DW3(2, true); else FIL_DW3(1, true);
   } else {
@@ -159,22 +162,23 @@ static size_t fwd_ws_bytes(const CinShape& s) {
   t += align_up(wf_floats(s) * sizeof(float), 256);                                                      // packed W
   return t;
 }
+// floats of the dW partial-sum buffer: the largest splits * C * H over the layers (both first-layer forms, so the
+// size does not depend on the FIL_CIN_SYM knob) and the last layer's rank-one dW (C' = Hp, H' = F)
+static size_t dw_part_floats(const CinShape& s) {
+  size_t pmax = 0;
+  for (int l = 0; l < s.L; ++l) pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(l) * s.F, s.H[l]).splits * s.Hp(l) * s.F * s.H[l]);
+  const int csym = s.F * (s.F / 2 + 1);
+  pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
+  pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
+  return pmax;
+}
 static size_t bwd_ws_bytes(const CinShape& s) {
   const size_t LK = (size_t)s.L * s.K;
   const size_t M = (size_t)s.M();
   size_t t = 0;
   t += align_up((size_t)s.B * LK * sizeof(float), 256);                  // dP
   t += 2 * align_up(M * s.HSmax() * sizeof(float), 256);                 // G ping-pong (also the last layer's x*dP rows)
-  size_t pmax = 0;
-  for (int l = 0; l < s.L; ++l) {
-    const DwPlan p = dw_plan(s.M(), s.Hp(l) * s.F, s.H[l]);
-    pmax = std::max(pmax, (size_t)p.splits * s.Hp(l) * s.F * s.H[l]);
-  }
-  {
-    const DwPlan p = dw_plan(s.M(), s.Hp(s.L - 1), s.F);                  // last layer's rank-one dW: C' = Hp, H' = F
-    pmax = std::max(pmax, (size_t)p.splits * s.Hp(s.L - 1) * s.F);
-  }
-  t += align_up(pmax * sizeof(float), 256);                              // dW partials
+  t += align_up(dw_part_floats(s) * sizeof(float), 256);                 // dW partials
   const size_t nblk = (size_t)cdiv(std::max(1, s.B), kHeadChunk);
   const size_t ncol = (M + kColRows - 1) / kColRows;
   t += align_up(std::max(ncol * s.HSmax(), nblk * (LK + 1)) * sizeof(float), 256);   // colsum / head partials
@@ -258,10 +262,19 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       pa.chunks[l] = 1;
     } else {
       const int chunks = chunks_of(Hl);
-      const long npack = (long)chunks * Hp * 2 * JT * 128;
-      hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
-      ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
-      cin_launch_fwd3(st, MB, JT, dim3(cdiv((int)M, 128 * MB), chunks), xT, xpT, xps, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hp, Hl);
+      if (l == 0 && sym_first_layer()) {
+        // first layer: x^{l-1} = x, reduce over unordered field pairs (half the steps)
+        const int JTs = cin_jt_sym(F);
+        const long npack = (long)chunks * F * 2 * JTs * 128;
+        hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
+        ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
+        cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl);
+      } else {
+        const long npack = (long)chunks * Hp * 2 * JT * 128;
+        hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
+        ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
+        cin_launch_fwd3(st, MB, JT, dim3(cdiv((int)M, 128 * MB), chunks), xT, xpT, xps, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hp, Hl);
+      }
     }
     FIL_CHECK_LAUNCH();
     xpT = xoutT;
@@ -309,10 +322,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   float* Gbuf[2];
   Gbuf[0] = ws.take<float>((size_t)M * s.HSmax());
   Gbuf[1] = ws.take<float>((size_t)M * s.HSmax());
-  size_t pmax = 0;
-  for (int l = 0; l < L; ++l) pmax = std::max(pmax, (size_t)dw_plan(M, s.Hp(l) * F, H[l]).splits * s.Hp(l) * F * H[l]);
-  pmax = std::max(pmax, (size_t)dw_plan(M, s.Hp(L - 1), F).splits * s.Hp(L - 1) * F);
-  float* part = ws.take<float>(pmax);
+  float* part = ws.take<float>(dw_part_floats(s));
   const int nblk = cdiv(B, kHeadChunk);
   const int ncol = (int)((M + kColRows - 1) / kColRows);
   float* small = ws.take<float>(std::max((size_t)ncol * s.HSmax(), (size_t)nblk * (LK + 1)));
@@ -401,15 +411,22 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     // dW
     int parts;
+    const int symD = (l == 0 && sym_first_layer()) ? F / 2 + 1 : 0;   // unordered field pairs: half the channels
+    const int Cl = symD > 0 ? F * symD : Hp * F;
     {
       ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl));
-      parts = launch_dw3(st, dw_plan(M, Hp * F, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl);
+      parts = launch_dw3(st, dw_plan(M, Cl, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl, symD);
     }
     FIL_CHECK_LAUNCH();
-    const long nW = (long)Hp * F * Hl;
+    const long nW = (long)Cl * Hl;
     {
       ProfScope ps("cin_reduce_dw", st, (double)(parts + 1) * nW * sizeof(float));
-      hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, dW[l], nW, parts);
+      // (the packed-W buffer of the dZ kernel is idle until this layer's pack below: scratch for the pair-indexed sum)
+      hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, symD > 0 ? Wz : dW[l], nW, parts);
+      if (symD > 0) {
+        const long full = (long)F * F * Hl;
+        hipLaunchKernelGGL(cin_expand_sym_kernel, dim3((int)std::min<long>((full + 255) / 256, 2048)), dim3(256), 0, st, Wz, dW[l], F, symD, Hl);
+      }
     }
     FIL_CHECK_LAUNCH();
     // dZ -> G^{l-1}, dX

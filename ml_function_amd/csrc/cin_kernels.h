@@ -85,10 +85,53 @@ static __global__ __launch_bounds__(256) void cin_pack_wf_kernel(const float* __
   }
 }
 
+// dW[(h,f),n] = dW[(f,h),n] = Dsym[pair(h,f)][n]: expands the pair-indexed first-layer weight gradient
+static __global__ __launch_bounds__(256) void cin_expand_sym_kernel(const float* __restrict__ dsym, float* __restrict__ dW, int F, int D, int H) {
+  const long total = (long)F * F * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % H);
+    const int c = (int)(i / H);
+    const int h = c / F, f = c - h * F;
+    const int d1 = f >= h ? f - h : f - h + F;
+    const long pair = d1 <= F / 2 ? (long)h * D + d1 : (long)f * D + (F - d1);
+    dW[i] = dsym[pair * H + n];
+  }
+}
+
+// Symmetric first layer: Wf[chunk][h][d < JT2][128] = pair weight of (h, f = (h+d) mod F): W[(h,h)] for d = 0,
+// W[(h,f)] + W[(f,h)] for 0 < d <= F/2 (halved at d = F/2 when F is even: that pair is met from both ends), else 0.
+static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float* __restrict__ W, float* __restrict__ Wf, int F, int H, int JT2,
+                                                              int chunks) {
+  const long total = (long)chunks * F * JT2 * 128;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i & 127);
+    long t = i >> 7;
+    const int d = (int)(t % JT2);
+    t /= JT2;
+    const int h = (int)(t % F), chunk = (int)(t / F);
+    const int n = chunk * 128 + col;
+    float v = 0.f;
+    if (n < H && d <= F / 2) {
+      const int f = (h + d) % F;
+      if (d == 0) v = W[((long)h * F + h) * H + n];
+      else {
+        v = W[((long)h * F + f) * H + n] + W[((long)f * F + h) * H + n];
+        if (2 * d == F) v *= 0.5f;
+      }
+    }
+    Wf[i] = v;
+  }
+}
+
 // Forward layer, streaming form.  Wave = 32*MB rows x 128 columns (one chunk); step (h, j): half 0 / 1 take
 // f = 2j / 2j+1; the W row pair of step s = h*JT + j is Wf row 2s+half, so the B-operand stream is linear.
 // x^{l-1}[m,h] is one dword per h (prefetched); the queue holds DEPTH steps of B operands (16 B per lane each).
-template <int MB, int JT>
+//
+// SYM (first layer only, x^{l-1} = x): Z[m,(h,f)] = x[m,h] x[m,f] is symmetric in (h,f), so the reduction runs over the
+// F*(F/2+1) unordered pairs (h, f = (h+d) mod F), d = 0..F/2, against pre-summed weights W[(h,f)] + W[(f,h)]
+// (cin_pack_wf_sym_kernel): half the MFMA work.  Step (h, j) then multiplies by x[m,(h + 2j + half) mod F], which
+// moves with h, so the x fragment is re-fetched per h (one h ahead) instead of living in registers for the whole run.
+template <int MB, int JT, bool SYM = false>
 __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                           const float* __restrict__ Wf, const float* __restrict__ bias,
                                                           float* __restrict__ xoutT, int HS, float* __restrict__ pool_part, int M,
@@ -104,16 +147,46 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   long mq[MB];
   bool vq[MB];
   float xr[MB][JT];
+  float xn[SYM ? MB : 1][SYM ? JT : 1];
+  int d0[SYM ? JT : 1];  // (2j + half) mod F
+  if constexpr (SYM) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) d0[j] = (2 * j + half) % F;
+  }
+  // SYM: x[m, (h + 2j + half) mod F] for every j (rows past M are clamped: computed, never stored)
+  auto load_x = [&](int h, float (&dst)[SYM ? MB : 1][SYM ? JT : 1]) {
+    if constexpr (SYM) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float* xrow = xT + mq[mb] * F;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          int idx = h + d0[j];
+          idx -= idx >= F ? F : 0;
+          dst[mb][j] = xrow[idx];
+        }
+      }
+    }
+  };
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = wrow0 + mb * 32 + r;
     vq[mb] = m < M;
     mq[mb] = vq[mb] ? m : M - 1;
+    if constexpr (!SYM) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const int f = 2 * j + half;
-      xr[mb][j] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+      for (int j = 0; j < JT; ++j) {
+        const int f = 2 * j + half;
+        xr[mb][j] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+      }
     }
+  }
+  if constexpr (SYM) {
+    load_x(0, xn);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) xr[mb][j] = xn[mb][j];
   }
   f32x16 acc[MB][4];
 #pragma unroll
@@ -141,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
       if (more) xpn[mb] = xprow[mb][h + 1];
+    if constexpr (SYM) load_x(more ? h + 1 : h, xn);
     const float4* wh = wbase + (long)h * (2 * JT) * 32;
     const float4* whn = wbase + (long)(more ? h + 1 : h) * (2 * JT) * 32;
 #pragma unroll
@@ -160,6 +234,12 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) xpv[mb] = xpn[mb];
+    if constexpr (SYM) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) xr[mb][j] = xn[mb][j];
+    }
   }
 
   // ---- epilogue: + bias, store [M][HS] (lane r owns columns 4r..4r+3 of the chunk), sum-pool over columns
@@ -393,10 +473,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
 template <int MB, bool XONES, int DEPTH = kDwDepth>
 __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ xT,
                                                           const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
-                                                          int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items) {
+                                                          int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items, int symD) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  const int C = Hp * F;
+  // symD > 0 (first layer, x^{l-1} = x): channels are the unordered pairs c = h*symD + d <-> (h, f = (h+d) mod F)
+  const int C = symD > 0 ? F * symD : Hp * F;
   // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup i
   // of XCD i%8 takes item (i%8)*(grid/8) + i/8 of the split-major item list: an XCD then streams only its own
   // row splits of G / x / x^{l-1} through its L2 instead of all of them (grid is a multiple of 8).
@@ -417,9 +498,10 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
     const int c = c0 + mb * 32 + r;
     cv[mb] = c < C;
     const int cc = cv[mb] ? c : C - 1;
-    const int hh = cc / F;
+    const int hh = symD > 0 ? cc / symD : cc / F;
+    const int ff = symD > 0 ? (hh + (cc - hh * symD)) % F : cc - hh * F;
     ho[mb] = (half * xps + hh) * 4;            // byte offsets of the lane's column inside row (m_lo + half)
-    fo[mb] = (half * F + (cc - hh * F)) * 4;
+    fo[mb] = (half * F + ff) * 4;
   }
   const int go = (half * HS + chunk * 128 + 4 * r) * 4;
   const int m_lo = split * rows_per_split;

@@ -7,6 +7,12 @@ namespace fil {
 // JT = steps per h of the streaming kernels: ceil(F/2) rounded up to a multiple of 4 (menu 4..32, F <= 64)
 inline int cin_jt_of(int F) { return ((F + 1) / 2 + 3) / 4 * 4; }
 
+// steps per h of the symmetric first-layer kernels: d = 0..F/2 in pairs, rounded up to an even count (menu 2..18)
+inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
+
+void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT,
+                         int HS, float* pool_part, int M, int F, int H);
+
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
                      const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H);
 
