@@ -151,7 +151,9 @@ static size_t wf_floats(const CinShape& s) {
 }
 static int dz_periods(const CinShape& s, int l) { return cdiv(s.Hp(l), cin_dz_h_per_period(s.JT())); }
 static size_t wz_floats(const CinShape& s) {
-  size_t w = 0;
+  const int jts = cin_jt_sym(s.F);   // symmetric first layer: its tile count and the pair-indexed dW sum both fit below
+  size_t w = ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
+  w = std::max(w, (size_t)s.F * (s.F / 2 + 1) * s.H[0]);
   for (int l = 0; l < s.L; ++l) w = std::max(w, ((size_t)dz_periods(s, l) * cin_dz_tiles_per_period(s.JT()) + 1) * 32 * s.HS(l));
   return w;
 }
@@ -433,15 +435,26 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     {
       const int NHMAX = HSl / 2;                  // 64 (H <= 128) or 128
       const int MB = NHMAX == 128 ? 1 : mb_rows(M);
-      const int periods = dz_periods(s, l);
-      const int tiles = periods * cin_dz_tiles_per_period(JT) + 1;
-      const long npack = (long)tiles * 32 * HSl;
-      hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
       const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
-      ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
-      cin_launch_dz3(st, MB, JT, NHMAX, dim3(cdiv((int)M, 128 * MB)), G, HSl, Wz, xT, xpT, xps, dPprev, (int)LK, K,
-                     l > 0 ? Gbuf[cur ^ 1] : nullptr, l > 0 ? s.HS(l - 1) : 0, l == 0 ? gx0T : nullptr, dxT, dx_started ? 1 : 0,
-                     (int)M, F, Hp, Hl, periods);
+      if (l == 0 && sym_first_layer() && F >= 2) {
+        // first layer over unordered field pairs (half the tiles); F = 1 would make both lane halves hit one word
+        const int JTs = cin_jt_sym(F);
+        const int periods = cdiv(F, cin_dz_h_per_period(JTs));
+        const int tiles = periods * cin_dz_tiles_per_period(JTs) + 1;
+        const long npack = (long)tiles * 32 * HSl;
+        hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
+        ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
+        cin_launch_dz3_sym(st, MB, JTs, NHMAX, dim3(cdiv((int)M, 128 * MB)), G, HSl, Wz, xT, gx0T, dxT, dx_started ? 1 : 0, (int)M, F, Hl, periods);
+      } else {
+        const int periods = dz_periods(s, l);
+        const int tiles = periods * cin_dz_tiles_per_period(JT) + 1;
+        const long npack = (long)tiles * 32 * HSl;
+        hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
+        ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
+        cin_launch_dz3(st, MB, JT, NHMAX, dim3(cdiv((int)M, 128 * MB)), G, HSl, Wz, xT, xpT, xps, dPprev, (int)LK, K,
+                       l > 0 ? Gbuf[cur ^ 1] : nullptr, l > 0 ? s.HS(l - 1) : 0, l == 0 ? gx0T : nullptr, dxT, dx_started ? 1 : 0,
+                       (int)M, F, Hp, Hl, periods);
+      }
       dx_started = true;
       if (l == 0) have_gx0 = true;
     }

@@ -282,6 +282,33 @@ static __global__ __launch_bounds__(256) void cin_pack_wz_kernel(const float* __
   }
 }
 
+// Symmetric first layer: slot (h, j), parity hf <-> pair (h, f = (h + d) mod F), d = 2j + hf; weights as in
+// cin_pack_wf_sym_kernel.
+static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float* __restrict__ W, float* __restrict__ Wz, int F, int H, int JT,
+                                                              int NCOL, int tiles) {
+  const long total = (long)tiles * 32 * NCOL;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % NCOL);
+    const long row = idx / NCOL;
+    const int i = (int)(row & 31);
+    const long t = row >> 5;
+    const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
+    const long slot = 16 * t + rr;
+    const int h = (int)(slot / JT), j = (int)(slot - (long)h * JT);
+    const int d = 2 * j + hf;
+    float v = 0.f;
+    if (h < F && d <= F / 2 && col < H) {
+      const int f = (h + d) % F;
+      if (d == 0) v = W[((long)h * F + h) * H + col];
+      else {
+        v = W[((long)h * F + f) * H + col] + W[((long)f * F + h) * H + col];
+        if (2 * d == F) v *= 0.5f;
+      }
+    }
+    Wz[idx] = v;
+  }
+}
+
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
 // Backward data path, streaming form.  Wave = 32*MB rows m (on the lanes).  dZ^T tile = Wz tile (32 slot rows,
@@ -291,12 +318,20 @@ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 //   gx       += dZ * x[m,f]            -> G^{l-1}[m,h] when the h is complete (halves added with one shuffle)
 //   dxacc[j] += dZ * x^{l-1}[m,h]      -> dX[m, 2j+half]
 // The (tile, register) -> (h, j) pattern repeats every P = JT/gcd(16,JT) tiles = HPP = 16P/JT values of h.
-template <int MB, int JT, int NHMAX>
+//
+// SYM (first layer, x^{l-1} = x, weights pre-summed over (h,f)/(f,h) by cin_pack_wz_sym_kernel): slot (h, j) is the
+// unordered pair (h, f = (h + 2j + half) mod F).  f now moves with h, so the x fragment / dX accumulators are
+// indexed at run time: they live in LDS as [mb][f][row] (FR rows of kSymStride floats per mb, one column per row m,
+// shared by the two lane halves of a row -- within one instruction the halves touch f and f+1, never the same word).
+//   gx      += dZ * x[m,f]  -> Gx[m,h]  (gx0T)        dxs[f] += dZ * x[m,h]  -> dX[m,f]   (summed by transpose_out)
+constexpr int kSymStride = 160;  // 4 waves x 32 rows + 32: consecutive f land in opposite bank halves
+
+template <int MB, int JT, int NHMAX, bool SYM = false>
 __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
                                                          const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                          const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
                                                          int HSp, float* __restrict__ gx0T, float* __restrict__ dxT, int accumulate,
-                                                         int M, int F, int Hp, int H, int periods) {
+                                                         int M, int F, int Hp, int H, int periods, int FR) {
   // Per-lane scratch in LDS, laid out [mb][j][tid] (lane-minor -> conflict-free, immediate offsets): the lane's x
   // fragment and its dX accumulators.  Every address is touched by exactly one lane: no barriers, no atomics.
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -308,8 +343,8 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   const int r = lane & 31, half = lane >> 5;
   const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
   if (wrow0 >= M) return;
-  float* xs = smem + tid;                       // xs[(mb*JT + j)*256]
-  float* dxs = smem + MB * JT * 256 + tid;      // dxs[(mb*JT + j)*256]
+  float* xs = SYM ? smem + wave * 32 + r : smem + tid;                                    // xs[(mb*JT + j)*256]   | SYM: xs[(mb*FR + f)*kSymStride]
+  float* dxs = SYM ? xs + MB * FR * kSymStride : smem + MB * JT * 256 + tid;              // dxs[(mb*JT + j)*256]  | SYM: same shape as xs
   long mq[MB];
   bool vq[MB];
   float greg[MB][NHMAX], dpp[MB];
@@ -318,11 +353,18 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
     const int m = wrow0 + mb * 32 + r;
     vq[mb] = m < M;
     mq[mb] = vq[mb] ? m : M - 1;
+    if constexpr (SYM) {
+      for (int f = half; f < FR; f += 2) {
+        xs[(mb * FR + f) * kSymStride] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+        dxs[(mb * FR + f) * kSymStride] = 0.f;
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const int f = 2 * j + half;
-      xs[(mb * JT + j) * 256] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
-      dxs[(mb * JT + j) * 256] = 0.f;
+      for (int j = 0; j < JT; ++j) {
+        const int f = 2 * j + half;
+        xs[(mb * JT + j) * 256] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+        dxs[(mb * JT + j) * 256] = 0.f;
+      }
     }
     const float* grow = gT + mq[mb] * HS + half * NHMAX;
 #pragma unroll
@@ -333,6 +375,7 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
       dpp[mb] = dPprev[bb * ldp + (mq[mb] - bb * K)];
     }
   }
+  if constexpr (SYM) __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
   const float4* wz = reinterpret_cast<const float4*>(Wz) + ((long)r * NCOL + half * NHMAX) / 4;
   constexpr long kTileStride = 32L * NCOL / 4;  // float4 per tile
   float4 q[NQ];
@@ -364,11 +407,20 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   auto contract_slot = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
     const int sp = 16 * tp + rr;
     const int hl = sp / JT, j = sp % JT;  // compile-time after unrolling
+    int fo = 0;
+    if constexpr (SYM) {
+      // f = (h + 2j + half) mod F; h + 2j + half < F + FR by the choice of FR; the fake tile before the first
+      // one (hb < 0, dZ = 0) is clamped to field 0
+      int t = hb + (hl + 2 * j) + half;
+      t -= t >= F ? F : 0;
+      fo = max(t, 0) * kSymStride;
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const float dz = d[mb][rr];
-      gx[mb] = fmaf(dz, xs[(mb * JT + j) * 256], gx[mb]);
-      dxs[(mb * JT + j) * 256] = fmaf(dz, xpv[mb][hl], dxs[(mb * JT + j) * 256]);
+      const int xi = SYM ? mb * FR * kSymStride + fo : (mb * JT + j) * 256;
+      gx[mb] = fmaf(dz, xs[xi], gx[mb]);
+      dxs[xi] = fmaf(dz, xpv[mb][hl], dxs[xi]);
       if (j == JT - 1) {
         // h = hb + hl is complete: collect the period's HPP values and store them with one 16/8/4-byte access
         // (single-dword stores at a row stride turn into one partial-line write each: 7x write amplification)
@@ -440,13 +492,21 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     if (vq[mb]) {
-#pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        const int f = 2 * j + half;
-        if (f < F) {
+      if constexpr (SYM) {
+        for (int f = half; f < F; f += 2) {
           float* p = dxT + mq[mb] * F + f;
-          const float v = dxs[(mb * JT + j) * 256];
+          const float v = dxs[(mb * FR + f) * kSymStride];
           *p = accumulate ? *p + v : v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const int f = 2 * j + half;
+          if (f < F) {
+            float* p = dxT + mq[mb] * F + f;
+            const float v = dxs[(mb * JT + j) * 256];
+            *p = accumulate ? *p + v : v;
+          }
         }
       }
     }

@@ -20,9 +20,16 @@ void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const 
                     const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,
                     int accumulate, int M, int F, int Hp, int H, int periods);
 
+// symmetric first layer (x^{l-1} = x); FR = field rows of the LDS scratch (see cin_dz_sym_rows)
+void cin_launch_dz3_sym(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
+                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods);
+
 // tiles per period / h per period of the dZ kernel for a given JT (mirrors the constexprs in cin_dz3_kernel)
 inline int cin_gcd(int a, int b) { return b == 0 ? a : cin_gcd(b, a % b); }
 inline int cin_dz_tiles_per_period(int JT) { return JT / cin_gcd(16, JT); }
 inline int cin_dz_h_per_period(int JT) { return 16 * cin_dz_tiles_per_period(JT) / JT; }
+
+// LDS field rows of the symmetric dZ kernel: h + 2j + half stays below F + rows for every (padded) slot
+inline int cin_dz_sym_rows(int F, int JT) { return F > cin_dz_h_per_period(JT) + 2 * JT ? F : cin_dz_h_per_period(JT) + 2 * JT; }
 
 }  // namespace fil

@@ -130,6 +130,10 @@ CIN_SHAPES = [
     (16, 26, 16, [200, 200]),      # reference default width: H > 128 -> two column chunks
     (130, 39, 16, [32, 64]),       # M not a multiple of the 128-row tile
     (4, 64, 4, [16, 16]),          # F at the limit
+    (6, 1, 4, [3, 2]),             # one field: the pair reduction of the first layer degenerates to (0,0)
+    (6, 2, 4, [3, 2]),             # even F: the d = F/2 pairs are met from both ends (half weights)
+    (10, 13, 8, [130, 20]),        # odd F, first layer H > 128
+    (33, 38, 16, [64, 48, 8]),     # even F near the north-star size
 ]
 
 
