@@ -404,27 +404,42 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   float gout[MB][HPP];
   const bool gvec = gx0T == nullptr;  // G^{l-1} rows are 512-byte aligned; the layer-1 side buffer [M][F] is not
 
-  auto contract_slot = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
+  // A slot is contracted in two halves one step group apart, so the LDS reads are back before they are needed (a
+  // read-then-wait inside a group parks the wave, and with one wave per SIMD that starves the MFMA pipe):
+  // slot_fetch reads the slot's x entry and dX accumulator, slot_apply (next group) does the two FMAs and the write.
+  // Within a group the apply (write) precedes the next fetch (read), so slots that alias one word stay ordered.
+  float lx[MB], ldx[MB];
+  int lfo = 0;
+  auto slot_fetch = [&](int hb, int tp, int rr) {
     const int sp = 16 * tp + rr;
     const int hl = sp / JT, j = sp % JT;  // compile-time after unrolling
-    int fo = 0;
     if constexpr (SYM) {
       // f = (h + 2j + half) mod F; h + 2j + half < F + FR by the choice of FR; the fake tile before the first
       // one (hb < 0, dZ = 0) is clamped to field 0
       int t = hb + (hl + 2 * j) + half;
       t -= t >= F ? F : 0;
-      fo = max(t, 0) * kSymStride;
+      lfo = max(t, 0) * kSymStride;
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+      const int xi = SYM ? mb * FR * kSymStride + lfo : (mb * JT + j) * 256;
+      lx[mb] = xs[xi];
+      ldx[mb] = dxs[xi];
+    }
+  };
+  auto slot_apply = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
+    const int sp = 16 * tp + rr;
+    const int hl = sp / JT, j = sp % JT;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
       const float dz = d[mb][rr];
-      const int xi = SYM ? mb * FR * kSymStride + fo : (mb * JT + j) * 256;
-      gx[mb] = fmaf(dz, xs[xi], gx[mb]);
-      dxs[xi] = fmaf(dz, xpv[mb][hl], dxs[xi]);
+      const int xi = SYM ? mb * FR * kSymStride + lfo : (mb * JT + j) * 256;
+      gx[mb] = fmaf(dz, lx[mb], gx[mb]);
+      dxs[xi] = fmaf(dz, xpv[mb][hl], ldx[mb]);
       if (j == JT - 1) {
         // h = hb + hl is complete: collect the period's HPP values and store them with one 16/8/4-byte access
         // (single-dword stores at a row stride turn into one partial-line write each: 7x write amplification)
-        gout[mb][hl] = gx[mb] + __shfl_xor(gx[mb], 32) + dpp[mb];
+        gout[mb][hl] = lane_halves_sum(gx[mb]) + dpp[mb];
         gx[mb] = 0.f;
         if (hl == HPP - 1 && half == 0 && vq[mb] && hb >= 0) {
           float* dst = gdst[mb] + hb;
@@ -441,6 +456,7 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
       }
     }
   };
+  slot_fetch(hprev, P - 1, 0);
 
 #pragma unroll 1
   for (int per = 0; per < periods; ++per) {
@@ -471,8 +487,14 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
         }
         // previous tile's slots, spread over this tile's step groups (NQ is 16 or 32; 16 slots per tile)
         if (s4 < 16) {
-          if (tp == 0) contract_slot(dprev, xprev, hprev, P - 1, s4);
-          else contract_slot(dprev, xcur, hbase, tp - 1, s4);
+          if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, s4);
+          else slot_apply(dprev, xcur, hbase, tp - 1, s4);
+          if (s4 < 15) {
+            if (tp == 0) slot_fetch(hprev, P - 1, s4 + 1);
+            else slot_fetch(hbase, tp - 1, s4 + 1);
+          } else {
+            slot_fetch(hbase, tp, 0);  // first slot of this tile, applied in the first group of the next one
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -487,7 +509,11 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   }
   // the last tile's slots
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) contract_slot(dprev, xprev, hprev, P - 1, rr);
+  for (int rr = 0; rr < 16; ++rr) {
+    slot_apply(dprev, xprev, hprev, P - 1, rr);
+    if (rr < 15) slot_fetch(hprev, P - 1, rr + 1);
+  }
+  if constexpr (SYM) __builtin_amdgcn_wave_barrier();
 
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {

@@ -73,6 +73,15 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+// v[lane] + v[lane ^ 32] in every lane, with the gfx950 VALU half swap (v_permlane32_swap) instead of a round trip
+// through the LDS crossbar (ds_bpermute + s_waitcnt stalls the wave; this does not).  Inline asm: the builtin of
+// this compiler returns the same register for both results.
+__device__ __forceinline__ float lane_halves_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   v = half_wave_sum(v);
   v += __shfl_xor(v, 32);
