@@ -513,28 +513,20 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
     slot_apply(dprev, xprev, hprev, P - 1, rr);
     if (rr < 15) slot_fetch(hprev, P - 1, rr + 1);
   }
-  if constexpr (SYM) __builtin_amdgcn_wave_barrier();
-
-#pragma unroll
+  // dX rows of the wave are contiguous in dxT ([32*MB rows][F]): written cooperatively from the LDS scratch so that
+  // every store instruction covers whole lines (one lane per row element = a 156-byte stride = 8-16x write
+  // amplification in WRITE_SIZE)
+  __builtin_amdgcn_wave_barrier();
+  const float* dsc = smem + (SYM ? MB * FR * kSymStride + wave * 32 : MB * JT * 256 + wave * 64);
+#pragma unroll 1
   for (int mb = 0; mb < MB; ++mb) {
-    if (vq[mb]) {
-      if constexpr (SYM) {
-        for (int f = half; f < F; f += 2) {
-          float* p = dxT + mq[mb] * F + f;
-          const float v = dxs[(mb * FR + f) * kSymStride];
-          *p = accumulate ? *p + v : v;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < JT; ++j) {
-          const int f = 2 * j + half;
-          if (f < F) {
-            float* p = dxT + mq[mb] * F + f;
-            const float v = dxs[(mb * JT + j) * 256];
-            *p = accumulate ? *p + v : v;
-          }
-        }
-      }
+    const int row0 = wrow0 + mb * 32;
+    const int nrow = min(32, M - row0);
+    float* dst = dxT + (long)row0 * F;
+    for (int idx = lane; idx < nrow * F; idx += 64) {
+      const int rr = idx / F, f = idx - rr * F;
+      const float v = SYM ? dsc[(mb * FR + f) * kSymStride + rr] : dsc[(mb * JT + (f >> 1)) * 256 + (f & 1) * 32 + rr];
+      dst[idx] = accumulate ? dst[idx] + v : v;
     }
   }
 }
