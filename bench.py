@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 B_PER_GPU, F, K = 4096, 39, 16
 CONV = [128, 128, 128]
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md dense fp16/bf16 MFMA peak (16x the fp32 matrix rate)
 
 
 def make_inputs(rank, device):
@@ -120,8 +121,8 @@ def side_benchmark(args):
         def step():
             for v in p.values():
                 v.grad = None
-            Fn.autoint_interact(p["x"], p["Wq"], p["Wk"], p["Wr"], p["gamma"], p["beta"]).backward(dy)
-        name, bound = "AutoInt interacting layer fwd+bwd F=200 K=16 H=4 A=16 fp32 B=%d" % B, "mfma"
+            Fn.autoint_interact(p["x"], p["Wq"], p["Wk"], p["Wr"], p["gamma"], p["beta"], precision=args.precision).backward(dy)
+        name, bound = "AutoInt interacting layer fwd+bwd F=200 K=16 H=4 A=16 %s B=%d" % (args.precision, B), "mfma"
         kernels = ("attn_fwd", "attn_bwd_pre", "attn_bwd_dq", "attn_bwd_dk", "attn_bwd_proj")
     for _ in range(args.warmup):
         step()
@@ -137,11 +138,14 @@ def side_benchmark(args):
     dom = max(ks, key=lambda k: ks[k]["total_ms"])
     d = ks[dom]
     rate = d["work"] / (d["avg_ms"] * 1e-3)
-    peak, unit, ach = (PEAK_HBM_GBPS, "GB/s", rate / 1e9) if bound == "hbm" else (PEAK_F32_MFMA_TFLOPS, "TFLOP/s", rate / 1e12)
+    f16 = args.workload == "autoint" and args.precision == "f16_mfma"
+    mfma_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+    peak, unit, ach = (PEAK_HBM_GBPS, "GB/s", rate / 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", rate / 1e12)
     print(json.dumps({
         "metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": name},
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 products, f32 accumulate" if f16 else "f32", "data": "synthetic",
+        "config": {"workload": name},
         "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                      "traffic": None, "avg_launch_ms": d["avg_ms"]},
         "kernels": {k: dict(avg_ms=round(v["avg_ms"], 4), work=v["work"]) for k, v in sorted(ks.items())},
@@ -178,6 +182,7 @@ def main():
     ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint"],
                     help="cin = the headline benchmark (default); the others are single-GPU side benchmarks of the "
                          "remaining hot-path rows (BASELINE.json configs 2, 3, 5)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16_mfma"], help="AutoInt side benchmark only")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
     args = ap.parse_args()
     if args.workload != "cin":

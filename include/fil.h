@@ -111,17 +111,23 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       y = LN(sigmoid(scale * q k^T) k),  res_out [H,B,F,A] = x Wr (may be NULL).
  *   bwd: dy [H,B,F,A] (and, when fuse_relu == 0 and Wr != NULL, dres_in [H,B,F,A] = gradient of res_out)
  *        -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
+ *   precision: FIL_PREC_F32 = every matrix product on the exact fp32 MFMA (1e-5 parity with the reference);
+ *       FIL_PREC_F16_MFMA = BASELINE config 5 ("fp16 MFMA QK^T V"): the operands of every matrix product (projections,
+ *       scores, weighted sums and their gradients) are rounded to fp16 and multiplied on v_mfma_f32_16x16x16_f16 with
+ *       fp32 accumulation; sigmoid, LayerNorm, residual, ReLU, all tensors in memory and all reductions stay fp32.
+ *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
  *   Limits: K <= 64, A <= 16, F <= 512 (and the LDS footprint <= 160 KiB).
  */
+enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A);
 int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                  const float* beta, float* y, float* res_out, int B, int F, int K, int H, int A, float scale,
-                 float eps, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
+                 float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream);
 int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                  const float* beta, const float* dy, const float* dres_in, float* dx, float* dWq, float* dWk,
                  float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H, int A, float scale, float eps,
-                 int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
+                 int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,

@@ -29,6 +29,25 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Four reduction steps into one accumulator: lane group g = lane>>4 contributes the products a_s * b_s, s = 0..3.
+// F16 = false: four exact-fp32 16x16x4 MFMAs (the 1e-5 parity mode).  F16 = true (BASELINE config 5, "fp16 MFMA"):
+// operands rounded to fp16 (v_cvt_pk_f16_f32, round-to-nearest-even), ONE 16x16x16 f16 MFMA with fp32 accumulation --
+// lane group g supplies k = 4g..4g+3 of both operands, which is the same (s, g) pairing as the four fp32 steps.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ f32x4 mma4(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3, f32x4 c) {
+  if constexpr (F16) {
+    const f32x4 av = {a0, a1, a2, a3}, bv = {b0, b1, b2, b3};
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_convertvector(av, f16x4), __builtin_convertvector(bv, f16x4), c, 0, 0, 0);
+  } else {
+    c = mfma16(a0, b0, c);
+    c = mfma16(a1, b1, c);
+    c = mfma16(a2, b2, c);
+    c = mfma16(a3, b3, c);
+    return c;
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // sum over the 16 lanes that share lane>>4 (one row of a D tile)
@@ -82,24 +101,20 @@ __device__ __forceinline__ void load_xfrag(const float* xs, int blk, const AttnD
 }
 
 // rows form: D[row <-> f = 4g+r][col <-> a] = x_blk W
-template <int NC>
+template <int NC, bool F16>
 __device__ __forceinline__ f32x4 proj_rows(const float (&xr)[NC][4], const float (&w)[NC][4]) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = mfma16(xr[c][s], w[c][s], acc);
+  for (int c = 0; c < NC; ++c) acc = mma4<F16>(xr[c][0], xr[c][1], xr[c][2], xr[c][3], w[c][0], w[c][1], w[c][2], w[c][3], acc);
   return acc;
 }
 
 // transposed form: D[row <-> a = 4g+r][col <-> f] = (x_blk W)^T
-template <int NC>
+template <int NC, bool F16>
 __device__ __forceinline__ f32x4 proj_T(const float (&xr)[NC][4], const float (&w)[NC][4]) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = mfma16(w[c][s], xr[c][s], acc);
+  for (int c = 0; c < NC; ++c) acc = mma4<F16>(w[c][0], w[c][1], w[c][2], w[c][3], xr[c][0], xr[c][1], xr[c][2], xr[c][3], acc);
   return acc;
 }
 
@@ -115,30 +130,28 @@ __device__ __forceinline__ float4 lds_row4(const float* arr, int row, int g) {
 }
 
 // all waves: arr[f][a] = (x W)[f][a] for every 16-row block (blocks dealt round-robin to the waves)
-template <int NC>
+template <int NC, bool F16>
 __device__ __forceinline__ void project_all(const float* xs, float* arr, const float (&w)[NC][4], const AttnDims& d, int wave,
                                             int lane) {
   for (int blk = wave; blk < d.nblk; blk += 4) {
     float xr[NC][4];
     load_xfrag<NC>(xs, blk, d, lane, xr);
-    store_rows(arr, blk, lane, proj_rows<NC>(xr, w));
+    store_rows(arr, blk, lane, proj_rows<NC, F16>(xr, w));
   }
 }
 
 // av_blk = sum_t sigmoid(k_t q_blk^T)^T k_t  -- shared by forward and bwd_pre.  qT is pre-scaled.
+template <bool F16>
 __device__ __forceinline__ f32x4 attend_block(const float* kks, const f32x4& qT, int nblk, int lane) {
   const int a = lane & 15, g = lane >> 4;
   f32x4 av = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < nblk; ++t) {
     const float4 kA = lds_row4(kks, 16 * t + a, g);
     f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-    sc = mfma16(kA.x, qT[0], sc);
-    sc = mfma16(kA.y, qT[1], sc);
-    sc = mfma16(kA.z, qT[2], sc);
-    sc = mfma16(kA.w, qT[3], sc);
+    sc = mma4<F16>(kA.x, kA.y, kA.z, kA.w, qT[0], qT[1], qT[2], qT[3], sc);
     const float* kb = kks + (16 * t + 4 * g) * kRS + a;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) av = mfma16(sigmoidf_fast(sc[s]), kb[s * kRS], av);
+    av = mma4<F16>(sigmoidf_fast(sc[0]), sigmoidf_fast(sc[1]), sigmoidf_fast(sc[2]), sigmoidf_fast(sc[3]), kb[0], kb[kRS], kb[2 * kRS],
+                   kb[3 * kRS], av);
   }
   return av;
 }
@@ -171,7 +184,7 @@ __device__ __forceinline__ void layer_norm_rows(const f32x4& av, bool avalid, fl
 
 // ================================================================================================= forward
 // y[h,b,f,a] = fuse_relu ? relu(res + ln) : ln ; res_out (optional, !fuse_relu) = x Wr
-template <int NC>
+template <int NC, bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                                 const float* __restrict__ Wk, const float* __restrict__ Wr,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -193,20 +206,20 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
   const float gam = (use_ln && avalid) ? gamma[a] : 0.f, bet = (use_ln && avalid) ? beta[a] : 0.f;
   const float inv_a = 1.0f / (float)d.A;
   __syncthreads();
-  project_all<NC>(xs, kks, wk, d, wave, lane);
+  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
   __syncthreads();
 
   for (int blk = wave; blk < d.nblk; blk += 4) {
     float xr[NC][4];
     load_xfrag<NC>(xs, blk, d, lane, xr);
-    f32x4 qT = proj_T<NC>(xr, wq);
+    f32x4 qT = proj_T<NC, F16>(xr, wq);
 #pragma unroll
     for (int r = 0; r < 4; ++r) qT[r] *= scale;
-    const f32x4 av = attend_block(kks, qT, d.nblk, lane);
+    const f32x4 av = attend_block<F16>(kks, qT, d.nblk, lane);
     LnOut ln;
     layer_norm_rows(av, avalid, inv_a, eps, gam, bet, use_ln, ln);
     f32x4 res = {0.f, 0.f, 0.f, 0.f};
-    if (Wr != nullptr) res = proj_rows<NC>(xr, wr);
+    if (Wr != nullptr) res = proj_rows<NC, F16>(xr, wr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = 16 * blk + 4 * g + r;
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
 // ================================================================================================= backward: pre
 // Recomputes av; fused mode: dz = dy * (res + ln > 0), dres = dz; unfused: dz = dy (grad of ln), dres given separately.
 // Writes dav (LayerNorm backward of dz) and, in fused mode, dres; accumulates dgamma/dbeta partials per workgroup.
-template <int NC>
+template <int NC, bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_kernel(
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ dy, float* __restrict__ dav,
@@ -249,21 +262,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_kernel(
   const float gam = (use_ln && avalid) ? gamma[a] : 0.f, bet = (use_ln && avalid) ? beta[a] : 0.f;
   const float inv_a = 1.0f / (float)d.A;
   __syncthreads();
-  project_all<NC>(xs, kks, wk, d, wave, lane);
+  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
   __syncthreads();
 
   float dg = 0.f, db = 0.f;
   for (int blk = wave; blk < d.nblk; blk += 4) {
     float xr[NC][4];
     load_xfrag<NC>(xs, blk, d, lane, xr);
-    f32x4 qT = proj_T<NC>(xr, wq);
+    f32x4 qT = proj_T<NC, F16>(xr, wq);
 #pragma unroll
     for (int r = 0; r < 4; ++r) qT[r] *= scale;
-    const f32x4 av = attend_block(kks, qT, d.nblk, lane);
+    const f32x4 av = attend_block<F16>(kks, qT, d.nblk, lane);
     LnOut ln;
     layer_norm_rows(av, avalid, inv_a, eps, gam, bet, use_ln, ln);
     f32x4 res = {0.f, 0.f, 0.f, 0.f};
-    if (fuse_relu && Wr != nullptr) res = proj_rows<NC>(xr, wr);
+    if (fuse_relu && Wr != nullptr) res = proj_rows<NC, F16>(xr, wr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = 16 * blk + 4 * g + r;
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_kernel(
 
 // ================================================================================================= backward: dq
 // key-major orientation: S'[f'][f], dS'[f'][f] = k[f'] . dav[f];  dq_blk = sum_t (dS' S'(1-S') scale)^T k_t
-template <int NC>
+template <int NC, bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                                    const float* __restrict__ Wk, const float* __restrict__ dav,
                                                                    float* __restrict__ dq, AttnDims d, float scale) {
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
   load_w<NC>(Wq, h, d, lane, wq);
   load_w<NC>(Wk, h, d, lane, wk);
   __syncthreads();
-  project_all<NC>(xs, kks, wk, d, wave, lane);
+  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
   __syncthreads();
   const float* davh = dav + ((long)h * d.B + b) * d.F * d.A;
   float* dqh = dq + ((long)h * d.B + b) * d.F * d.A;
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
   for (int blk = wave; blk < d.nblk; blk += 4) {
     float xr[NC][4];
     load_xfrag<NC>(xs, blk, d, lane, xr);
-    f32x4 qT = proj_T<NC>(xr, wq);
+    f32x4 qT = proj_T<NC, F16>(xr, wq);
 #pragma unroll
     for (int r = 0; r < 4; ++r) qT[r] *= scale;
     // B operand of dS': lane (j = f = lane&15, k = g) needs dav[f][4g+s]
@@ -345,16 +358,16 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
     for (int t = 0; t < d.nblk; ++t) {
       const float4 kA = lds_row4(kks, 16 * t + a, g);
       f32x4 sc = {0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f};
-      sc = mfma16(kA.x, qT[0], sc); ds = mfma16(kA.x, dv[0], ds);
-      sc = mfma16(kA.y, qT[1], sc); ds = mfma16(kA.y, dv[1], ds);
-      sc = mfma16(kA.z, qT[2], sc); ds = mfma16(kA.z, dv[2], ds);
-      sc = mfma16(kA.w, qT[3], sc); ds = mfma16(kA.w, dv[3], ds);
+      sc = mma4<F16>(kA.x, kA.y, kA.z, kA.w, qT[0], qT[1], qT[2], qT[3], sc);
+      ds = mma4<F16>(kA.x, kA.y, kA.z, kA.w, dv[0], dv[1], dv[2], dv[3], ds);
       const float* kb = kks + (16 * t + 4 * g) * kRS + a;
+      float dpre[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const float sg = sigmoidf_fast(sc[s]);
-        acc = mfma16(ds[s] * sg * (1.f - sg) * scale, kb[s * kRS], acc);
+        dpre[s] = ds[s] * sg * (1.f - sg) * scale;
       }
+      acc = mma4<F16>(dpre[0], dpre[1], dpre[2], dpre[3], kb[0], kb[kRS], kb[2 * kRS], kb[3 * kRS], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
 // ================================================================================================= backward: dk
 // query-major orientation: S[f][f'], dS[f][f'] = dav[f] . k[f'];  waves split the key tiles.
 //   dk_t = sum_blk (dS S(1-S) scale)^T q_blk + S^T dav_blk
-template <int NC>
+template <int NC, bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dk_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                                    const float* __restrict__ Wk, const float* __restrict__ dav,
                                                                    float* __restrict__ dk, AttnDims d, float scale) {
@@ -393,8 +406,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dk_kernel(const float* 
 #pragma unroll
     for (int s = 0; s < 4; ++s) wq[c][s] *= scale;  // q pre-scaled: scores = (scale q) . k
   __syncthreads();
-  project_all<NC>(xs, kks, wk, d, wave, lane);
-  project_all<NC>(xs, qs, wq, d, wave, lane);
+  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
+  project_all<NC, F16>(xs, qs, wq, d, wave, lane);
   __syncthreads();
   float* dkh = dk + ((long)h * d.B + b) * d.F * d.A;
 
@@ -405,20 +418,20 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dk_kernel(const float* 
       const float4 qA = lds_row4(qs, 16 * blk + a, g);     // A: (scale q)[f][4g+s]
       const float4 dA = lds_row4(davs, 16 * blk + a, g);   // A: dav[f][4g+s]
       f32x4 sc = {0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f};
-      sc = mfma16(qA.x, kB.x, sc); ds = mfma16(dA.x, kB.x, ds);
-      sc = mfma16(qA.y, kB.y, sc); ds = mfma16(dA.y, kB.y, ds);
-      sc = mfma16(qA.z, kB.z, sc); ds = mfma16(dA.z, kB.z, ds);
-      sc = mfma16(qA.w, kB.w, sc); ds = mfma16(dA.w, kB.w, ds);
+      sc = mma4<F16>(qA.x, qA.y, qA.z, qA.w, kB.x, kB.y, kB.z, kB.w, sc);
+      ds = mma4<F16>(dA.x, dA.y, dA.z, dA.w, kB.x, kB.y, kB.z, kB.w, ds);
       // accumulators: row <-> f = 16 blk + 4g + r, col <-> f' = lane&15
       const float* qb = qs + (16 * blk + 4 * g) * kRS + a;
       const float* db = davs + (16 * blk + 4 * g) * kRS + a;
+      float sgv[4], dpre[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float sg = sigmoidf_fast(sc[s]);
+        sgv[s] = sigmoidf_fast(sc[s]);
         // qs holds scale*q: dpre (without the scale factor) times (scale q) == (dpre with scale) times q
-        acc = mfma16(ds[s] * sg * (1.f - sg), qb[s * kRS], acc);
-        acc = mfma16(sg, db[s * kRS], acc);
+        dpre[s] = ds[s] * sgv[s] * (1.f - sgv[s]);
       }
+      acc = mma4<F16>(dpre[0], dpre[1], dpre[2], dpre[3], qb[0], qb[kRS], qb[2 * kRS], qb[3 * kRS], acc);
+      acc = mma4<F16>(sgv[0], sgv[1], sgv[2], sgv[3], db[0], db[kRS], db[2 * kRS], db[3 * kRS], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj_kernel(const float
 // and keeps the dW accumulators in registers across all its tiles (per-wave partials, reduced afterwards).
 constexpr int kProjMaxSeg = 24;
 
-template <int NC>
+template <int NC, bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj3_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                                       const float* __restrict__ Wk, const float* __restrict__ Wr,
                                                                       const float* __restrict__ dq, const float* __restrict__ dk,
@@ -580,15 +593,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj3_kernel(const floa
 #pragma unroll
         for (int kt = 0; kt < NC; ++kt) {
           const float4 wb = *reinterpret_cast<const float4*>(smem + (sgk * 16 * NC + 16 * kt + li) * kRS + 4 * g);
-          accx[kt] = mfma16(dv[0], wb.x, accx[kt]);
-          accx[kt] = mfma16(dv[1], wb.y, accx[kt]);
-          accx[kt] = mfma16(dv[2], wb.z, accx[kt]);
-          accx[kt] = mfma16(dv[3], wb.w, accx[kt]);
+          accx[kt] = mma4<F16>(dv[0], dv[1], dv[2], dv[3], wb.x, wb.y, wb.z, wb.w, accx[kt]);
           f32x4& aw = accw[sgk * NC + kt];
-          aw = mfma16(xa[kt][0], dc[0], aw);
-          aw = mfma16(xa[kt][1], dc[1], aw);
-          aw = mfma16(xa[kt][2], dc[2], aw);
-          aw = mfma16(xa[kt][3], dc[3], aw);
+          aw = mma4<F16>(xa[kt][0], xa[kt][1], xa[kt][2], xa[kt][3], dc[0], dc[1], dc[2], dc[3], aw);
         }
       }
     }
@@ -703,12 +710,13 @@ static void allow_lds_attn(KernelT kernel, size_t sh) {
   if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
 }
 
-#define FIL_ATTN_NC(NCV, CALL) \
-  switch (NCV) {               \
-    case 1: { CALL(1); } break; \
-    case 2: { CALL(2); } break; \
-    case 3: { CALL(3); } break; \
-    case 4: { CALL(4); } break; \
+// CALL(NC, F16) for the runtime (NC, precision) pair; `f16` must be in scope
+#define FIL_ATTN_NC(NCV, CALL)                                               \
+  switch (NCV) {                                                             \
+    case 1: { if (f16) { CALL(1, true); } else { CALL(1, false); } } break;  \
+    case 2: { if (f16) { CALL(2, true); } else { CALL(2, false); } } break;  \
+    case 3: { if (f16) { CALL(3, true); } else { CALL(3, false); } } break;  \
+    case 4: { if (f16) { CALL(4, true); } else { CALL(4, false); } } break;  \
   }
 
 }  // namespace fil
@@ -725,11 +733,13 @@ extern "C" size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A
 
 extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                             const float* beta, float* y, float* res_out, int B, int F, int K, int H, int A, float scale,
-                            float eps, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream) {
+                            float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace; (void)workspace_bytes;
   AttnDims d;
   int rc = make_dims("fil_attn_fwd", B, F, K, H, A, d);
   if (rc != FIL_OK) return rc;
+  if (precision != FIL_PREC_F32 && precision != FIL_PREC_F16_MFMA) return fail(FIL_ERR_ARG, "fil_attn_fwd: precision=%d", precision);
+  const bool f16 = precision == FIL_PREC_F16_MFMA;
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && Wq && Wk && y);
   FIL_CHECK_ARG((gamma == nullptr) == (beta == nullptr));
@@ -739,9 +749,9 @@ extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, co
   const dim3 grid(B * H);
   // flops: projections 2*F*K*A*(2 or 3) + scores and weighted sum 2*2*F*F*A, per (b,h)
   ProfScope ps("attn_fwd", st, (double)B * H * (2.0 * F * K * A * (Wr ? 3 : 2) + 4.0 * F * (double)F * A));
-#define CALL_FWD(N)                                                                                                     \
-  allow_lds_attn(attn_fwd_kernel<N>, sh);                                                                               \
-  hipLaunchKernelGGL((attn_fwd_kernel<N>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, d, \
+#define CALL_FWD(N, P)                                                                                                     \
+  allow_lds_attn(attn_fwd_kernel<N, P>, sh);                                                                               \
+  hipLaunchKernelGGL((attn_fwd_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, d, \
                      scale, eps, fuse_relu)
   FIL_ATTN_NC(d.NC, CALL_FWD)
 #undef CALL_FWD
@@ -752,10 +762,12 @@ extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, co
 extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                             const float* beta, const float* dy, const float* dres_in, float* dx, float* dWq, float* dWk,
                             float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H, int A, float scale,
-                            float eps, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream) {
+                            float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream) {
   AttnDims d;
   int rc = make_dims("fil_attn_bwd", B, F, K, H, A, d);
   if (rc != FIL_OK) return rc;
+  if (precision != FIL_PREC_F32 && precision != FIL_PREC_F16_MFMA) return fail(FIL_ERR_ARG, "fil_attn_bwd: precision=%d", precision);
+  const bool f16 = precision == FIL_PREC_F16_MFMA;
   FIL_CHECK_ARG(Wq && Wk && dWq && dWk);
   FIL_CHECK_ARG((gamma == nullptr) == (beta == nullptr));
   FIL_CHECK_ARG(gamma == nullptr || (dgamma && dbeta));
@@ -798,9 +810,9 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   {
     const size_t sh = sh_base + 4 * 2 * 16 * sizeof(float);
     ProfScope ps("attn_bwd_pre", st, core);
-#define CALL_PRE(N)                                                                                                      \
-  allow_lds_attn(attn_bwd_pre_kernel<N>, sh);                                                                            \
-  hipLaunchKernelGGL((attn_bwd_pre_kernel<N>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, dy, dav,    \
+#define CALL_PRE(N, P)                                                                                                      \
+  allow_lds_attn(attn_bwd_pre_kernel<N, P>, sh);                                                                            \
+  hipLaunchKernelGGL((attn_bwd_pre_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, dy, dav,    \
                      (fuse_relu && has_res) ? dres : nullptr, gb_part, d, scale, eps, fuse_relu)
     FIL_ATTN_NC(d.NC, CALL_PRE)
 #undef CALL_PRE
@@ -812,9 +824,9 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   }
   {
     ProfScope ps("attn_bwd_dq", st, core * 1.5);
-#define CALL_DQ(N)                                                                                                       \
-  allow_lds_attn(attn_bwd_dq_kernel<N>, sh_base);                                                                        \
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<N>), grid, dim3(kAttnThreads), sh_base, st, x, Wq, Wk, dav, dq, d, scale)
+#define CALL_DQ(N, P)                                                                                                       \
+  allow_lds_attn(attn_bwd_dq_kernel<N, P>, sh_base);                                                                        \
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<N, P>), grid, dim3(kAttnThreads), sh_base, st, x, Wq, Wk, dav, dq, d, scale)
     FIL_ATTN_NC(d.NC, CALL_DQ)
 #undef CALL_DQ
   }
@@ -822,9 +834,9 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   {
     const size_t sh = sh_base + 2 * (size_t)d.FP * kRS * sizeof(float);
     ProfScope ps("attn_bwd_dk", st, core * 2.0);
-#define CALL_DK(N)                                                                                                       \
-  allow_lds_attn(attn_bwd_dk_kernel<N>, sh);                                                                             \
-  hipLaunchKernelGGL((attn_bwd_dk_kernel<N>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, dav, dk, d, scale)
+#define CALL_DK(N, P)                                                                                                       \
+  allow_lds_attn(attn_bwd_dk_kernel<N, P>, sh);                                                                             \
+  hipLaunchKernelGGL((attn_bwd_dk_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, dav, dk, d, scale)
     FIL_ATTN_NC(d.NC, CALL_DK)
 #undef CALL_DK
   }
@@ -837,9 +849,9 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     ProfScope ps("attn_bwd_proj", st, (double)B * F * 4.0 * K * DW);
     if (proj_mfma_ok(d)) {
       const size_t sh3 = (size_t)NJ * H * 16 * d.NC * kRS * sizeof(float);
-#define CALL_PROJ3(N)                                                                                                    \
-  allow_lds_attn(attn_bwd_proj3_kernel<N>, sh3);                                                                         \
-  hipLaunchKernelGGL((attn_bwd_proj3_kernel<N>), dim3(proj3_blocks(d)), dim3(kAttnThreads), sh3, st, x, Wq, Wk, Wr, dq, dk, drsrc, \
+#define CALL_PROJ3(N, P)                                                                                                    \
+  allow_lds_attn(attn_bwd_proj3_kernel<N, P>, sh3);                                                                         \
+  hipLaunchKernelGGL((attn_bwd_proj3_kernel<N, P>), dim3(proj3_blocks(d)), dim3(kAttnThreads), sh3, st, x, Wq, Wk, Wr, dq, dk, drsrc, \
                      dx, wpart, d)
       FIL_ATTN_NC(d.NC, CALL_PROJ3)
 #undef CALL_PROJ3

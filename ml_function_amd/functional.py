@@ -220,7 +220,7 @@ class _AttnFn(torch.autograd.Function):
     """fuse_relu=True: returns y = relu(res + LN(av)); fuse_relu=False: returns (LN(av), res)."""
 
     @staticmethod
-    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps, fuse_relu):
+    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps, fuse_relu, precision=0):
         _require_cuda(x, Wq, Wk, Wr, gamma, beta)
         x, Wq, Wk, Wr, gamma, beta = [_f32c(t) for t in (x, Wq, Wk, Wr, gamma, beta)]
         B, F, K = x.shape
@@ -231,9 +231,9 @@ class _AttnFn(torch.autograd.Function):
         if not fuse_relu and Wr is not None:
             res = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
         check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), B, F, K, H, A,
-                               float(scale), float(eps), int(bool(fuse_relu)), None, 0, stream_ptr()), "fil_attn_fwd")
+                               float(scale), float(eps), int(bool(fuse_relu)), int(precision), None, 0, stream_ptr()), "fil_attn_fwd")
         ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None])
-        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu))
+        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu), int(precision))
         if fuse_relu:
             return y
         if res is None:
@@ -242,7 +242,7 @@ class _AttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dres=None):
-        has_res, has_ln, scale, eps, fuse_relu = ctx.cfg
+        has_res, has_ln, scale, eps, fuse_relu, precision = ctx.cfg
         sv = list(ctx.saved_tensors)
         x, Wq, Wk = sv[:3]
         rest = sv[3:]
@@ -265,22 +265,32 @@ class _AttnFn(torch.autograd.Function):
         ws = _workspace(nws, x.device)
         check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(dx),
                                ptr(dWq), ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps,
-                               int(fuse_relu), ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
-        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None
+                               int(fuse_relu), precision, ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
+        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None, None
 
 
 def _attn_scale(Wq, use_scale):
     return (1.0 / (Wq.shape[-1] ** 0.5)) if use_scale else 1.0
 
 
-def autoint_interact(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3):
-    """x [B,F,K], W* [K,H,A] -> y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale q k^T) k))  (V == K projection)."""
-    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, True)
+PRECISIONS = {"f32": 0, "f16_mfma": 1}
 
 
-def mult_head_attention(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3):
+def _precision(p):
+    if p not in PRECISIONS:
+        raise ValueError("precision must be one of %s, got %r" % (sorted(PRECISIONS), p))
+    return PRECISIONS[p]
+
+
+def autoint_interact(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3, precision="f32"):
+    """x [B,F,K], W* [K,H,A] -> y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale q k^T) k))  (V == K projection).
+    precision "f16_mfma": matrix products on the fp16 MFMA with fp32 accumulation (include/fil.h, fil_precision)."""
+    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, True, _precision(precision))
+
+
+def mult_head_attention(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3, precision="f32"):
     """Stand-alone MultHeadAttentionLayer: returns (atten_v [H,B,F,A] = LN(sigmoid(scale q k^T) k), res = x Wr or None)."""
-    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, False)
+    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, False, _precision(precision))
 
 
 # --------------------------------------------------------------------------------------------- N1  embeddings

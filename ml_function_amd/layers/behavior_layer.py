@@ -36,8 +36,9 @@ class MultHeadAttentionLayer(Layer):
     squeezed tensor when attention_head_dim == 1, like the reference :374-375)."""
 
     def __init__(self, attention_dim, attention_head_dim, seed=2020, use_scale=True, use_res=True, use_ln=True,
-                 head_concat=False, supports_masking=True, atten_mask_mod=1):
+                 head_concat=False, supports_masking=True, atten_mask_mod=1, precision="f32"):
         super().__init__()
+        self.precision = precision  # extension: "f16_mfma" = BASELINE config 5 (fp16 MFMA products, fp32 accumulate)
         self.attention_dim = attention_dim
         self.attention_head_dim = attention_head_dim
         self.attention_cal = ProductAttentionLayer(use_scale=use_scale, mask_mod=atten_mask_mod)
@@ -66,14 +67,15 @@ class MultHeadAttentionLayer(Layer):
     def fused_relu(self, inputs):
         """relu(res + LN(attention)) in one kernel: what DnnLayer(res_unit=1, other_dense=[self]) computes."""
         Wq, Wk, Wr, g, b = self._args()
-        return Fn.autoint_interact(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale, eps=self.ln_epsilon)
+        return Fn.autoint_interact(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale, eps=self.ln_epsilon,
+                                   precision=self.precision)
 
     def call(self, inputs, mask=None, **kwargs):
         if mask is not None:
             raise FilError("MultHeadAttentionLayer: masks are not supported on the HIP path (AutoInt passes none)")
         Wq, Wk, Wr, g, b = self._args()
         atten_v, res = Fn.mult_head_attention(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale,
-                                              eps=self.ln_epsilon)
+                                              eps=self.ln_epsilon, precision=self.precision)
         if res is None:
             res = []
         if self.head_concat:

@@ -259,6 +259,53 @@ def test_attn_fused(B, F, K, H, A, use_res, use_ln):
         check("attn dbeta", t["beta"].grad, db, tol=2e-5)
 
 
+@pytest.mark.parametrize("B,F,K,H,A", [(4, 200, 16, 4, 16), (3, 39, 16, 3, 8), (2, 33, 24, 2, 16)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_attn_f16_mfma_mode(B, F, K, H, A, fused):
+    """BASELINE config 5 ("fp16 MFMA QK^T V"): operands of the matrix products rounded to fp16, fp32 accumulation.
+    Tolerances of this labelled mode (norm-relative to the fp64 oracle): 5e-3 on outputs, 2e-2 on gradients
+    (fp16 has an 11-bit significand: 4.9e-4 per rounded operand; the fp32 mode's bar stays 1e-5)."""
+    from ml_function_amd import functional as Fn
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    t = {n: dev(c[n]).requires_grad_() for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
+    args = (t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"])
+    if fused:
+        # (a) the layer as AutoInt uses it.  Outputs are compared at 5e-3.  For the gradients the ReLU kink matters:
+        # an output within ~1e-3 of zero can land on the other side in the f16 forward, and every such element moves
+        # its whole upstream gradient (norm error ~ sqrt(fraction flipped)), so the random case is held to 0.25 ...
+        y = Fn.autoint_interact(*args, precision="f16_mfma")
+        want = closed.attn_fwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], c["beta"], use_res=True, use_ln=True)
+        check("attn f16 y", y, want, tol=5e-3)
+        y32 = Fn.autoint_interact(*args)
+        assert float((y.detach() - y32.detach()).abs().max()) > 0.0, "the f16 mode must not silently run the fp32 kernels"
+        y.backward(dev(c["dy"]))
+        grads = closed.attn_bwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], c["beta"], c["dy"], use_res=True, use_ln=True)
+        names = ["x", "Wq", "Wk", "Wr", "gamma", "beta"]
+        for n, want_g in zip(names, grads):
+            check("attn f16 d" + n, t[n].grad, want_g, tol=0.25)
+        # ... (b) and with beta shifted so that no output sits near the kink, the same backward is held to 2e-2
+        beta_hi = (c["beta"] + 6.0).astype(np.float32)
+        for n in names:
+            t[n].grad = None
+        tb = dev(beta_hi).requires_grad_()
+        Fn.autoint_interact(t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], tb, precision="f16_mfma").backward(dev(c["dy"]))
+        grads = closed.attn_bwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], beta_hi, c["dy"], use_res=True, use_ln=True)
+        for n, got, want_g in zip(names, [t["x"].grad, t["Wq"].grad, t["Wk"].grad, t["Wr"].grad, t["gamma"].grad, tb.grad], grads):
+            check("attn f16 (no kink) d" + n, got, want_g, tol=2e-2)
+    else:
+        av, res = Fn.mult_head_attention(*args, precision="f16_mfma")
+        av32, res32 = Fn.mult_head_attention(*args)
+        check("attn f16 av", av, av32.detach().cpu().numpy(), tol=5e-3)
+        check("attn f16 res", res, res32.detach().cpu().numpy(), tol=5e-3)
+        (av.sum() + (res * res).sum()).backward()
+        g16 = [t[n].grad.clone() for n in ["x", "Wq", "Wk", "Wr"]]
+        for n in t:
+            t[n].grad = None
+        (av32.sum() + (res32 * res32).sum()).backward()
+        for name, a, b in zip(["dx", "dWq", "dWk", "dWr"], g16, [t[n].grad for n in ["x", "Wq", "Wk", "Wr"]]):
+            check("attn f16 unfused " + name, a, b.detach().cpu().numpy(), tol=2e-2)
+
+
 def test_attn_unfused_matches_reference_layer_outputs():
     """MultHeadAttentionLayer.call returns [atten_v, res] (behavior_layer.py:377); gradients flow through both."""
     from ml_function_amd import functional as Fn

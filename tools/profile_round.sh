@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX through gpurun:  gpurun -- 'bash tools/profile_round.sh r01_v5'
+# Produces under gpurun_out/<tag>/: bench.json (unprofiled run), kernel stats of the same command, and the two PMC
+# passes (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only) that tools/pmc_traffic.py summarises.
+set -u
+tag=${1:-prof}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 bench.py > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline > $out/bench_profiled.json 2> $out/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write.log
+python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json 4 > $out/pmc_traffic.txt
+find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
+# raw traces are large; keep the summaries
+find $out -name "*kernel_trace.csv" -delete
+find $out -name "*counter_collection.csv" -delete
+cat $out/bench.json
