@@ -147,7 +147,7 @@ static size_t saved_bytes(const CinShape& s) {
 static size_t wf_floats(const CinShape& s) {
   size_t w = 0;
   for (int l = 0; l < s.L; ++l) w = std::max(w, (size_t)chunks_of(s.H[l]) * s.Hp(l) * 2 * s.JT() * 128);
-  return w;
+  return w + (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
 }
 static int dz_periods(const CinShape& s, int l) { return cdiv(s.Hp(l), cin_dz_h_per_period(s.JT())); }
 static size_t wz_floats(const CinShape& s) {
@@ -157,9 +157,12 @@ static size_t wz_floats(const CinShape& s) {
   for (int l = 0; l < s.L; ++l) w = std::max(w, ((size_t)dz_periods(s, l) * cin_dz_tiles_per_period(s.JT()) + 1) * 32 * s.HS(l));
   return w;
 }
+// column chunks a layer's pooled partials may come in: its own, or (last layer pooled by the epilogue of the layer
+// below) that layer's
+static int pool_chunks(const CinShape& s, int l) { return std::max(chunks_of(s.H[l]), l > 0 ? chunks_of(s.H[l - 1]) : 1); }
 static size_t fwd_ws_bytes(const CinShape& s) {
   size_t t = 0;
-  for (int l = 0; l < s.L; ++l) t += align_up((size_t)chunks_of(s.H[l]) * s.M() * sizeof(float), 256);  // pool partials
+  for (int l = 0; l < s.L; ++l) t += align_up((size_t)pool_chunks(s, l) * s.M() * sizeof(float), 256);   // pool partials
   t += align_up((size_t)s.Hp(s.L - 1) * s.F * sizeof(float), 256);                                       // wsum of the last layer
   t += align_up(wf_floats(s) * sizeof(float), 256);                                                      // packed W
   return t;
@@ -236,7 +239,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   Carver ws(workspace);
   PoolArgs pa;
   for (int l = 0; l < L; ++l) {
-    pa.part[l] = ws.take<float>((size_t)chunks_of(H[l]) * M);
+    pa.part[l] = ws.take<float>((size_t)pool_chunks(s, l) * M);
     pa.chunks[l] = chunks_of(H[l]);
   }
   float* wsum = ws.take<float>((size_t)s.Hp(L - 1) * F);
@@ -249,19 +252,24 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   }
   FIL_CHECK_LAUNCH();
   const float* xpT = xT;
+  bool fused_last = false;   // the last layer's sum-pool was produced by the epilogue of the layer below
   for (int l = 0; l < L; ++l) {
     FIL_CHECK_ARG(W[l] && bias[l]);
     const int Hp = s.Hp(l), Hl = H[l], xps = s.xps(l);
     float* xoutT = l + 1 < L ? sv.take<float>((size_t)M * s.HS(l)) : nullptr;
     float* part = const_cast<float*>(pa.part[l]);
+    // mode 0, last layer: only its sum-pool is observable -> contract with wsum[c] = sum_n W[c,n].  When the layer
+    // below it runs the general (non pair-symmetric) forward kernel, that kernel's epilogue does it (fused_last).
+    const bool fuse_next = mode == 0 && l == L - 2 && !(l == 0 && sym_first_layer());
     if (l == L - 1 && mode == 0) {
-      // last layer: only its sum-pool is observable -> contract with wsum[c] = sum_n W[c,n]
-      const size_t sh = (size_t)Hp * ((F + 3) & ~3) * sizeof(float);
-      ProfScope ps("cin_last_fwd", st, 2.0 * (double)M * Hp * F);
-      hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hp * F, 8)), dim3(256), 0, st, W[l], wsum, Hp * F, Hl);
-      allow_lds(cin_last_fwd_kernel, sh);
-      hipLaunchKernelGGL(cin_last_fwd_kernel, dim3(cdiv((int)M, kLastRows)), dim3(256), sh, st, xT, xpT, xps, wsum, bias[l], part, (int)M, F, Hp, Hl);
-      pa.chunks[l] = 1;
+      if (!fused_last) {
+        const size_t sh = (size_t)Hp * ((F + 3) & ~3) * sizeof(float);
+        ProfScope ps("cin_last_fwd", st, 2.0 * (double)M * Hp * F);
+        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hp * F, 8)), dim3(256), 0, st, W[l], wsum, Hp * F, Hl);
+        allow_lds(cin_last_fwd_kernel, sh);
+        hipLaunchKernelGGL(cin_last_fwd_kernel, dim3(cdiv((int)M, kLastRows)), dim3(256), sh, st, xT, xpT, xps, wsum, bias[l], part, (int)M, F, Hp, Hl);
+        pa.chunks[l] = 1;
+      }
     } else {
       const int chunks = chunks_of(Hl);
       if (l == 0 && sym_first_layer()) {
@@ -274,8 +282,19 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       } else {
         const long npack = (long)chunks * Hp * 2 * JT * 128;
         hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
-        ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
-        cin_launch_fwd3(st, MB, JT, dim3(cdiv((int)M, 128 * MB), chunks), xT, xpT, xps, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hp, Hl);
+        const float* wsn = nullptr;
+        if (fuse_next) {
+          FIL_CHECK_ARG(W[l + 1] && bias[l + 1]);
+          float* wsn_buf = Wf + (size_t)npack;   // behind this layer's packed weights
+          hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hl * F, 8)), dim3(256), 0, st, W[l + 1], wsum, Hl * F, H[l + 1]);
+          hipLaunchKernelGGL(cin_pack_wsn_kernel, dim3(cdiv(chunks * 2 * JT * 128, 256)), dim3(256), 0, st, wsum, wsn_buf, Hl, F, 2 * JT, chunks);
+          wsn = wsn_buf;
+          pa.chunks[l + 1] = chunks;
+          fused_last = true;
+        }
+        ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl) + (fuse_next ? 2.0 * (double)M * Hl * F : 0.0));
+        cin_launch_fwd3(st, MB, JT, dim3(cdiv((int)M, 128 * MB), chunks), xT, xpT, xps, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hp, Hl,
+                        wsn, fuse_next ? bias[l + 1] : nullptr, fuse_next ? H[l + 1] : 0, fuse_next ? const_cast<float*>(pa.part[l + 1]) : nullptr);
       }
     }
     FIL_CHECK_LAUNCH();
@@ -384,10 +403,17 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       hipLaunchKernelGGL(cin_fill_rows_kernel, dim3((int)std::min<long>(((long)cl * Hl + 255) / 256, 2048)), dim3(256), 0, st, vlast, dW[l], (long)cl, Hl);
     }
     // G^{L-1} and dX
-    const size_t shb = shw + (l == 0 ? (size_t)kLastRows * (kLastFMax + 1) * sizeof(float) : 0);
-    allow_lds(cin_last_bwd_kernel, shb);
-    hipLaunchKernelGGL(cin_last_bwd_kernel, dim3(cdiv((int)M, kLastRows)), dim3(256), shb, st, xT, xpT, xps, wsum, dPl, (int)LK, dPprev,
-                       l > 0 ? Gbuf[cur] : nullptr, l > 0 ? s.HS(l - 1) : 0, dxT, /*layer1=*/l == 0, (int)M, F, K, Hp);
+    if (l > 0) {
+      // (the dZ kernels' packed-W buffer is idle here: scratch for wsum in the MFMA operand layout)
+      const int chunks = chunks_of(Hp);
+      hipLaunchKernelGGL(cin_pack_wsn_kernel, dim3(cdiv(chunks * 2 * JT * 128, 256)), dim3(256), 0, st, wsum, Wz, Hp, F, 2 * JT, chunks);
+      cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPl, (int)LK, dPprev, Gbuf[cur], s.HS(l - 1), dxT, (int)M, F, K, Hp);
+    } else {
+      const size_t shb = shw + (size_t)kLastRows * (kLastFMax + 1) * sizeof(float);
+      allow_lds(cin_last_bwd_kernel, shb);
+      hipLaunchKernelGGL(cin_last_bwd_kernel, dim3(cdiv((int)M, kLastRows)), dim3(256), shb, st, xT, xpT, xps, wsum, dPl, (int)LK, dPprev,
+                         nullptr, 0, dxT, /*layer1=*/1, (int)M, F, K, Hp);
+    }
     FIL_CHECK_LAUNCH();
     dx_started = true;
     ltop = L - 2;

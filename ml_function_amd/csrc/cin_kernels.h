@@ -135,7 +135,9 @@ template <int MB, int JT, bool SYM = false>
 __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                           const float* __restrict__ Wf, const float* __restrict__ bias,
                                                           float* __restrict__ xoutT, int HS, float* __restrict__ pool_part, int M,
-                                                          int F, int Hp, int H) {
+                                                          int F, int Hp, int H, const float* __restrict__ wsn,
+                                                          const float* __restrict__ bias_next, int H_next,
+                                                          float* __restrict__ pool_next) {
   // queue depth: the largest divisor of JT not above kQDepthMax (slot j % DEPTH must mean the same step in every h)
   constexpr int DEPTH = JT <= kQDepthMax ? JT : (JT % 10 == 0 ? 10 : (JT % 8 == 0 ? 8 : (JT % 7 == 0 ? 7 : (JT % 6 == 0 ? 6 : 4))));
   static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
@@ -260,6 +262,48 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
         *reinterpret_cast<float4*>(xoutT + (long)m * HS + chunk * 128 + 4 * r) = make_float4(v0 + bv[0], v1 + bv[1], v2 + bv[2], v3 + bv[3]);
       const float p = half_wave_sum((v0 + v1) + (v2 + v3)) + bsum;
       if (r == 0 && m < M) pool_part[(long)chunk * M + m] = p;
+    }
+  }
+
+  // ---- fused sum-pool of the NEXT layer when that is the last one (mode 0; see the cin_last_* kernels):
+  //   p_next[m] = sum_n x^l[m,n] * t[m,n],  t[m,n] = sum_f x[m,f] wsum_next[n,f]
+  // t is one more small MFMA product from the x fragment already in registers; wsn is packed like Wf ([2*JT][128]
+  // per chunk), so t's accumulators line up element for element with this layer's output tile.
+  if constexpr (!SYM) {
+    if (wsn != nullptr) {
+      float bn = 0.f;
+      if (chunk == 0) {
+        for (int n = lane; n < H_next; n += 64) bn += bias_next[n];
+        bn = wave_sum(bn);
+      }
+      const float4* wsb = reinterpret_cast<const float4*>(wsn + (long)chunk * (2 * JT) * 128) + (half * 32 + r);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        f32x16 t[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t[nb][i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const float4 w = wsb[(long)(2 * j) * 32];
+          const float a = xr[mb][j];
+          t[0] = mfma32(a, w.x, t[0]);
+          t[1] = mfma32(a, w.y, t[1]);
+          t[2] = mfma32(a, w.z, t[2]);
+          t[3] = mfma32(a, w.w, t[3]);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = wrow0 + mb * 32 + mfma32_row(reg, half);
+          float e = (acc[mb][0][reg] + bv[0]) * t[0][reg];
+          e = fmaf(acc[mb][1][reg] + bv[1], t[1][reg], e);
+          e = fmaf(acc[mb][2][reg] + bv[2], t[2][reg], e);
+          e = fmaf(acc[mb][3][reg] + bv[3], t[3][reg], e);
+          const float p = half_wave_sum(e) + bn;
+          if (r == 0 && m < M) pool_next[(long)chunk * M + m] = p;
+        }
+      }
     }
   }
 }
@@ -764,6 +808,18 @@ static __global__ __launch_bounds__(256) void cin_wsum_kernel(const float* __res
   if (row < C && l == 0) wsum[row] = t;
 }
 
+// wsn[chunk][fp < JT2][128] = wsum[(chunk*128 + col)*F + fp]  (zero for fp >= F or n >= Hp): the last layer's pooled
+// weights in the operand layout of the forward kernel (see the fused epilogue of cin_fwd3_kernel)
+static __global__ __launch_bounds__(256) void cin_pack_wsn_kernel(const float* __restrict__ wsum, float* __restrict__ wsn, int Hp, int F, int JT2,
+                                                           int chunks) {
+  const int total = chunks * JT2 * 128;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int col = i & 127, fp = (i >> 7) % JT2, chunk = (i >> 7) / JT2;
+    const int n = chunk * 128 + col;
+    wsn[i] = (fp < F && n < Hp) ? wsum[n * F + fp] : 0.f;
+  }
+}
+
 // stages wsum as [Hp][FP4] (FP4 = F rounded up to 4, zero padded) so rows can be read 16 bytes at a time
 __device__ __forceinline__ void stage_wsum(const float* __restrict__ wsum, float* ws, int Hp, int F, int FP4) {
   for (int idx = threadIdx.x; idx < Hp * FP4; idx += blockDim.x) {
@@ -878,6 +934,107 @@ static __global__ __launch_bounds__(256) void cin_last_bwd_kernel(const float* _
 static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* __restrict__ v, float* __restrict__ dW, long C, int H) {
   const long total = C * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dW[i] = v[i / H];
+}
+
+// MFMA form of the last layer's data gradients (mode 0, L >= 2; the VALU kernel above stays for L == 1):
+//   t[m,n] = sum_f x[m,f] wsum[n,f]         -> G^{L-1}[m,n] = dP[m] t[m,n] + dPprev[m]     (A = x fragment, B = wsn)
+//   u[m,f] = sum_h x^{L-1}[m,h] wsum[h,f]   -> dX[m,f]      = dP[m] u[m,f]                 (A = the lane's x^{L-1} row)
+// Wave = 32 rows.  wsn is wsum in the forward kernel's operand layout (cin_pack_wsn_kernel) so lane r owns columns
+// 4r..4r+3 of a chunk and G^{L-1} leaves as 16-byte stores; for u the reduction order is permuted (free in a GEMM)
+// so that wave half `half` takes h = 4q + 2*half + {0,1}: one 8-byte load of its own row per two steps.
+template <int JT>
+__global__ __launch_bounds__(256) void cin_last_bwd2_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+                                                            const float* __restrict__ wsum, const float* __restrict__ wsn,
+                                                            const float* __restrict__ dP, int ldp, const float* __restrict__ dPprev,
+                                                            float* __restrict__ GprevT, int HSp, float* __restrict__ dxT, int M, int F,
+                                                            int K, int Hp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // wsum [Hp][F]
+  for (int i = threadIdx.x; i < Hp * F; i += 256) smem[i] = wsum[i];
+  __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
+  if (wrow0 >= M) return;
+  const long mq = min(wrow0 + r, M - 1);
+  float xr[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    const int f = 2 * j + half;
+    xr[j] = f < F ? xT[mq * F + f] : 0.f;
+  }
+  float dpr[16], dppr[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int mm = min(wrow0 + mfma32_row(reg, half), M - 1);
+    const int b = mm / K, k = mm - b * K;
+    dpr[reg] = dP[(long)b * ldp + k];
+    dppr[reg] = dPprev != nullptr ? dPprev[(long)b * ldp + k] : 0.f;
+  }
+  const int chunks = (Hp + 127) >> 7;
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    f32x16 t[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[nb][i] = 0.f;
+    const float4* wsb = reinterpret_cast<const float4*>(wsn + (long)chunk * (2 * JT) * 128) + (half * 32 + r);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const float4 w = wsb[(long)(2 * j) * 32];
+      t[0] = mfma32(xr[j], w.x, t[0]);
+      t[1] = mfma32(xr[j], w.y, t[1]);
+      t[2] = mfma32(xr[j], w.z, t[2]);
+      t[3] = mfma32(xr[j], w.w, t[3]);
+    }
+    const int n0 = chunk * 128 + 4 * r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = wrow0 + mfma32_row(reg, half);
+      if (m < M) {
+        float* dst = GprevT + (long)m * HSp + n0;
+        const float v0 = fmaf(dpr[reg], t[0][reg], dppr[reg]), v1 = fmaf(dpr[reg], t[1][reg], dppr[reg]);
+        const float v2 = fmaf(dpr[reg], t[2][reg], dppr[reg]), v3 = fmaf(dpr[reg], t[3][reg], dppr[reg]);
+        if (n0 + 3 < Hp) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+        } else {
+          if (n0 < Hp) dst[0] = v0;
+          if (n0 + 1 < Hp) dst[1] = v1;
+          if (n0 + 2 < Hp) dst[2] = v2;
+        }
+      }
+    }
+  }
+  // u = x^{L-1} wsum: two column blocks of fields (f = r, f = 32 + r)
+  f32x16 u0, u1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) u0[i] = u1[i] = 0.f;
+  const float* xprow = xpT + mq * xps + 2 * half;   // columns >= Hp of a feature map are zero (and xps >= Hp + pad)
+  const bool two = F > 32;
+  const int quads = (Hp + 3) >> 2;
+#pragma unroll 4
+  for (int q = 0; q < quads; ++q) {
+    const float2 a = *reinterpret_cast<const float2*>(xprow + 4 * q);
+    const int h = 4 * q + 2 * half;
+    const float* w0 = smem + h * F;
+    const float b00 = (h < Hp && r < F) ? w0[r] : 0.f;
+    const float b01 = (h + 1 < Hp && r < F) ? w0[F + r] : 0.f;
+    u0 = mfma32(a.x, b00, u0);
+    u0 = mfma32(a.y, b01, u0);
+    if (two) {
+      const float b10 = (h < Hp && r + 32 < F) ? w0[r + 32] : 0.f;
+      const float b11 = (h + 1 < Hp && r + 32 < F) ? w0[F + r + 32] : 0.f;
+      u1 = mfma32(a.x, b10, u1);
+      u1 = mfma32(a.y, b11, u1);
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = wrow0 + mfma32_row(reg, half);
+    if (m < M) {
+      if (r < F) dxT[(long)m * F + r] = dpr[reg] * u0[reg];
+      if (two && r + 32 < F) dxT[(long)m * F + 32 + r] = dpr[reg] * u1[reg];
+    }
+  }
 }
 
 struct PoolArgs {

@@ -13,12 +13,18 @@ inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
 void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT,
                          int HS, float* pool_part, int M, int F, int H);
 
+// wsn != nullptr: also sum-pool the next (last, mode 0) layer in the epilogue -> pool_next (see cin_fwd3_kernel)
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
-                     const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H);
+                     const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H,
+                     const float* wsn = nullptr, const float* bias_next = nullptr, int H_next = 0, float* pool_next = nullptr);
 
 void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
                     const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,
                     int accumulate, int M, int F, int Hp, int H, int periods);
+
+// MFMA data gradients of the last layer in mode 0 (L >= 2): see cin_last_bwd2_kernel
+void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn,
+                          const float* dP, int ldp, const float* dPprev, float* GprevT, int HSp, float* dxT, int M, int F, int K, int Hp);
 
 // symmetric first layer (x^{l-1} = x); FR = field rows of the LDS scratch (see cin_dz_sym_rows)
 void cin_launch_dz3_sym(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
