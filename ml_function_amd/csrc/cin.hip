@@ -395,10 +395,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     // all-ones field (F' = 1, so c = h) and G' = x * dP ([M][128], zero padded) as its right-hand side
     {
       float* yT = Gbuf[1];
-      const long tot = M * 128;
-      hipLaunchKernelGGL(cin_scale_rows3_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, xT, dPl, (int)LK, K, yT, (int)M, F);
+      const int YS = (F + 3) & ~3;
+      const long tot = M * YS;
+      hipLaunchKernelGGL(cin_scale_rows3_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, xT, dPl, (int)LK, K, yT, (int)M, F, YS);
       const DwPlan p = dw_plan(M, Hp, F);
-      const int nb = launch_dw3(st, p, yT, 128, nullptr, xpT, xps, part, M, /*F=*/1, Hp, /*H=*/F);
+      const int nb = launch_dw3(st, p, yT, YS, nullptr, xpT, xps, part, M, /*F=*/1, Hp, /*H=*/F);
       hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)cl, 64)), dim3(256), 0, st, part, vlast, (long)cl, nb);
       hipLaunchKernelGGL(cin_fill_rows_kernel, dim3((int)std::min<long>(((long)cl * Hl + 255) / 256, 2048)), dim3(256), 0, st, vlast, dW[l], (long)cl, Hl);
     }

@@ -698,20 +698,40 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   }
 }
 
-// part[blk][n] = sum over a chunk of rows of gT[m][n]   (thread <-> n: coalesced; fixed order)
+// part[blk][n] = sum over a chunk of rows of gT[m][n]: 16-byte loads, HS/4 threads per row and 256/(HS/4) row groups
+// per workgroup (two rows in flight per thread), the groups folded through LDS in a fixed order.
 static __global__ __launch_bounds__(256) void cin_colsum3_kernel(const float* __restrict__ gT, int HS, float* __restrict__ part, int M, int H,
                                                           int rows_per_block) {
-  const int n = threadIdx.x;
-  if (n >= H) return;
+  __shared__ float4 red[256];
+  const int q = HS >> 2;  // float4 per row: 32 or 64
+  const int c4 = threadIdx.x % q, g = threadIdx.x / q, ng = 256 / q;
   const long m_lo = (long)blockIdx.x * rows_per_block, m_hi = min((long)M, m_lo + rows_per_block);
-  float t0 = 0.f, t1 = 0.f;
-  long m = m_lo;
-  for (; m + 1 < m_hi; m += 2) {
-    t0 += gT[m * HS + n];
-    t1 += gT[(m + 1) * HS + n];
+  const float4* src = reinterpret_cast<const float4*>(gT) + c4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  long m = m_lo + g;
+  for (; m + ng < m_hi; m += 2 * ng) {
+    const float4 u = src[m * q], v = src[(m + ng) * q];
+    a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+    a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
   }
-  if (m < m_hi) t0 += gT[m * HS + n];
-  part[(long)blockIdx.x * H + n] = t0 + t1;
+  if (m < m_hi) {
+    const float4 u = src[m * q];
+    a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+  }
+  red[threadIdx.x] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  __syncthreads();
+  if (g == 0) {
+    float4 t = red[c4];
+    for (int k = 1; k < ng; ++k) {
+      const float4 u = red[k * q + c4];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    float* dst = part + (long)blockIdx.x * H + 4 * c4;
+    if (4 * c4 < H) dst[0] = t.x;
+    if (4 * c4 + 1 < H) dst[1] = t.y;
+    if (4 * c4 + 2 < H) dst[2] = t.z;
+    if (4 * c4 + 3 < H) dst[3] = t.w;
+  }
 }
 
 // gT[m][n] = dP[b*ldp + k] for n < H (general path for the top layer: the pooled gradient broadcast over feature maps)
@@ -726,13 +746,15 @@ static __global__ __launch_bounds__(256) void cin_bcast3_kernel(const float* __r
   }
 }
 
-// yT[m][0..128) = xT[m][f] * dP[m] for f < F, zero beyond (right-hand side of the last layer's rank-one dW)
+// yT[m][0..YS) = xT[m][f] * dP[m] for f < F, zero beyond (right-hand side of the last layer's rank-one dW); YS = F
+// rounded up to 4 keeps the rows 16-byte aligned for the dW kernel's B-operand loads (its lanes past YS/4 read into the
+// following rows: finite values feeding columns that are never stored)
 static __global__ __launch_bounds__(256) void cin_scale_rows3_kernel(const float* __restrict__ xT, const float* __restrict__ dP, int ldp, int K,
-                                                              float* __restrict__ yT, int M, int F) {
-  const long total = (long)M * 128;
+                                                              float* __restrict__ yT, int M, int F, int YS) {
+  const long total = (long)M * YS;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i >> 7;
-    const int f = (int)(i & 127);
+    const long m = i / YS;
+    const int f = (int)(i - m * YS);
     const long b = m / K;
     yT[i] = f < F ? xT[m * F + f] * dP[b * ldp + (m - b * K)] : 0.f;
   }
