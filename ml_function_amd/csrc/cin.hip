@@ -136,7 +136,7 @@ static int launch_dw3(hipStream_t st, const DwPlan& p, const float* gT, int HS, 
   return p.splits;
 }
 
-constexpr int kHeadChunk = 64;    // samples per block in the head partial reductions
+constexpr int kHeadChunk = 16;    // samples per block in the head partial reductions
 constexpr int kColRows = 128;     // rows per block in the dbias (column-sum) partial reductions
 
 static size_t saved_bytes(const CinShape& s) {
@@ -302,7 +302,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   }
   {
     ProfScope ps("cin_head_fwd", st);
-    hipLaunchKernelGGL(cin_head_fwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, pa, dense_w, dense_b, pooled,
+    hipLaunchKernelGGL(cin_head_fwd_kernel, dim3(cdiv(B, kHeadSamples)), dim3(256), (size_t)kHeadSamples * L * K * sizeof(float), st, pa, dense_w, dense_b, pooled,
                        output_dim == 1 ? out : nullptr, B, K, L);
   }
   FIL_CHECK_LAUNCH();

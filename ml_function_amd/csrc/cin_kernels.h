@@ -1033,20 +1033,26 @@ __global__ __launch_bounds__(256) void cin_last_bwd2_kernel(const float* __restr
   const float* xprow = xpT + mq * xps + 2 * half;   // columns >= Hp of a feature map are zero (and xps >= Hp + pad)
   const bool two = F > 32;
   const int quads = (Hp + 3) >> 2;
-#pragma unroll 4
-  for (int q = 0; q < quads; ++q) {
-    const float2 a = *reinterpret_cast<const float2*>(xprow + 4 * q);
-    const int h = 4 * q + 2 * half;
-    const float* w0 = smem + h * F;
-    const float b00 = (h < Hp && r < F) ? w0[r] : 0.f;
-    const float b01 = (h + 1 < Hp && r < F) ? w0[F + r] : 0.f;
-    u0 = mfma32(a.x, b00, u0);
-    u0 = mfma32(a.y, b01, u0);
-    if (two) {
-      const float b10 = (h < Hp && r + 32 < F) ? w0[r + 32] : 0.f;
-      const float b11 = (h + 1 < Hp && r + 32 < F) ? w0[F + r + 32] : 0.f;
-      u1 = mfma32(a.x, b10, u1);
-      u1 = mfma32(a.y, b11, u1);
+#pragma unroll 1
+  for (int q0 = 0; q0 < quads; q0 += 16) {
+    // the lane's row segment first (16 independent 8-byte loads in flight), then the MFMA steps
+    float2 av[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) av[i] = q0 + i < quads ? *reinterpret_cast<const float2*>(xprow + 4 * (q0 + i)) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int h = 4 * (q0 + i) + 2 * half;
+      const float* w0 = smem + h * F;
+      const float b00 = (h < Hp && r < F) ? w0[r] : 0.f;
+      const float b01 = (h + 1 < Hp && r < F) ? w0[F + r] : 0.f;
+      u0 = mfma32(av[i].x, b00, u0);
+      u0 = mfma32(av[i].y, b01, u0);
+      if (two) {
+        const float b10 = (h < Hp && r + 32 < F) ? w0[r + 32] : 0.f;
+        const float b11 = (h + 1 < Hp && r + 32 < F) ? w0[F + r + 32] : 0.f;
+        u1 = mfma32(av[i].x, b10, u1);
+        u1 = mfma32(av[i].y, b11, u1);
+      }
     }
   }
 #pragma unroll
@@ -1065,44 +1071,76 @@ struct PoolArgs {
 };
 
 // pooled[b, l*K+k] = sum_chunk part_l[chunk][b*K+k];  out[b] = pooled[b,:] . dense_w + dense_b
+// One thread per pooled element, kHeadSamples samples per workgroup; the per-sample dot is summed in index order.
+constexpr int kHeadSamples = 8;
 static __global__ __launch_bounds__(256) void cin_head_fwd_kernel(PoolArgs pa, const float* __restrict__ dense_w,
                                                            const float* __restrict__ dense_b, float* __restrict__ pooled,
                                                            float* __restrict__ out, int B, int K, int L) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  extern __shared__ float sh[];  // [kHeadSamples][L*K] products
+  const int LK = L * K;
   const long M = (long)B * K;
-  float o = 0.f;
-  for (int l = 0; l < L; ++l) {
-    for (int k = 0; k < K; ++k) {
-      float v = 0.f;
-      for (int ch = 0; ch < pa.chunks[l]; ++ch) v += pa.part[l][(long)ch * M + (long)b * K + k];
-      pooled[(long)b * L * K + l * K + k] = v;
-      if (out != nullptr) o = fmaf(v, dense_w[l * K + k], o);
-    }
+  const int b0 = blockIdx.x * kHeadSamples;
+  const int nb = min(kHeadSamples, B - b0);
+  for (int e = threadIdx.x; e < nb * LK; e += 256) {
+    const int bl = e / LK, j = e - bl * LK;
+    const int l = j / K, k = j - l * K;
+    const long b = b0 + bl;
+    float v = 0.f;
+    for (int ch = 0; ch < pa.chunks[l]; ++ch) v += pa.part[l][(long)ch * M + b * K + k];
+    pooled[b * LK + j] = v;
+    if (out != nullptr) sh[e] = v * dense_w[j];
   }
-  if (out != nullptr) out[b] = o + dense_b[0];
+  if (out == nullptr) return;
+  __syncthreads();
+  if (threadIdx.x < nb) {
+    float o = 0.f;
+    for (int j = 0; j < LK; ++j) o += sh[threadIdx.x * LK + j];
+    out[b0 + threadIdx.x] = o + dense_b[0];
+  }
 }
 
 // output_dim == 1: dP[b,j] = g[b] * dense_w[j];  partial[blk][j] = sum_{b in blk} g[b]*pooled[b,j]  (j < LK),
-// partial[blk][LK] = sum g[b].   One thread per j, blocks over chunks of b.
+// partial[blk][LK] = sum g[b].   Lane <-> j (LK + 1 <= 64 lanes... up to 256: see host check), the 256/64 waves of a
+// workgroup split its chunk of samples and are folded in wave order.
 static __global__ __launch_bounds__(256) void cin_head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dense_w,
                                                            const float* __restrict__ pooled, float* __restrict__ dP,
                                                            float* __restrict__ part, int B, int LK, int bchunk) {
-  const int j = threadIdx.x;
-  if (j > LK) return;
+  __shared__ float red[4][256];
   const int b_lo = blockIdx.x * bchunk, b_hi = min(B, b_lo + bchunk);
-  const float wj = j < LK ? dense_w[j] : 0.f;
-  float t = 0.f;
-  for (int b = b_lo; b < b_hi; ++b) {
-    const float gb = g[b];
-    if (j < LK) {
-      dP[(long)b * LK + j] = gb * wj;
-      t = fmaf(gb, pooled[(long)b * LK + j], t);
-    } else {
-      t += gb;
+  if (LK + 1 <= 64) {
+    const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float t = 0.f;
+    if (j <= LK) {
+      const float wj = j < LK ? dense_w[j] : 0.f;
+      for (int b = b_lo + w; b < b_hi; b += 4) {
+        const float gb = g[b];
+        if (j < LK) {
+          dP[(long)b * LK + j] = gb * wj;
+          t = fmaf(gb, pooled[(long)b * LK + j], t);
+        } else {
+          t += gb;
+        }
+      }
     }
+    red[w][j] = t;
+    __syncthreads();
+    if (w == 0 && j <= LK) part[(long)blockIdx.x * (LK + 1) + j] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+  } else {
+    const int j = threadIdx.x;
+    if (j > LK) return;
+    const float wj = j < LK ? dense_w[j] : 0.f;
+    float t = 0.f;
+    for (int b = b_lo; b < b_hi; ++b) {
+      const float gb = g[b];
+      if (j < LK) {
+        dP[(long)b * LK + j] = gb * wj;
+        t = fmaf(gb, pooled[(long)b * LK + j], t);
+      } else {
+        t += gb;
+      }
+    }
+    part[(long)blockIdx.x * (LK + 1) + j] = t;
   }
-  part[(long)blockIdx.x * (LK + 1) + j] = t;
 }
 
 
