@@ -263,15 +263,30 @@ __global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restri
   }
 }
 
-// out[i] = sum over `parts` partials (fixed order); n = elements per partial.
+// out[i] = sum over `parts` partials (fixed order).  One workgroup per 64 outputs: the 4 waves take every 4th partial
+// (coalesced over i, four independent load streams), then the 4 wave sums are added in wave order.
 __global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                          float* __restrict__ db, int parts, int LD) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * LD) return;
-  float t = 0.f;
-  for (int p = 0; p < parts; ++p) t += partial[(long)p * 2 * LD + i];
-  if (i < LD) dw[i] = t;
-  else db[i - LD] = t;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int n = 2 * LD;
+  float t0 = 0.f, t1 = 0.f;
+  if (i < n) {
+    int p = wave;
+    for (; p + 4 < parts; p += 8) {
+      t0 += partial[(long)p * n + i];
+      t1 += partial[(long)(p + 4) * n + i];
+    }
+    if (p < parts) t0 += partial[(long)p * n + i];
+  }
+  red[wave][lane] = t0 + t1;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (i < LD) dw[i] = t;
+    else db[i - LD] = t;
+  }
 }
 
 static int dcn_grid(int B) { return std::max(1, std::min(cdiv(B, kDcnWaves), 512)); }
@@ -393,7 +408,7 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
     const dim3 grid(cdiv(D, 256), cdiv(B, nchunk));
     hipLaunchKernelGGL(dcn_bwd_cols_kernel, grid, dim3(256), 0, st, x, w, b, s, dsbuf, g, dx, partial, B, D, L, nchunk);
     FIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 256)), dim3(256), 0, st, partial, dw, db, (int)grid.y, L * D);
+    hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 64)), dim3(256), 0, st, partial, dw, db, (int)grid.y, L * D);
     FIL_CHECK_LAUNCH();
     return FIL_OK;
   }
@@ -414,7 +429,7 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
 #undef BWD_SCALAR
   if (rc != 0) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: no kernel for L=%d", L);
   FIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 256)), dim3(256), 0, st, partial, dw, db, grid, L * D);
+  hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 64)), dim3(256), 0, st, partial, dw, db, grid, L * D);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
