@@ -1,8 +1,9 @@
 from .base import Layer
 from .behavior_layer import MultHeadAttentionLayer, ProductAttentionLayer
 from .core_layer import Dense, DnnLayer, HiddenLayer, MergeScoreLayer, ResActivateLayer, ScoreLayer, StackLayer
-from .interactive_layer import CIN, CrossLayer, FmLayer, InnerLayer, SparseEmbed
+from .interactive_layer import (CIN, AttentionBaseLayer, CrossLayer, FmLayer, InnerLayer, IPnnLayer, LinearLayer, OPnnLayer,
+                                SparseEmbed)
 
 __all__ = ["Layer", "InnerLayer", "FmLayer", "CrossLayer", "CIN", "SparseEmbed", "ProductAttentionLayer",
            "MultHeadAttentionLayer", "StackLayer", "ScoreLayer", "MergeScoreLayer", "HiddenLayer", "ResActivateLayer",
-           "DnnLayer", "Dense"]
+           "DnnLayer", "Dense", "IPnnLayer", "OPnnLayer", "LinearLayer", "AttentionBaseLayer"]

@@ -55,6 +55,86 @@ class InnerLayer(Layer):
         return list(pairs.split(1, dim=1))
 
 
+class IPnnLayer(Layer):
+    """IPnnLayer (interactive_layer.py:68-80): the pair list of InnerLayer(), unchanged."""
+
+    def __init__(self, seed=2020):
+        super().__init__()
+        self.seed = seed
+        self.inner = InnerLayer()
+
+    def call(self, inputs, **kwargs):
+        return self.inner(inputs)
+
+
+class OPnnLayer(Layer):
+    """OPnnLayer (interactive_layer.py:111-143).  Its InnerLayer(use_inner=False, ...) reads the attribute the
+    reference never defines, so calling it raises AttributeError there; the same here (kept for constructor parity)."""
+
+    def __init__(self, use_reduce=True, seed=2020, use_flatten=True):
+        super().__init__()
+        self.seed = seed
+        self.use_reduce = use_reduce
+        self.outer = InnerLayer(use_inner=False, perm=[0, 2, 1], mod=(1, 2))
+        self.use_flatten = use_flatten
+
+    def call(self, inputs, **kwargs):
+        if self.use_reduce:
+            from .core_layer import keras_add
+            sum_inputs = keras_add(list(inputs))
+            return self.outer([sum_inputs, sum_inputs])
+        return self.outer(inputs)
+
+
+class LinearLayer(Layer):
+    """LinearLayer (interactive_layer.py:172-187): w [in,1], b [1] (both `initializer`, default random_normal);
+    call(list of tensors [..., in]) -> list of tensordot(t, w, 1) + b."""
+
+    def __init__(self, initializer: str = "random_normal"):
+        super().__init__()
+        self.initalizer = initializer  # (sic) the reference's attribute name
+
+    def build(self, input_shape):
+        last = input_shape[-1]
+        while isinstance(last, (list, tuple)):  # Keras passes the list's last shape; input_shape[-1] is its last dim
+            last = last[-1]
+        self.w = self.add_weight("w", [last, 1], self.initalizer)
+        self.b = self.add_weight("b", [1], self.initalizer)
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        return [torch.matmul(t, self.w) + self.b for t in inputs]
+
+
+class AttentionBaseLayer(Layer):
+    """AttentionBaseLayer, the AFM pooling (interactive_layer.py:329-366), as coded:
+    x = concat(pairs, axis=1) [B,P,K]; score = Dense(1, relu, no bias)(x . single_score_w + single_score_b) [B,P,1];
+    ``Activation('softmax')`` normalises over the LAST axis, which has size 1 here, so every weight is exactly 1 and
+    the layer returns Dense(output_dim)(sum_p x_p): the reference's quirk is kept (the score weights get zero gradient).
+    The pair tensor comes from the HIP pair kernel (InnerLayer); the small dense algebra runs in torch."""
+
+    def __init__(self, attention_dim=4, seed=2020, output_dim=1):
+        super().__init__()
+        from .core_layer import Dense
+        self.atten_dim = attention_dim
+        self.seed = seed
+        self.output_layer = Dense(output_dim)
+
+    def build(self, input_shape):
+        k = input_shape[0][-1]
+        self.kernel_w = self.add_weight("single_score_w", [k, self.atten_dim], "glorot_uniform", seed=self.seed)
+        self.kernel_b = self.add_weight("single_score_b", [self.atten_dim], "glorot_uniform", seed=self.seed)
+        self.single_mlp_kernel = self.add_weight("single_mlp_kernel", [self.atten_dim, 1], "glorot_uniform", seed=self.seed)
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        x = pack_fields(inputs)
+        score = torch.relu(torch.matmul(torch.matmul(x, self.kernel_w) + self.kernel_b, self.single_mlp_kernel))
+        score_w = torch.softmax(score, dim=-1)
+        atten_inputs = (score_w * x).sum(dim=1)
+        return self.output_layer(atten_inputs)
+
+
 class FmLayer(Layer):
     """FmLayer (interactive_layer.py:145-170): call([cross_embed, linear_embed]) -> [B,1,K] =
     sum_{i<j} e_i*e_j + the broadcast sum of the linear terms (no reduction over K)."""

@@ -9,8 +9,8 @@ from collections import namedtuple
 
 import torch
 
-from .layers import (CIN, CrossLayer, DnnLayer, FmLayer, MergeScoreLayer, MultHeadAttentionLayer, ScoreLayer, SparseEmbed,
-                     StackLayer)
+from .layers import (CIN, AttentionBaseLayer, CrossLayer, DnnLayer, FmLayer, InnerLayer, IPnnLayer, MergeScoreLayer,
+                     MultHeadAttentionLayer, OPnnLayer, ScoreLayer, SparseEmbed, StackLayer)
 from .layers.base import Layer
 from .layers.core_layer import keras_add
 
@@ -77,6 +77,89 @@ class FM(torch.nn.Module):
     def forward(self, inputFea):
         fm_ = self.fm([inputFea.sparse_embed, inputFea.linear_embed])
         return self.score(fm_.squeeze(1))
+
+
+class PNN(torch.nn.Module):
+    """models.PNN (:42-55).  use_outer=True goes through OPnnLayer, which raises AttributeError in the reference
+    (and here); the default constructor keeps the reference's defaults, so pass use_outer=False to run it.
+    linear_embed must be a list (FeatureInput(useLinear=True))."""
+
+    def __init__(self, hidden_units=None, use_inner=True, use_outer=True):
+        super().__init__()
+        self.use_inner, self.use_outer = use_inner, use_outer
+        self.ipnn, self.opnn = IPnnLayer(), OPnnLayer()
+        self.stack = StackLayer()
+        self.dnn = DnnLayer(hidden_units or [256, 256, 256])
+        self.score = MergeScoreLayer(use_merge=False)
+
+    def forward(self, inputFea):
+        cross_fea = list(inputFea.linear_embed)
+        if self.use_inner:
+            cross_fea += self.ipnn(inputFea.sparse_embed)
+        if self.use_outer:
+            cross_fea += self.opnn(inputFea.sparse_embed)
+        return self.score(self.dnn(self.stack(cross_fea)))
+
+
+class DeepCross(torch.nn.Module):
+    """models.DeepCross (:57-66): the body only runs when hidden_units is None (its indentation in the reference puts
+    everything under that `if`); with explicit hidden_units the reference returns None, and so does this."""
+
+    def __init__(self, hidden_units=None):
+        super().__init__()
+        self.given = hidden_units is not None
+        self.stack = StackLayer()
+        self.dnn = DnnLayer(hidden_units=[256, 256, 256])
+        self.score = MergeScoreLayer(use_merge=False)
+
+    def forward(self, inputFea):
+        if self.given:
+            return None
+        return self.score(self.dnn(self.stack(list(inputFea.dense_inputs) + list(inputFea.sparse_embed))))
+
+
+class Wide_Deep(torch.nn.Module):
+    """models.Wide_Deep (:68-78)."""
+
+    def __init__(self, hidden_units=None):
+        super().__init__()
+        self.stack = StackLayer()
+        self.dnn = DnnLayer(hidden_units=hidden_units or [256, 128, 64])
+        self.score = MergeScoreLayer()
+
+    def forward(self, inputFea):
+        dnn_ = self.dnn(self.stack(list(inputFea.dense_inputs) + list(inputFea.sparse_embed)))
+        return self.score(list(inputFea.linear_embed) + [dnn_])
+
+
+class NFM(torch.nn.Module):
+    """models.NFM (:108-119): bi-interaction (sum of pair products) -> DNN(output_dim=1) + linear terms -> sigmoid."""
+
+    def __init__(self, hidden_units=None):
+        super().__init__()
+        self.inner = InnerLayer(use_inner=True, use_add=True)
+        self.stack = StackLayer()
+        self.dnn = DnnLayer(hidden_units=hidden_units or [256, 128, 64], output_dim=1)
+        self.score = ScoreLayer()
+
+    def forward(self, inputFea):
+        cross_inputs = self.inner(inputFea.sparse_embed)
+        dnn_fea = self.dnn(self.stack(list(inputFea.dense_inputs) + [cross_inputs]))
+        return self.score(keras_add(list(inputFea.linear_embed) + [dnn_fea]))
+
+
+class AFM(torch.nn.Module):
+    """models.AFM (:141-147)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inner = InnerLayer()
+        self.atten = AttentionBaseLayer()
+        self.score = ScoreLayer(use_add=True)
+
+    def forward(self, inputFea):
+        atten_output = self.atten(self.inner(inputFea.sparse_embed))
+        return self.score(list(inputFea.linear_embed) + [atten_output])
 
 
 class DeepFM(torch.nn.Module):

@@ -190,3 +190,18 @@ def sparse_embed(tables, indices):
     tables: list of F [V_f, K]; indices: list of F integer tensors [B,1].  Returns F x [B,1,K].
     """
     return [t[i.long()] for t, i in zip(tables, indices)]
+
+
+def linear_layer(inputs, w, b):
+    """LinearLayer.call (interactive_layer.py:186-187): tensordot(input, w, axes=1) + b for every input."""
+    return [torch.tensordot(t, w, dims=1) + b for t in inputs]
+
+
+def attention_base_layer(inputs, kernel_w, kernel_b, mlp_kernel, out_w, out_b):
+    """AttentionBaseLayer.call (interactive_layer.py:357-364), op for op.  Activation('softmax') is Keras' softmax over
+    axis -1; score_ has shape [B,P,1], so the normalisation runs over a single element."""
+    x = torch.cat(list(inputs), dim=1)                                   # tf.concat(inputs, axis=1)
+    score_ = torch.relu(torch.matmul(torch.matmul(x, kernel_w) + kernel_b, mlp_kernel))   # Dense(1, 'relu', use_bias=False)
+    score_w = torch.softmax(score_, dim=-1)
+    atten_inputs = torch.sum(score_w * x, dim=1)
+    return torch.matmul(atten_inputs, out_w) + out_b

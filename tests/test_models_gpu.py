@@ -82,5 +82,69 @@ def test_zoo_models_train(name):
         loss = torch.nn.functional.binary_cross_entropy(p.clamp(1e-6, 1 - 1e-6), y)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert np.isfinite(losses).all() and losses[-1] < losses[0] * 0.9, losses[::6]
+
+
+def test_afm_matches_oracle_composition():
+    """AFM (models.py:141-147) through InnerLayer pairs (HIP) + AttentionBaseLayer, against the oracle graph."""
+    vocab = [7, 11, 5, 13]
+    B, K = 17, 8
+    info = models.make_sparse_info(vocab, embed_dim=K)
+    fi = models.FeatureInput(sparseInfo=info, useLinear=True, useFlattenLinear=True)
+    model = models.CTRModel(fi, models.AFM()).cuda()
+    _, idx = _inputs(B, 1, vocab, seed=3)
+    out = model(None, idx)
+    assert out.shape == (B, 1)
+    D = lambda t: t.detach().cpu().double()
+    emb, offs = D(fi.sparse_embed.embeddings), fi.sparse_embed.offsets.cpu()
+    sparse_embed = graph.sparse_embed([emb[offs[f]:offs[f] + vocab[f]] for f in range(len(vocab))],
+                                      [idx[:, f:f + 1].cpu() for f in range(len(vocab))])
+    lin, loff = D(fi.linear_embed.embeddings), fi.linear_embed.offsets.cpu()
+    linear = [lin[loff[f]:loff[f] + vocab[f]][idx[:, f].cpu()] for f in range(len(vocab))]  # F x [B,1]
+    a = model.body.atten
+    atten = graph.attention_base_layer(graph.inner_layer(sparse_embed), D(a.kernel_w), D(a.kernel_b), D(a.single_mlp_kernel),
+                                       D(a.output_layer.kernel), D(a.output_layer.bias))
+    want = torch.sigmoid(sum(linear) + atten)
+    assert rel(out, want) < 1e-5
+    # the reference's softmax runs over a size-1 axis: the score weights cannot receive gradient
+    out.sum().backward()
+    assert float(a.kernel_w.grad.abs().max()) == 0.0 and float(fi.sparse_embed.embeddings.grad.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("name", ["NFM", "AFM", "PNN", "Wide_Deep", "DeepCross"])
+def test_more_zoo_models_train(name):
+    torch.manual_seed(0)
+    vocab = [9, 4, 6, 12, 5]
+    B, K = 64, 8
+    info = models.make_sparse_info(vocab, embed_dim=K)
+    fi = models.FeatureInput(sparseInfo=info, useLinear=True, useFlattenLinear=True)
+    body = {"NFM": lambda: models.NFM(hidden_units=[16, 8]), "AFM": lambda: models.AFM(),
+            "PNN": lambda: models.PNN(hidden_units=[16, 8], use_outer=False),
+            "Wide_Deep": lambda: models.Wide_Deep(hidden_units=[16, 8]), "DeepCross": lambda: models.DeepCross()}[name]()
+    model = models.CTRModel(fi, body).cuda()
+    dense, idx = _inputs(B, 2, vocab, seed=1)
+    y = torch.tensor(np.random.default_rng(2).integers(0, 2, B), dtype=torch.float32, device="cuda")
+    out = model(dense, idx)
+    opt = torch.optim.Adam(model.parameters(), lr=0.002 if name == "DeepCross" else 0.05)  # DeepCross: fixed 3x256 MLP
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        out = model(dense, idx)
+        p = out[:, 1] if out.shape[1] == 2 else out[:, 0]
+        loss = torch.nn.functional.binary_cross_entropy(p.clamp(1e-6, 1 - 1e-6), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] * 0.9, losses[::6]
+
+
+def test_reference_quirks_of_the_zoo():
+    vocab = [5, 6, 7]
+    info = models.make_sparse_info(vocab, embed_dim=4)
+    fi = models.FeatureInput(sparseInfo=info, useLinear=True, useFlattenLinear=True).cuda()
+    dense, idx = _inputs(8, 1, vocab)
+    fea = fi((dense, idx))
+    with pytest.raises(AttributeError):   # PNN's default use_outer=True reaches InnerLayer(use_inner=False) (models.py:50)
+        models.PNN(hidden_units=[8])(fea)
+    assert models.DeepCross(hidden_units=[8])(fea) is None   # models.py:57-66: the body sits under `if hidden_units is None`

@@ -197,3 +197,29 @@ def test_embed_gather_scatter():
     assert np.allclose(d[2].sum(0), g[:, 2].sum(0))
     got = graph.sparse_embed([torch.tensor(t) for t in tables], [torch.tensor(idx[:, f:f + 1]) for f in range(3)])
     assert got[0].shape == (16, 1, 4) and np.array_equal(torch.cat(got, 1).numpy(), e)
+
+
+def test_attention_base_layer_softmax_is_over_a_single_element():
+    """AFM's AttentionBaseLayer (interactive_layer.py:357-364): softmax over the last axis of [B,P,1] is identically 1, so
+    the layer equals Dense(sum of the pair tensors) whatever the score weights are."""
+    import torch
+    from oracle import graph
+    g = torch.Generator().manual_seed(0)
+    pairs = [torch.randn(5, 1, 6, dtype=torch.float64, generator=g) for _ in range(10)]
+    ow, ob = torch.randn(6, 1, dtype=torch.float64, generator=g), torch.randn(1, dtype=torch.float64, generator=g)
+    outs = []
+    for seed in (1, 2):
+        gg = torch.Generator().manual_seed(seed)
+        kw, kb, mk = (torch.randn(6, 4, dtype=torch.float64, generator=gg), torch.randn(4, dtype=torch.float64, generator=gg),
+                      torch.randn(4, 1, dtype=torch.float64, generator=gg))
+        outs.append(graph.attention_base_layer(pairs, kw, kb, mk, ow, ob))
+    want = torch.cat(pairs, 1).sum(1) @ ow + ob
+    assert torch.allclose(outs[0], want) and torch.equal(outs[0], outs[1])
+
+
+def test_linear_layer_restatement():
+    import torch
+    from oracle import graph
+    w, b = torch.tensor([[2.0], [3.0]], dtype=torch.float64), torch.tensor([0.5], dtype=torch.float64)
+    out = graph.linear_layer([torch.tensor([[1.0, 1.0], [0.0, 2.0]], dtype=torch.float64)], w, b)
+    assert torch.equal(out[0], torch.tensor([[5.5], [6.5]], dtype=torch.float64))
