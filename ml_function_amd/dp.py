@@ -71,3 +71,37 @@ def allreduce_module_grads(module, group=None):
     bucket.all_reduce(group)
     bucket.assign_to_grads(params)
     return bucket
+
+
+def exchange_sparse_rows(grad, touched_rows, group=None):
+    """Data-parallel sum of an embedding-table gradient that is zero outside the rows each rank touched.
+
+    grad [V, K] holds this rank's scatter-added gradient (rows outside `touched_rows` are zero); `touched_rows` is a
+    1-D int64 tensor of the table rows this rank's batch shard indexed (duplicates allowed).  Instead of all-reducing
+    the whole table (V*K floats: 100s of MB for Criteo-size vocabularies), every rank contributes only its unique
+    touched rows: counts are all-gathered, then the padded (row id, row value) lists, and each rank adds the lists in
+    rank order -- the same fixed order everywhere, so all replicas end with bit-identical gradients.
+    Returns the sorted union of touched rows (the only rows an optimizer needs to visit).  No-op for world size 1.
+    """
+    rows = torch.unique(touched_rows.reshape(-1).to(torch.int64))
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return rows
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([rows.numel()], dtype=torch.int64, device=grad.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(max(counts), 1)
+    k = grad.shape[1]
+    pad_rows = torch.zeros(n_max, dtype=torch.int64, device=grad.device)
+    pad_vals = torch.zeros((n_max, k), dtype=grad.dtype, device=grad.device)
+    pad_rows[:rows.numel()] = rows
+    pad_vals[:rows.numel()] = grad[rows]
+    all_rows = [torch.empty_like(pad_rows) for _ in range(world)]
+    all_vals = [torch.empty_like(pad_vals) for _ in range(world)]
+    dist.all_gather(all_rows, pad_rows, group=group)
+    dist.all_gather(all_vals, pad_vals, group=group)
+    grad[rows] = 0
+    for r in range(world):  # rank order: identical summation order on every replica
+        grad.index_add_(0, all_rows[r][:counts[r]], all_vals[r][:counts[r]])
+    return torch.unique(torch.cat([all_rows[r][:counts[r]] for r in range(world)]))

@@ -77,3 +77,46 @@ def test_gradient_allreduce_equals_full_batch(tmp_path):
     want = np.concatenate([g.reshape(-1) for g in list(dWs) + list(dbs) + [ddw, ddb]])
     assert flat.shape == want.shape
     assert np.abs(flat - want).max() / np.abs(want).max() < 1e-6
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, K, B = 50, 4, 12
+        rng = np.random.default_rng(5)
+        idx = torch.tensor(rng.integers(0, V, B))
+        g = torch.tensor(rng.normal(size=(B, K)), dtype=torch.float32)
+        lo, hi = dp.shard_bounds(B, rank, world)
+        grad = torch.zeros(V, K)
+        grad.index_add_(0, idx[lo:hi], g[lo:hi])          # what fil_embed_scatter_add produces for this shard
+        rows = dp.exchange_sparse_rows(grad, idx[lo:hi])
+        np.save(os.path.join(out_dir, "g%d.npy" % rank), grad.numpy())
+        np.save(os.path.join(out_dir, "r%d.npy" % rank), rows.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_row_exchange_equals_full_batch(tmp_path):
+    """Embedding-table gradients: exchanging only the touched rows gives the full-batch gradient, bit-identical on
+    every replica (fixed rank order of the additions)."""
+    world = 2
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    V, K, B = 50, 4, 12
+    rng = np.random.default_rng(5)
+    idx = torch.tensor(rng.integers(0, V, B))
+    g = torch.tensor(rng.normal(size=(B, K)), dtype=torch.float32)
+    want = torch.zeros(V, K)
+    want.index_add_(0, idx, g)
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(g0, g1)
+    assert np.abs(g0 - want.numpy()).max() < 1e-6
+    assert np.array_equal(np.load(tmp_path / "r0.npy"), np.unique(idx.numpy()))
+
+
+def test_sparse_row_exchange_single_process_is_a_noop():
+    grad = torch.arange(12, dtype=torch.float32).reshape(6, 2)
+    keep = grad.clone()
+    rows = dp.exchange_sparse_rows(grad, torch.tensor([4, 1, 4]))
+    assert torch.equal(grad, keep) and rows.tolist() == [1, 4]
