@@ -223,6 +223,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # timed region: HIP events around the three GEMM kernels of every layer only (an event pair costs ~5 us of
+    # stream time; with all 13 scopes recorded the step is 2.3 % slower)
+    os.environ["FIL_PROFILE_FILTER"] = "cin_fwd_l,cin_bwd_dw_l,cin_bwd_dz_l"
     _lib.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -234,6 +237,14 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # separate, untimed pass with every scope recorded: the per-kernel table of the small kernels
+    os.environ["FIL_PROFILE_FILTER"] = ""
+    _lib.profile_begin()
+    for _ in range(max(2, args.steps // 4)):
+        step()
+    fence()
+    prof_all = _lib.profile_end()
+    n_all = max(2, args.steps // 4)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -243,10 +254,13 @@ def main():
         dom = max(mf, key=lambda k: mf[k]["total_ms"])
         d = mf[dom]
         achieved = d["work"] / (d["avg_ms"] * 1e-3) / 1e12
-        kernels = {k: dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / args.steps,
+        kernels = {k: dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / n_all,
                            tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2) if k in mf else None)
-                   for k, v in sorted(prof.items())}
-        gpu_ms = sum(v["total_ms"] for v in prof.values()) / args.steps
+                   for k, v in sorted(prof_all.items())}
+        for k, v in mf.items():  # the GEMM kernels: numbers of the timed region itself
+            kernels[k] = dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / args.steps,
+                              tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2))
+        gpu_ms = sum(v["total_ms"] for v in prof_all.values()) / n_all
         res = {
             "metric": "samples/sec fwd+bwd xDeepFM-CIN B=4096,F=39,K=16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -32,14 +32,14 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Opt-in per-kernel timing (fil_profile_begin/_end in include/fil.h): when enabled, every major launch is
 // bracketed by a pair of HIP events recorded on the launch stream.  Off by default (zero overhead, capture-safe).
 bool prof_enabled();
-void prof_begin_scope(const char* name, hipStream_t st, double work);
+bool prof_begin_scope(const char* name, hipStream_t st, double work);
 void prof_end_scope(hipStream_t st);
 struct ProfScope {
   hipStream_t st;
   bool on;
   // work = algorithmic flops (MFMA kernels) or bytes (streaming kernels) of this launch, reported back verbatim
   ProfScope(const char* name, hipStream_t s, double work = 0.0) : st(s), on(prof_enabled()) {
-    if (on) prof_begin_scope(name, st, work);
+    if (on) on = prof_begin_scope(name, st, work);
   }
   ~ProfScope() {
     if (on) prof_end_scope(st);

@@ -1,5 +1,7 @@
 // Error reporting + version for libfil_hip.so.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 #include <string.h>
 
@@ -49,11 +51,39 @@ static hipEvent_t pool_event() {
   return g_pool[g_pool_next++];
 }
 
-void prof_begin_scope(const char* name, hipStream_t st, double work) {
+// FIL_PROFILE_FILTER=<substr>[,<substr>...] (read at fil_profile_begin): only scopes whose name contains one of the
+// substrings record events -- an event pair costs about 5 us of stream time per scope, so bench.py's timed region
+// profiles the GEMM kernels only and takes the full per-kernel table from a separate pass.
+static std::vector<std::string> g_prof_filter;
+static void load_filter() {
+  g_prof_filter.clear();
+  const char* f = getenv("FIL_PROFILE_FILTER");
+  if (f == nullptr) return;
+  std::string cur;
+  for (const char* p = f;; ++p) {
+    if (*p == ',' || *p == 0) {
+      if (!cur.empty()) g_prof_filter.push_back(cur);
+      cur.clear();
+      if (*p == 0) break;
+    } else {
+      cur.push_back(*p);
+    }
+  }
+}
+static bool scope_selected(const char* name) {
+  if (g_prof_filter.empty()) return true;
+  for (const auto& f : g_prof_filter)
+    if (strstr(name, f.c_str()) != nullptr) return true;
+  return false;
+}
+
+bool prof_begin_scope(const char* name, hipStream_t st, double work) {
+  if (!scope_selected(name)) return false;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{name, work, pool_event(), pool_event()};
   (void)hipEventRecord(r.e0, st);
   g_prof.push_back(r);
+  return true;
 }
 
 void prof_end_scope(hipStream_t st) {
@@ -67,6 +97,7 @@ extern "C" int fil_profile_begin(void) {
   std::lock_guard<std::mutex> lk(fil::g_prof_mu);
   fil::g_prof.clear();
   fil::g_pool_next = 0;
+  fil::load_filter();
   fil::g_prof_on = true;
   return FIL_OK;
 }
