@@ -86,7 +86,7 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) with the last layer contracted against
  *             sum_n W_L[c,n] (its feature map is only ever sum-pooled, so this is the same function at 1/H_L of the flops);
  *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
- *   Limits: F <= 64, H_l <= 256, L <= 8, L*K <= 255, B*K < 2^21.
+ *   Limits: F <= 64, H_l <= 256, L <= 8, L*K <= 255, B*K <= 2^28.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
 size_t fil_cin_fwd_workspace_bytes(int B, int F, int K, int L, const int* H);

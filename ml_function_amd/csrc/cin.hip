@@ -33,7 +33,7 @@ static int check_shape(const char* fn, int B, int F, int K, int L, const int* H,
   if (B < 0 || F < 1 || K < 1 || L < 1 || H == nullptr) return fail(FIL_ERR_ARG, "%s: bad shape B=%d F=%d K=%d L=%d", fn, B, F, K, L);
   if (L > kCinMaxL) return fail(FIL_ERR_UNSUPPORTED, "%s: L=%d > %d", fn, L, kCinMaxL);
   if (F > 64) return fail(FIL_ERR_UNSUPPORTED, "%s: F=%d > 64 fields", fn, F);
-  if ((long)B * K * 256 * 4 >= (1L << 31)) return fail(FIL_ERR_UNSUPPORTED, "%s: B*K = %ld rows exceed the 2 GiB buffer-descriptor range of the kernels", fn, (long)B * K);
+  if ((long)B * K > (1L << 28)) return fail(FIL_ERR_UNSUPPORTED, "%s: B*K = %ld rows > 2^28 (row-split byte offsets of the dW kernel are 32-bit)", fn, (long)B * K);
   s.B = B; s.F = F; s.K = K; s.L = L;
   for (int l = 0; l < L; ++l) {
     if (H[l] < 1) return fail(FIL_ERR_ARG, "%s: H[%d]=%d", fn, l, H[l]);
@@ -97,7 +97,8 @@ static DwPlan dw_plan(long M, int C, int H) {
   if (best <= 0) {
     static const double t_of[4] = {0.0, 1.05e-4, 1.39e-4, 1.96e-4};
     double best_ms = -1.0;
-    for (int sp = 1; sp <= 256; ++sp) {
+    // a split's byte offsets (rows * up to 1 KiB) must stay below 2^31: at most 2^20 rows per split
+    for (int sp = (int)std::max<long>(1, (M + (1L << 20) - 1) >> 20); sp <= 256; ++sp) {
       const long rps = rows_of(sp);
       const long real = (M + rps - 1) / rps;           // splits that actually get rows
       if (real != sp && sp > 1) continue;              // same plan as a smaller sp

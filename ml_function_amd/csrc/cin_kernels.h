@@ -610,9 +610,13 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   const int split = item / (blocks_x * chunks);
   const int c0 = (bx * 4 + wave) * (32 * MB);
   if (c0 >= C) return;
-  const __amdgpu_buffer_rsrc_t rg = make_rsrc(gT, (long)M * HS * 4);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(XONES ? gT : xT, (long)M * F * 4);
-  const __amdgpu_buffer_rsrc_t rp = make_rsrc(xpT, (long)M * xps * 4);
+  // descriptors start at the split's first row (offsets stay far below the 2 GiB descriptor range for any M) and end
+  // with the tensor, so the prefetch past the last row reads zeros
+  const int m_lo = split * rows_per_split;
+  const long mrem = (long)M - m_lo;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(gT + (long)m_lo * HS, mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(XONES ? gT : xT + (long)m_lo * F, mrem * F * 4);
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(xpT + (long)m_lo * xps, mrem * xps * 4);
   int fo[MB], ho[MB];
   bool cv[MB];
 #pragma unroll
@@ -626,7 +630,6 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
     fo[mb] = (half * F + ff) * 4;
   }
   const int go = (half * HS + chunk * 128 + 4 * r) * 4;
-  const int m_lo = split * rows_per_split;
   const int m_hi = min(M, m_lo + rows_per_split);
   const int steps = (m_hi - m_lo + 1) >> 1;
   const int groups = (steps + DEPTH - 1) / DEPTH;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   float qx[DEPTH][MB], qp[DEPTH][MB];
   // step s reads rows m_lo + 2s (+half): scalar byte offsets advance by two rows per step
   auto fetch = [&](int s, f32x4v& g4, float (&xv)[MB], float (&pv)[MB]) {
-    const int row = m_lo + 2 * s;  // uniform
+    const int row = 2 * s;  // uniform, relative to the split's first row
     g4 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rg, go, row * HS * 4, 0));
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {

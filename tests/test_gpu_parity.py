@@ -31,6 +31,38 @@ def check(name, got, want, tol=TOL):
     assert np.isfinite(e) and e <= tol, "%s: rel err %.3e > %.1e" % (name, e, tol)
 
 
+def test_cin_large_batch_rows_beyond_2_pow_21():
+    """B*K = 2.4 M rows (the dW kernel's buffer descriptors used to span the whole tensor: 2^21 rows at most).
+    Size-independent checks: the first samples equal a small run bit for bit (batch independence), and the weight
+    gradient equals the sum of the two half-batch gradients."""
+    from ml_function_amd import functional as Fn
+    B, F, K, conv = 150000, 39, 16, [64, 32]
+    c = synth.cin_case(64, F, K, conv, dist="uniform")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = (torch.rand((B, F, K), device="cuda", generator=g) - 0.5)
+    x[:64] = dev(c["x"])
+    Ws = [dev(w) for w in c["Ws"]]
+    bs = [dev(b) for b in c["bs"]]
+    dw, db = dev(c["dense_w"]), dev(c["dense_b"])
+    gout = torch.randn((B, 1), device="cuda", generator=g)
+
+    def run(xs, gs):
+        xs = xs.clone().requires_grad_()
+        W2 = [w.clone().requires_grad_() for w in Ws]
+        out = Fn.cin(xs, W2, bs, dw, db)
+        out.backward(gs)
+        return out.detach(), xs.grad, [w.grad for w in W2]
+
+    out, dx, dW = run(x, gout)
+    out_s, dx_s, _ = run(x[:64], gout[:64])
+    assert torch.equal(out[:64], out_s) and torch.equal(dx[:64], dx_s)
+    h = B // 2
+    _, _, dWa = run(x[:h], gout[:h])
+    _, _, dWb = run(x[h:], gout[h:])
+    for l in range(len(conv)):
+        check("large-batch dW%d" % l, dW[l], (dWa[l] + dWb[l]).cpu().numpy(), tol=2e-5)
+
+
 # ------------------------------------------------------------------ FM
 @pytest.mark.parametrize("B,F,K", [(256, 39, 8), (4096, 39, 16), (7, 3, 4), (33, 5, 6), (1, 2, 1), (130, 26, 32)])
 @pytest.mark.parametrize("dist", ["uniform", "normal"])
