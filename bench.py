@@ -64,7 +64,7 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(sample_b=512, steps=3):
+def cpu_baseline(sample_b=1024, steps=10):
     """Reference-graph restatement (oracle/graph.py) on the host CPU, fp32, all cores, bounded sample."""
     from ml_function_amd import synth
     from oracle import graph
@@ -274,7 +274,7 @@ def main():
                          "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["work"]},
             "kernels": kernels, "gpu_kernel_ms_per_step": gpu_ms,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:
