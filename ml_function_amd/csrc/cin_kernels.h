@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     const int n = chunk * 128 + 4 * r + nb;
     bv[nb] = n < H ? bias[n] : 0.f;
   }
-  const float bsum = half_wave_sum(bv[0] + bv[1] + bv[2] + bv[3]);
+  const float bsum = half_wave_sum_hi(bv[0] + bv[1] + bv[2] + bv[3]);  // (valid on the writer lane r == 31)
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
       const float v0 = acc[mb][0][reg], v1 = acc[mb][1][reg], v2 = acc[mb][2][reg], v3 = acc[mb][3][reg];
       if (xoutT != nullptr && m < M)
         *reinterpret_cast<float4*>(xoutT + (long)m * HS + chunk * 128 + 4 * r) = make_float4(v0 + bv[0], v1 + bv[1], v2 + bv[2], v3 + bv[3]);
-      const float p = half_wave_sum((v0 + v1) + (v2 + v3)) + bsum;
-      if (r == 0 && m < M) pool_part[(long)chunk * M + m] = p;
+      const float p = half_wave_sum_hi((v0 + v1) + (v2 + v3)) + bsum;
+      if (r == 31 && m < M) pool_part[(long)chunk * M + m] = p;
     }
   }
 
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
           e = fmaf(acc[mb][1][reg] + bv[1], t[1][reg], e);
           e = fmaf(acc[mb][2][reg] + bv[2], t[2][reg], e);
           e = fmaf(acc[mb][3][reg] + bv[3], t[3][reg], e);
-          const float p = half_wave_sum(e) + bn;
-          if (r == 0 && m < M) pool_next[(long)chunk * M + m] = p;
+          const float p = half_wave_sum_hi(e) + bn;
+          if (r == 31 && m < M) pool_next[(long)chunk * M + m] = p;
         }
       }
     }

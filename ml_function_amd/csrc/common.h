@@ -73,6 +73,21 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+// Sum over the 32 lanes of each wave half with DPP adds (VALU only: no LDS crossbar round trips like the ds_bpermute
+// behind __shfl_xor).  The total is valid in lanes 16..31 / 48..63 of the half only (use lane (lane & 31) == 31).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+  v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_mov<0x140, 0xF>(v);  // row_mirror
+  v += dpp_mov<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  return v;
+}
+
 // v[lane] + v[lane ^ 32] in every lane, with the gfx950 VALU half swap (v_permlane32_swap) instead of a round trip
 // through the LDS crossbar (ds_bpermute + s_waitcnt stalls the wave; this does not).  Inline asm: the builtin of
 // this compiler returns the same register for both results.
