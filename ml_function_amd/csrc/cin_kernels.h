@@ -284,14 +284,21 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
           for (int i = 0; i < 16; ++i) t[nb][i] = 0.f;
+        // (4-deep operand queue: an unprefetched 16-byte load per step would pay the L2 latency JT times)
+        constexpr int QD = JT < 4 ? JT : 4;
+        float4 wq[QD];
+#pragma unroll
+        for (int j = 0; j < QD; ++j) wq[j] = wsb[(long)(2 * j) * 32];
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-          const float4 w = wsb[(long)(2 * j) * 32];
+          const float4 w = wq[j % QD];
+          if (j + QD < JT) wq[j % QD] = wsb[(long)(2 * (j + QD)) * 32];
           const float a = xr[mb][j];
           t[0] = mfma32(a, w.x, t[0]);
           t[1] = mfma32(a, w.y, t[1]);
           t[2] = mfma32(a, w.z, t[2]);
           t[3] = mfma32(a, w.w, t[3]);
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
