@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint"],
                     help="cin = the headline benchmark (default); the others are single-GPU side benchmarks of the "
                          "remaining hot-path rows (BASELINE.json configs 2, 3, 5)")
+    ap.add_argument("--cin-mode", type=int, default=0, help="fil_cin mode bits (experiments; the headline is mode 0)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16_mfma"], help="AutoInt side benchmark only")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
     args = ap.parse_args()
@@ -209,8 +210,8 @@ def main():
     flat, grads = make_bucket(inp, device)
 
     def step():
-        out, pooled, saved = Fn.cin_forward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], inp["dense_b"], 1, 0)
-        Fn.cin_backward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], pooled, saved, inp["g"], 1, 0, grads=grads)
+        out, pooled, saved = Fn.cin_forward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], inp["dense_b"], 1, args.cin_mode)
+        Fn.cin_backward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], pooled, saved, inp["g"], 1, args.cin_mode, grads=grads)
         if world > 1:
             dist.all_reduce(flat)  # sum of layer gradients over the data-parallel ranks (RCCL over xGMI)
         return out
@@ -265,7 +266,7 @@ def main():
             "metric": "samples/sec fwd+bwd xDeepFM-CIN B=4096,F=39,K=16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.cin_mode < 2 else "f32 (forward GEMMs: split-bf16 x3, fp32-equivalent; experiment)", "data": "synthetic",
             "config": {"workload": "xDeepFM CIN 3x128 feature maps fwd+bwd, F=39 K=16, B=4096 per GPU, fp32 "
                                    "(BASELINE.json configs[3])", "global_batch": world * B_PER_GPU,
                        "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if world > 1 else 0},

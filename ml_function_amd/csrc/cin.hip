@@ -147,7 +147,10 @@ static size_t saved_bytes(const CinShape& s) {
 }
 static size_t wf_floats(const CinShape& s) {
   size_t w = 0;
-  for (int l = 0; l < s.L; ++l) w = std::max(w, (size_t)chunks_of(s.H[l]) * s.Hp(l) * 2 * s.JT() * 128);
+  for (int l = 0; l < s.L; ++l) {
+    w = std::max(w, (size_t)chunks_of(s.H[l]) * s.Hp(l) * 2 * s.JT() * 128);
+    w = std::max(w, cin_wb_floats(s.Hp(l), s.JT(), chunks_of(s.H[l])));   // split-bf16 planes (mode bit 1)
+  }
   return w + (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
 }
 static int dz_periods(const CinShape& s, int l) { return cdiv(s.Hp(l), cin_dz_h_per_period(s.JT())); }
@@ -228,7 +231,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode != 0 && mode != 1) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (0 = fp32 MFMA + last-layer shortcut, 1 = fp32 MFMA, general kernels only)", mode);
+  if (mode < 0 || mode > 3) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bit 0: general kernels for every layer; bit 1: split-bf16 GEMMs)", mode);
+  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
+  mode &= 1;
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && W && bias && pooled && saved);
   FIL_CHECK_ARG(output_dim != 1 || (dense_w && dense_b && out));
@@ -281,8 +286,15 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
         cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl);
       } else {
-        const long npack = (long)chunks * Hp * 2 * JT * 128;
-        hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
+        long npack = (long)chunks * Hp * 2 * JT * 128;
+        if (split) {
+          npack = (long)cin_wb_floats(Hp, JT, chunks);
+          const long nvec = npack / 4;
+          hipLaunchKernelGGL(cin_pack_wb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
+                             reinterpret_cast<bf16x8*>(Wf), Hp, F, Hl, JT, (Hp + 3) / 4, chunks);
+        } else {
+          hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
+        }
         const float* wsn = nullptr;
         if (fuse_next) {
           FIL_CHECK_ARG(W[l + 1] && bias[l + 1]);
@@ -295,7 +307,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         }
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl) + (fuse_next ? 2.0 * (double)M * Hl * F : 0.0));
         cin_launch_fwd3(st, MB, JT, dim3(cdiv((int)M, 128 * MB), chunks), xT, xpT, xps, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hp, Hl,
-                        wsn, fuse_next ? bias[l + 1] : nullptr, fuse_next ? H[l + 1] : 0, fuse_next ? const_cast<float*>(pa.part[l + 1]) : nullptr);
+                        wsn, fuse_next ? bias[l + 1] : nullptr, fuse_next ? H[l + 1] : 0, fuse_next ? const_cast<float*>(pa.part[l + 1]) : nullptr,
+                        split);
       }
     }
     FIL_CHECK_LAUNCH();
@@ -318,7 +331,10 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode != 0 && mode != 1) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (0 = fp32 MFMA + last-layer shortcut, 1 = fp32 MFMA, general kernels only)", mode);
+  if (mode < 0 || mode > 3) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bit 0: general kernels for every layer; bit 1: split-bf16 GEMMs)", mode);
+  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (this round: forward kernels only; the backward GEMMs stay exact fp32)
+  (void)split;
+  mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
   hipStream_t st = (hipStream_t)stream;
   const size_t LK = (size_t)L * K;

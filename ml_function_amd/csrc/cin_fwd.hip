@@ -7,18 +7,22 @@ namespace fil {
 template <int MB, int JT>
 static void fwd3(hipStream_t st, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf, const float* bias,
                  float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H, const float* wsn, const float* bias_next,
-                 int H_next, float* pool_next) {
-  hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H,
-                     wsn, bias_next, H_next, pool_next);
+                 int H_next, float* pool_next, bool split) {
+  if (split)
+    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, false, true>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M,
+                       F, Hp, H, wsn, bias_next, H_next, pool_next);
+  else
+    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H,
+                       wsn, bias_next, H_next, pool_next);
 }
 
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
                      const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H, const float* wsn,
-                     const float* bias_next, int H_next, float* pool_next) {
+                     const float* bias_next, int H_next, float* pool_next, bool split) {
 #define FIL_F3(JTV)                                                                                                                      \
   case JTV:                                                                                                                              \
-    if (MB == 2) fwd3<2, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next);   \
-    else fwd3<1, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next);           \
+    if (MB == 2) fwd3<2, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next, split);   \
+    else fwd3<1, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next, split);           \
     break;
   switch (JT) { FIL_F3(4) FIL_F3(8) FIL_F3(12) FIL_F3(16) FIL_F3(20) FIL_F3(24) FIL_F3(28) FIL_F3(32) }
 #undef FIL_F3

@@ -123,6 +123,79 @@ static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float
   }
 }
 
+// ---- split-bf16 ("bf16x3") operands -------------------------------------------------------------------------------
+// fp32 value v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) (3 x 8 significand bits).
+// A product a*b is then a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 (+ terms below 2^-24 relative, dropped): six bf16 MFMAs
+// with fp32 accumulation on the separate bf16 matrix pipe (16x the f32-MFMA rate) instead of one f32 MFMA step, and the
+// split's VALU work hides behind them (tools/probe_bf16x3.hip).  Opt-in (mode bit 1): the exact-fp32 kernels stay the default.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma32b(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split3(const float (&p)[8], bf16x8& a1, bf16x8& a2, bf16x8& a3) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h1 = (__bf16)p[i];
+    const float r1 = p[i] - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    a1[i] = h1;
+    a2[i] = h2;
+    a3[i] = (__bf16)r2;
+  }
+}
+
+// acc += a * b to fp32 accuracy from the split operands (small terms first)
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  c = mfma32b(a[2], b[0], c);
+  c = mfma32b(a[0], b[2], c);
+  c = mfma32b(a[1], b[1], c);
+  c = mfma32b(a[1], b[0], c);
+  c = mfma32b(a[0], b[1], c);
+  c = mfma32b(a[0], b[0], c);
+  return c;
+}
+
+// Split-bf16 forward weights.  The reduction runs in groups of 8 steps; a super-period = 4 values of h = 4*JT steps =
+// JT/2 groups (even, JT being a multiple of 4: the kernel double-buffers groups).  Group gg of super-period sp, element e: step s = 8*gg + e,
+// h = 4*sp + s / JT, j = s % JT, f = 2j + half.  Layout [chunk][sp][gg][plane][nb][lane 64][8 bf16]: one aligned
+// 16-byte load per (group, plane, nb) and lane; lane r owns columns 4r..4r+3 (nb) of the chunk.
+static __global__ __launch_bounds__(256) void cin_pack_wb_kernel(const float* __restrict__ W, bf16x8* __restrict__ Wb, int Hp, int F, int H,
+                                                          int JT, int nsp, int chunks) {
+  const int ngs = JT / 2;  // groups per super-period
+  const long total = (long)chunks * nsp * ngs * 12 * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long t = idx >> 6;
+    const int nb = (int)(t & 3);
+    t >>= 2;
+    const int plane = (int)(t % 3);
+    t /= 3;
+    const int gg = (int)(t % ngs);
+    t /= ngs;
+    const int sp = (int)(t % nsp), chunk = (int)(t / nsp);
+    const int r = lane & 31, half = lane >> 5;
+    const int n = chunk * 128 + 4 * r + nb;
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int s = 8 * gg + e;
+      const int h = 4 * sp + s / JT, j = s % JT;
+      const int f = 2 * j + half;
+      const float w = (h < Hp && f < F && n < H) ? W[((long)h * F + f) * H + n] : 0.f;
+      const __bf16 h1 = (__bf16)w;
+      const float r1 = w - (float)h1;
+      const __bf16 h2 = (__bf16)r1;
+      const __bf16 h3 = (__bf16)(r1 - (float)h2);
+      out[e] = plane == 0 ? h1 : (plane == 1 ? h2 : h3);
+    }
+    Wb[idx] = out;
+  }
+}
+
 // Forward layer, streaming form.  Wave = 32*MB rows x 128 columns (one chunk); step (h, j): half 0 / 1 take
 // f = 2j / 2j+1; the W row pair of step s = h*JT + j is Wf row 2s+half, so the B-operand stream is linear.
 // x^{l-1}[m,h] is one dword per h (prefetched); the queue holds DEPTH steps of B operands (16 B per lane each).
@@ -131,7 +204,10 @@ static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float
 // F*(F/2+1) unordered pairs (h, f = (h+d) mod F), d = 0..F/2, against pre-summed weights W[(h,f)] + W[(f,h)]
 // (cin_pack_wf_sym_kernel): half the MFMA work.  Step (h, j) then multiplies by x[m,(h + 2j + half) mod F], which
 // moves with h, so the x fragment is re-fetched per h (one h ahead) instead of living in registers for the whole run.
-template <int MB, int JT, bool SYM = false>
+//
+// SPLIT (opt-in, general layers): the main loop runs on split-bf16 operands (see above); Wf then points to the
+// cin_pack_wb_kernel layout.  Prologue, epilogue and the fused next-layer pooling are shared with the fp32 form.
+template <int MB, int JT, bool SYM = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                           const float* __restrict__ Wf, const float* __restrict__ bias,
                                                           float* __restrict__ xoutT, int HS, float* __restrict__ pool_part, int M,
@@ -198,49 +274,108 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
-  const float4* wbase = reinterpret_cast<const float4*>(Wf + (long)chunk * Hp * (2 * JT) * 128) + (half * 32 + r);
-  float4 q[DEPTH];
+  if constexpr (SPLIT) {
+    static_assert(!SYM, "the split-bf16 loop is for the general layers");
+    static_assert(JT % 4 == 0, "groups per super-period must be even");
+    constexpr int NGS = JT / 2;  // groups of 8 steps per super-period of 4 h
+    const int nsp = (Hp + 3) >> 2;
+    const long chunk_bytes = (long)nsp * NGS * 12 * 1024;
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wf) + (long)chunk * (chunk_bytes >> 2), 0, (int)chunk_bytes, 0x00020000);
+    const int vo = lane * 16;
+    u32x4 bb[2][12];
+    auto fetch_group = [&](int grp, u32x4 (&dst)[12]) {  // grp = sp*NGS + gg (uniform); past the end reads zeros
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) q[d] = wbase[(long)(2 * d) * 32];
-  const float* xprow[MB];
-  float xpv[MB], xpn[MB];
+      for (int i = 0; i < 12; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (grp * 12 + i) * 1024, 0));
+    };
+    fetch_group(0, bb[0]);
+    const float* xprow[MB];
+    float xph[MB][4], xpn[MB][4];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    xprow[mb] = xpT + mq[mb] * xps;
-    xpv[mb] = xprow[mb][0];
-    xpn[mb] = 0.f;
-  }
-#pragma unroll 1
-  for (int h = 0; h < Hp; ++h) {
-    const bool more = h + 1 < Hp;
+    for (int mb = 0; mb < MB; ++mb) {
+      xprow[mb] = xpT + mq[mb] * xps;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-      if (more) xpn[mb] = xprow[mb][h + 1];
-    if constexpr (SYM) load_x(more ? h + 1 : h, xn);
-    const float4* wh = wbase + (long)h * (2 * JT) * 32;
-    const float4* whn = wbase + (long)(more ? h + 1 : h) * (2 * JT) * 32;
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const float4 w = q[j % DEPTH];
-      const int jn = j + DEPTH;  // refill this slot with the operand of step j + DEPTH (possibly in the next h)
-      q[j % DEPTH] = jn < JT ? wh[(long)(2 * jn) * 32] : whn[(long)(2 * (jn - JT)) * 32];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const float a = xpv[mb] * xr[mb][j];
-        acc[mb][0] = mfma32(a, w.x, acc[mb][0]);
-        acc[mb][1] = mfma32(a, w.y, acc[mb][1]);
-        acc[mb][2] = mfma32(a, w.z, acc[mb][2]);
-        acc[mb][3] = mfma32(a, w.w, acc[mb][3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the refill load here (the scheduler would sink it to its use)
+      for (int u = 0; u < 4; ++u) xph[mb][u] = u < Hp ? xprow[mb][u] : 0.f;
     }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) xpv[mb] = xpn[mb];
-    if constexpr (SYM) {
+#pragma unroll 1
+    for (int sp = 0; sp < nsp; ++sp) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) xr[mb][j] = xn[mb][j];
+        for (int u = 0; u < 4; ++u) xpn[mb][u] = 4 * (sp + 1) + u < Hp ? xprow[mb][4 * (sp + 1) + u] : 0.f;
+#pragma unroll
+      for (int gg = 0; gg < NGS; ++gg) {
+        fetch_group(sp * NGS + gg + 1, bb[(gg + 1) & 1]);
+        bf16x8 b[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bb[gg & 1][pl * 4 + nb]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          float p[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int st = 8 * gg + e;  // compile-time
+            p[e] = xph[mb][st / JT] * xr[mb][st % JT];
+          }
+          bf16x8 a[3];
+          split3(p, a[0], a[1], a[2]);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma_split(a, b[nb], acc[mb][nb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xph[mb][u] = xpn[mb][u];
+    }
+  } else {
+  const float4* wbase = reinterpret_cast<const float4*>(Wf + (long)chunk * Hp * (2 * JT) * 128) + (half * 32 + r);
+    float4 q[DEPTH];
+  #pragma unroll
+    for (int d = 0; d < DEPTH; ++d) q[d] = wbase[(long)(2 * d) * 32];
+    const float* xprow[MB];
+    float xpv[MB], xpn[MB];
+  #pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      xprow[mb] = xpT + mq[mb] * xps;
+      xpv[mb] = xprow[mb][0];
+      xpn[mb] = 0.f;
+    }
+  #pragma unroll 1
+    for (int h = 0; h < Hp; ++h) {
+      const bool more = h + 1 < Hp;
+  #pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        if (more) xpn[mb] = xprow[mb][h + 1];
+      if constexpr (SYM) load_x(more ? h + 1 : h, xn);
+      const float4* wh = wbase + (long)h * (2 * JT) * 32;
+      const float4* whn = wbase + (long)(more ? h + 1 : h) * (2 * JT) * 32;
+  #pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const float4 w = q[j % DEPTH];
+        const int jn = j + DEPTH;  // refill this slot with the operand of step j + DEPTH (possibly in the next h)
+        q[j % DEPTH] = jn < JT ? wh[(long)(2 * jn) * 32] : whn[(long)(2 * (jn - JT)) * 32];
+  #pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float a = xpv[mb] * xr[mb][j];
+          acc[mb][0] = mfma32(a, w.x, acc[mb][0]);
+          acc[mb][1] = mfma32(a, w.y, acc[mb][1]);
+          acc[mb][2] = mfma32(a, w.z, acc[mb][2]);
+          acc[mb][3] = mfma32(a, w.w, acc[mb][3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill load here (the scheduler would sink it to its use)
+      }
+  #pragma unroll
+      for (int mb = 0; mb < MB; ++mb) xpv[mb] = xpn[mb];
+      if constexpr (SYM) {
+  #pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+  #pragma unroll
+          for (int j = 0; j < JT; ++j) xr[mb][j] = xn[mb][j];
+      }
     }
   }
 

@@ -16,7 +16,11 @@ void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float*
 // wsn != nullptr: also sum-pool the next (last, mode 0) layer in the epilogue -> pool_next (see cin_fwd3_kernel)
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
                      const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H,
-                     const float* wsn = nullptr, const float* bias_next = nullptr, int H_next = 0, float* pool_next = nullptr);
+                     const float* wsn = nullptr, const float* bias_next = nullptr, int H_next = 0, float* pool_next = nullptr,
+                     bool split = false);
+
+// floats of the split-bf16 forward weight buffer (cin_pack_wb_kernel layout) of one layer
+inline size_t cin_wb_floats(int Hp, int JT, int chunks) { return (size_t)chunks * ((Hp + 3) / 4) * (JT / 2) * 12 * 256; }
 
 void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
                     const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,

@@ -31,6 +31,35 @@ def check(name, got, want, tol=TOL):
     assert np.isfinite(e) and e <= tol, "%s: rel err %.3e > %.1e" % (name, e, tol)
 
 
+@pytest.mark.parametrize("B,F,K,conv", [(64, 39, 16, [128, 128, 128]), (9, 5, 8, [6, 7]), (16, 26, 16, [200, 200]), (130, 39, 16, [32, 64]),
+                                        (33, 38, 16, [64, 48, 8]), (7, 6, 5, [40, 33])])
+@pytest.mark.parametrize("mode", [2, 3])
+def test_cin_split_bf16_forward(B, F, K, conv, mode):
+    """Opt-in mode bit 1 (FIL_CIN_SPLIT_BF16): the general layers' forward GEMMs on split-bf16 operands (three bf16
+    pieces per fp32 value, six bf16 MFMAs per product, fp32 accumulation).  Bar of this labelled mode: 1e-5 norm-relative
+    to the fp64 oracle, the same bar as the exact-fp32 kernels (observed ~1e-6); gradients (exact-fp32 backward kernels
+    on the split forward's saved maps) 2e-5."""
+    from ml_function_amd import functional as Fn
+    c = synth.cin_case(B, F, K, conv, dist="uniform")
+    c["x"] = (c["x"] * 10).astype(np.float32)
+    x = dev(c["x"]).requires_grad_()
+    Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+    bs = [dev(b).requires_grad_() for b in c["bs"]]
+    dw, db = dev(c["dense_w"]).requires_grad_(), dev(c["dense_b"]).requires_grad_()
+    out = Fn.cin(x, Ws, bs, dw, db, output_dim=1, mode=mode)
+    want = closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"], 1)
+    check("cin split out", out, want, tol=1e-5)
+    # layers that go through a general forward GEMM: all but the (pair-symmetric) first and, in mode 2, the shortcut last
+    if len(conv) - 1 - (1 if mode == 2 else 0) > 0:
+        out_exact = Fn.cin(x, Ws, bs, dw, db, output_dim=1, mode=mode & 1)
+        assert not torch.equal(out.detach(), out_exact.detach()), "mode bit 1 must select the split kernels"
+    out.backward(dev(c["g"]))
+    dx, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"], 1)
+    check("cin split dx", x.grad, dx, tol=2e-5)
+    for l in range(len(conv)):
+        check("cin split dW%d" % l, Ws[l].grad, dWs[l], tol=2e-5)
+
+
 def test_cin_large_batch_rows_beyond_2_pow_21():
     """B*K = 2.4 M rows (the dW kernel's buffer descriptors used to span the whole tensor: 2^21 rows at most).
     Size-independent checks: the first samples equal a small run bit for bit (batch independence), and the weight
