@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     const long chunk_bytes = (long)nsp * NGS * 12 * 1024;
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wf) + (long)chunk * (chunk_bytes >> 2), 0, (int)chunk_bytes, 0x00020000);
+    // B planes: a register double buffer per wave, fetched one group ahead with scalar-offset buffer loads.  (Sharing
+    // them between the 4 waves through LDS-DMA + one barrier per group was tried: same speed, so the L2 stream is not
+    // what holds this loop at ~60 % of the bf16 pipe.)
     const int vo = lane * 16;
     u32x4 bb[2][12];
     auto fetch_group = [&](int grp, u32x4 (&dst)[12]) {  // grp = sp*NGS + gg (uniform); past the end reads zeros
@@ -297,6 +300,21 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
       for (int u = 0; u < 4; ++u) xph[mb][u] = u < Hp ? xprow[mb][u] : 0.f;
     }
+    // A operand of unit (gg, mb): the 8 products x^{l-1}[m,h] * x[m,f] of the group's steps, split into three bf16 planes
+    auto make_a = [&](const float (&xp4)[MB][4], int gg, int mb, bf16x8 (&a)[3]) {
+      float p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int st = 8 * gg + e;  // compile-time
+        p[e] = xp4[mb][st / JT] * xr[mb][st % JT];
+      }
+      split3(p, a[0], a[1], a[2]);
+    };
+    // Software pipeline over the units (gg, mb): the split of the NEXT unit's A operand is issued alongside the 24 MFMAs
+    // of the current one (bf16 MFMAs run on their own pipe; VALU issued between them is hidden, VALU issued in a
+    // block is not), the B planes of the next group are fetched one group ahead.
+    bf16x8 acur[3], anext[3];
+    make_a(xph, 0, 0, acur);
 #pragma unroll 1
     for (int sp = 0; sp < nsp; ++sp) {
 #pragma unroll
@@ -306,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
       for (int gg = 0; gg < NGS; ++gg) {
         fetch_group(sp * NGS + gg + 1, bb[(gg + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the fetch here (the scheduler would sink it to its use)
         bf16x8 b[4][3];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -313,18 +332,20 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
           for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bb[gg & 1][pl * 4 + nb]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          float p[8];
+          if (mb + 1 < MB) make_a(xph, gg, mb + 1, anext);
+          else if (gg + 1 < NGS) make_a(xph, gg + 1, 0, anext);
+          else make_a(xpn, 0, 0, anext);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int st = 8 * gg + e;  // compile-time
-            p[e] = xph[mb][st / JT] * xr[mb][st % JT];
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma_split(acur, b[nb], acc[mb][nb]);
+#pragma unroll
+          for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU behind it
           }
-          bf16x8 a[3];
-          split3(p, a[0], a[1], a[2]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma_split(a, b[nb], acc[mb][nb]);
+          for (int pl = 0; pl < 3; ++pl) acur[pl] = anext[pl];
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
