@@ -181,6 +181,8 @@ static size_t dw_part_floats(const CinShape& s) {
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
   return pmax;
 }
+// bytes of G as three bf16 planes in row blocks of 16 (cin_split_g_kernel)
+static size_t gb_bytes(const CinShape& s) { return (size_t)((s.M() + 15) / 16) * (s.HSmax() / 128) * 12 * 1024; }
 static size_t bwd_ws_bytes(const CinShape& s) {
   const size_t LK = (size_t)s.L * s.K;
   const size_t M = (size_t)s.M();
@@ -195,6 +197,7 @@ static size_t bwd_ws_bytes(const CinShape& s) {
   t += 2 * align_up(cl * sizeof(float), 256);                            // wsum, v of the last layer
   t += align_up(wz_floats(s) * sizeof(float), 256);                      // packed W (slot order)
   t += 2 * align_up(M * s.F * sizeof(float), 256);                       // dxT, Gx^0
+  t += align_up(gb_bytes(s), 256);                                       // split-bf16 planes of G (mode bit 1)
   return t;
 }
 
@@ -332,8 +335,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
   if (mode < 0 || mode > 3) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bit 0: general kernels for every layer; bit 1: split-bf16 GEMMs)", mode);
-  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (this round: forward kernels only; the backward GEMMs stay exact fp32)
-  (void)split;
+  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (this round: forward and dW GEMMs; dZ stays exact fp32)
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
   hipStream_t st = (hipStream_t)stream;
@@ -370,6 +372,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   float* Wz = ws.take<float>(wz_floats(s));
   float* dxT = ws.take<float>((size_t)M * F);
   float* gx0T = ws.take<float>((size_t)M * F);
+  bf16x8* Gb = reinterpret_cast<bf16x8*>(ws.take<char>(gb_bytes(s)));
 
   // saved tensors
   Carver sv(const_cast<float*>(saved));
@@ -461,7 +464,18 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const int Cl = symD > 0 ? F * symD : Hp * F;
     {
       ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl));
-      parts = launch_dw3(st, dw_plan(M, Cl, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl, symD);
+      if (split && symD == 0) {
+        // opt-in split-bf16 GEMM: G re-laid as three bf16 planes (inside the scope: it is part of this GEMM's cost)
+        const long nvec = ((M + 15) / 16) * (HSl / 128) * 12 * 64;
+        hipLaunchKernelGGL(cin_split_g_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 8192)), dim3(256), 0, st, G, HSl, Gb, (int)M, Hl);
+        const DwPlan p = dw_plan(M, Cl, Hl);
+        const int items = p.blocks_x * p.splits * p.chunks;
+        hipLaunchKernelGGL(cin_dw3b_kernel, dim3((items + 7) / 8 * 8), dim3(kCinThreads), 0, st, Gb, xT, xpT, xps, part, (int)M, F, Hp, Hl,
+                           p.rows_per_split, p.blocks_x, p.chunks, items);
+        parts = p.splits;
+      } else {
+        parts = launch_dw3(st, dw_plan(M, Cl, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl, symD);
+      }
     }
     FIL_CHECK_LAUNCH();
     const long nW = (long)Cl * Hl;

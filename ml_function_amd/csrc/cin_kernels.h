@@ -864,6 +864,146 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   }
 }
 
+// ---- split-bf16 dW (opt-in, general layers; see the split-bf16 notes above the forward kernel) ---------------------
+// Gb = G as three bf16 planes in the B-operand layout of v_mfma_f32_32x32x16_bf16 with the reduction over rows:
+// [chunk][row block of 16][plane][nb][lane 64][8 bf16]; element e of lane (r, half) = G[16*blk + 8*half + e][chunk*128 + 4r + nb].
+static __global__ __launch_bounds__(256) void cin_split_g_kernel(const float* __restrict__ gT, int HS, bf16x8* __restrict__ Gb, int M, int H) {
+  const int chunks = HS >> 7;
+  const long nblk = ((long)M + 15) >> 4;
+  const long total = (long)chunks * nblk * 12 * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long t = idx >> 6;
+    const int nb = (int)(t & 3);
+    t >>= 2;
+    const int plane = (int)(t % 3);
+    t /= 3;
+    const long blk = t % nblk;
+    const int chunk = (int)(t / nblk);
+    const int r = lane & 31, half = lane >> 5;
+    const int n = chunk * 128 + 4 * r + nb;
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long m = blk * 16 + 8 * half + e;
+      const float g = (m < M && n < H) ? gT[m * HS + n] : 0.f;
+      const __bf16 h1 = (__bf16)g;
+      const float r1 = g - (float)h1;
+      const __bf16 h2 = (__bf16)r1;
+      const __bf16 h3 = (__bf16)(r1 - (float)h2);
+      out[e] = plane == 0 ? h1 : (plane == 1 ? h2 : h3);
+    }
+    Gb[idx] = out;
+  }
+}
+
+// dW[c,n] = sum_m Z[m,c] G[m,n] on split-bf16 operands.  Wave = 32 channel rows x one 128-column chunk over one row split
+// (same work mapping as cin_dw3_kernel).  Per block of 16 rows: lane (c = r, half) gathers x^{l-1}[m,h_c] and x[m,f_c] of
+// its 8 rows m = 16 blk + 8 half + e, multiplies, splits the 8 products into three bf16 planes (one block ahead of
+// their MFMAs), and reads the 12 plane vectors of Gb (fetched one block ahead): 24 bf16 MFMAs per block.
+static __global__ __launch_bounds__(256, 2) void cin_dw3b_kernel(const bf16x8* __restrict__ Gb, const float* __restrict__ xT,
+                                                           const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
+                                                           int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int C = Hp * F;
+  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware, as in cin_dw3_kernel
+  if (item >= items) return;
+  const int bx = item % blocks_x;
+  const int chunk = (item / blocks_x) % chunks;
+  const int split = item / (blocks_x * chunks);
+  const int c0 = (bx * 4 + wave) * 32;
+  if (c0 >= C) return;
+  const int m_lo = split * rows_per_split;          // a multiple of 16
+  const int m_hi = min(M, m_lo + rows_per_split);
+  const int nkb = (m_hi - m_lo + 15) >> 4;          // row blocks of this split
+  const long mrem = (long)M - m_lo;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xT + (long)m_lo * F, mrem * F * 4);
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(xpT + (long)m_lo * xps, mrem * xps * 4);
+  const long nblk = ((long)M + 15) >> 4;
+  const bf16x8* gbase = Gb + ((long)chunk * nblk + (m_lo >> 4)) * 12 * 64;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(gbase), 0, (int)std::min<long>((long)nkb * 12 * 1024, 0x7fffffffL), 0x00020000);
+  const int c = c0 + r;
+  const bool cv = c < C;
+  const int cc = cv ? c : C - 1;
+  const int hh = cc / F, ff = cc - hh * F;
+  const int ho = (8 * half * xps + hh) * 4, fo = (8 * half * F + ff) * 4;  // byte offsets of the lane's first row inside a block
+  const int vo = lane * 16;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  float xq[2][8], pq[2][8];
+  u32x4 bq[2][12];
+  auto fetch = [&](int kb, int buf) {  // kb uniform; rows past the tensor / blocks past the split's planes read zeros
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xq[buf][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, fo, (kb * 16 + e) * F * 4, 0));
+      pq[buf][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ho, (kb * 16 + e) * xps * 4, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) bq[buf][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, (kb * 12 + i) * 1024, 0));
+  };
+  auto make_a = [&](int kb, int buf, bf16x8 (&a)[3]) {
+    float p[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool live = cv && m_lo + kb * 16 + 8 * half + e < m_hi;
+      p[e] = live ? xq[buf][e] * pq[buf][e] : 0.f;
+    }
+    split3(p, a[0], a[1], a[2]);
+  };
+  bf16x8 acur[3], anext[3];
+  fetch(0, 0);
+  fetch(1, 1);
+  make_a(0, 0, acur);
+  // two blocks per iteration so that the double buffers are indexed at compile time
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; kb += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 b[4][3];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bq[u][pl * 4 + nb]);
+      make_a(kb + u + 1, u ^ 1, anext);   // the next block's operand, issued alongside this block's MFMAs
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma_split(acur, b[nb], acc[nb]);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(kb + u + 2, u);               // refill the buffer this block just released
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) acur[pl] = anext[pl];
+    }
+  }
+  float* pout = part + (long)split * C * H;
+  const bool vec = (H & 3) == 0;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int cr = c0 + mfma32_row(reg, half);
+    if (cr < C) {
+      const int n = chunk * 128 + 4 * r;
+      float* dst = pout + (long)cr * H + n;
+      if (vec && n + 3 < H) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          if (n + nb < H) dst[nb] = acc[nb][reg];
+      }
+    }
+  }
+}
+
 // part[blk][n] = sum over a chunk of rows of gT[m][n]: 16-byte loads, HS/4 threads per row and 256/(HS/4) row groups
 // per workgroup (two rows in flight per thread), the groups folded through LDS in a fixed order.
 static __global__ __launch_bounds__(256) void cin_colsum3_kernel(const float* __restrict__ gT, int HS, float* __restrict__ part, int M, int H,

@@ -34,11 +34,11 @@ def check(name, got, want, tol=TOL):
 @pytest.mark.parametrize("B,F,K,conv", [(64, 39, 16, [128, 128, 128]), (9, 5, 8, [6, 7]), (16, 26, 16, [200, 200]), (130, 39, 16, [32, 64]),
                                         (33, 38, 16, [64, 48, 8]), (7, 6, 5, [40, 33])])
 @pytest.mark.parametrize("mode", [2, 3])
-def test_cin_split_bf16_forward(B, F, K, conv, mode):
-    """Opt-in mode bit 1 (FIL_CIN_SPLIT_BF16): the general layers' forward GEMMs on split-bf16 operands (three bf16
-    pieces per fp32 value, six bf16 MFMAs per product, fp32 accumulation).  Bar of this labelled mode: 1e-5 norm-relative
-    to the fp64 oracle, the same bar as the exact-fp32 kernels (observed ~1e-6); gradients (exact-fp32 backward kernels
-    on the split forward's saved maps) 2e-5."""
+def test_cin_split_bf16_gemms(B, F, K, conv, mode):
+    """Opt-in mode bit 1 (FIL_CIN_SPLIT_BF16): the general layers' forward and dW GEMMs on split-bf16 operands (three
+    bf16 pieces per fp32 value, six bf16 MFMAs per product, fp32 accumulation; dZ stays exact fp32).  Bar of this
+    labelled mode: 1e-5 norm-relative to the fp64 oracle on the outputs, the same bar as the exact-fp32 kernels;
+    gradients 2e-5."""
     from ml_function_amd import functional as Fn
     c = synth.cin_case(B, F, K, conv, dist="uniform")
     c["x"] = (c["x"] * 10).astype(np.float32)

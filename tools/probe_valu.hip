@@ -6,7 +6,8 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum Kind { VALU = 0, VMEM = 1, LDS = 2, SALU = 3, VADDR = 4 };
+enum Kind { VALU = 0, VMEM = 1, LDS = 2, SALU = 3, VADDR = 4, PKFMA = 5, ACCREAD = 6 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KIND, int N>
 __global__ __launch_bounds__(256, 1) void probe(float* out, const float* __restrict__ src, int iters, float seed) {
@@ -20,6 +21,9 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, const float* __restr
   for (int i = 0; i < (N > 0 ? N : 1); ++i) v[i] = seed + i;
   const float a = seed * 0.5f + threadIdx.x, b = seed * 0.25f;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 1 << 20, 0x00020000);
+  f32x2 pk[N > 0 ? N : 1];
+  for (int i = 0; i < (N > 0 ? N : 1); ++i) pk[i] = f32x2{seed + i, seed - i};
+  const f32x2 pka = {a, b}, pkb = {b, a};
   int so = 0;
   unsigned long long vaddr = (unsigned long long)src + threadIdx.x * 4;
   for (int it = 0; it < iters; ++it) {
@@ -33,6 +37,8 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, const float* __restr
         if constexpr (KIND == LDS) v[k] = lds[(threadIdx.x + k * 64 + it) & 4095];
         if constexpr (KIND == SALU) { so = (so * 3 + k) & 0xffff; asm volatile("" : "+s"(so)); }
         if constexpr (KIND == VADDR) { vaddr += 1024; asm volatile("" : "+v"(vaddr)); }
+        if constexpr (KIND == PKFMA) { pk[k] = __builtin_elementwise_fma(pk[k], pkb, pka); }
+        if constexpr (KIND == ACCREAD) { v[k] += acc[(m + 2) & 3][k & 15]; }
       }
     }
     if constexpr (KIND == VMEM) so = (so + 4096) & 0xffff;
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, const float* __restr
   float s = (float)so + (float)(vaddr & 0xff);
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 16; ++j) s += acc[i][j];
-  for (int i = 0; i < (N > 0 ? N : 1); ++i) s += v[i];
+  for (int i = 0; i < (N > 0 ? N : 1); ++i) s += v[i] + pk[i][0] + pk[i][1];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -77,5 +83,8 @@ int main() {
   run<SALU, 8>(d, src, iters, "s_mul/s_add/s_and");
   run<SALU, 32>(d, src, iters, "s_mul/s_add/s_and");
   run<VADDR, 8>(d, src, iters, "64-bit v_add (address math)");
+  run<PKFMA, 8>(d, src, iters, "v_pk_fma_f32");
+  run<PKFMA, 16>(d, src, iters, "v_pk_fma_f32");
+  run<ACCREAD, 8>(d, src, iters, "v_accvgpr_read + v_add");
   return 0;
 }
