@@ -159,7 +159,7 @@ static size_t wz_floats(const CinShape& s) {
   size_t w = ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
   w = std::max(w, (size_t)s.F * (s.F / 2 + 1) * s.H[0]);
   for (int l = 0; l < s.L; ++l) w = std::max(w, ((size_t)dz_periods(s, l) * cin_dz_tiles_per_period(s.JT()) + 1) * 32 * s.HS(l));
-  return w;
+  return w + w / 2;   // the split-bf16 planes (mode bit 1) take 6 bytes per weight instead of 4
 }
 // column chunks a layer's pooled partials may come in: its own, or (last layer pooled by the epilogue of the layer
 // below) that layer's
@@ -335,7 +335,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
   if (mode < 0 || mode > 3) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bit 0: general kernels for every layer; bit 1: split-bf16 GEMMs)", mode);
-  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (this round: forward and dW GEMMs; dZ stays exact fp32)
+  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (general layers l >= 1; the pair-symmetric first layer and the last-layer shortcut stay exact fp32)
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
   hipStream_t st = (hipStream_t)stream;
@@ -507,11 +507,17 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
         const int periods = dz_periods(s, l);
         const int tiles = periods * cin_dz_tiles_per_period(JT) + 1;
         const long npack = (long)tiles * 32 * HSl;
-        hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
+        if (split) {
+          const long nvec = (long)tiles * (HSl / 16) * 3 * 64;
+          hipLaunchKernelGGL(cin_pack_wzb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
+                             reinterpret_cast<bf16x8*>(Wz), Hp, F, Hl, JT, HSl, tiles);
+        } else {
+          hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
+        }
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
         cin_launch_dz3(st, MB, JT, NHMAX, dim3(cdiv((int)M, 128 * MB)), G, HSl, Wz, xT, xpT, xps, dPprev, (int)LK, K,
                        l > 0 ? Gbuf[cur ^ 1] : nullptr, l > 0 ? s.HS(l - 1) : 0, l == 0 ? gx0T : nullptr, dxT, dx_started ? 1 : 0,
-                       (int)M, F, Hp, Hl, periods);
+                       (int)M, F, Hp, Hl, periods, split);
       }
       dx_started = true;
       if (l == 0) have_gx0 = true;

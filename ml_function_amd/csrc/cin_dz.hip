@@ -4,27 +4,28 @@
 
 namespace fil {
 
-template <int MB, int JT, int NHMAX>
+template <int MB, int JT, int NHMAX, bool SPLIT>
 static void dz3(hipStream_t st, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT, const float* xpT, int xps,
                 const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT, int accumulate, int M, int F,
                 int Hp, int H, int periods) {
   // per-lane LDS scratch: x fragment + dX accumulators, [2][MB][JT][256] floats
   const size_t sh = (size_t)2 * MB * JT * 256 * sizeof(float);
   if (sh > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_dz3_kernel<MB, JT, NHMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  hipLaunchKernelGGL((cin_dz3_kernel<MB, JT, NHMAX>), grid, dim3(kCinThreads), sh, st, gT, HS, Wz, xT, xpT, xps, dPprev, ldp, K, GprevT,
-                     HSp, gx0T, dxT, accumulate, M, F, Hp, H, periods, 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_dz3_kernel<MB, JT, NHMAX, false, SPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL((cin_dz3_kernel<MB, JT, NHMAX, false, SPLIT>), grid, dim3(kCinThreads), sh, st, gT, HS, Wz, xT, xpT, xps, dPprev, ldp, K,
+                     GprevT, HSp, gx0T, dxT, accumulate, M, F, Hp, H, periods, 0);
 }
 
 void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
                     const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,
-                    int accumulate, int M, int F, int Hp, int H, int periods) {
+                    int accumulate, int M, int F, int Hp, int H, int periods, bool split) {
 #define FIL_ARGS st, grid, gT, HS, Wz, xT, xpT, xps, dPprev, ldp, K, GprevT, HSp, gx0T, dxT, accumulate, M, F, Hp, H, periods
-#define FIL_Z3(JTV)                                    \
-  case JTV:                                            \
-    if (NHMAX == 128) dz3<1, JTV, 128>(FIL_ARGS);      \
-    else if (MB == 2) dz3<2, JTV, 64>(FIL_ARGS);       \
-    else dz3<1, JTV, 64>(FIL_ARGS);                    \
+#define FIL_Z3(JTV)                                                                                 \
+  case JTV:                                                                                         \
+    if (NHMAX == 128) { if (split) dz3<1, JTV, 128, true>(FIL_ARGS); else dz3<1, JTV, 128, false>(FIL_ARGS); } \
+    else if (MB == 2) { if (split) dz3<2, JTV, 64, true>(FIL_ARGS); else dz3<2, JTV, 64, false>(FIL_ARGS); }   \
+    else { if (split) dz3<1, JTV, 64, true>(FIL_ARGS); else dz3<1, JTV, 64, false>(FIL_ARGS); }                \
     break;
   switch (JT) { FIL_Z3(4) FIL_Z3(8) FIL_Z3(12) FIL_Z3(16) FIL_Z3(20) FIL_Z3(24) FIL_Z3(28) FIL_Z3(32) }
 #undef FIL_Z3

@@ -516,6 +516,39 @@ static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float
   }
 }
 
+// Split-bf16 form of Wz: [(tile*NT + t)*3 + plane][lane 64][8 bf16], NT = NCOL/16.  Element e of lane (r, half) is the
+// plane of Wz[tile][row r][col = half*NCOL/2 + 8t + e] (rows and columns as in cin_pack_wz_kernel).
+static __global__ __launch_bounds__(256) void cin_pack_wzb_kernel(const float* __restrict__ W, bf16x8* __restrict__ Wzb, int Hp, int F, int H,
+                                                           int JT, int NCOL, int tiles) {
+  const int NT = NCOL / 16;
+  const long total = (long)tiles * NT * 3 * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    long u = idx >> 6;
+    const int plane = (int)(u % 3);
+    u /= 3;
+    const int t = (int)(u % NT);
+    const long tile = u / NT;
+    const int i = lane & 31, half = lane >> 5;
+    const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
+    const long slot = 16 * tile + rr;
+    const int h = (int)(slot / JT), j = (int)(slot - (long)h * JT);
+    const int f = 2 * j + hf;
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = half * (NCOL / 2) + 8 * t + e;
+      const float w = (h < Hp && f < F && col < H) ? W[((long)h * F + f) * H + col] : 0.f;
+      const __bf16 h1 = (__bf16)w;
+      const float r1 = w - (float)h1;
+      const __bf16 h2 = (__bf16)r1;
+      const __bf16 h3 = (__bf16)(r1 - (float)h2);
+      out[e] = plane == 0 ? h1 : (plane == 1 ? h2 : h3);
+    }
+    Wzb[idx] = out;
+  }
+}
+
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
 // Backward data path, streaming form.  Wave = 32*MB rows m (on the lanes).  dZ^T tile = Wz tile (32 slot rows,
@@ -533,7 +566,11 @@ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 //   gx      += dZ * x[m,f]  -> Gx[m,h]  (gx0T)        dxs[f] += dZ * x[m,h]  -> dX[m,f]   (summed by transpose_out)
 constexpr int kSymStride = 160;  // 4 waves x 32 rows + 32: consecutive f land in opposite bank halves
 
-template <int MB, int JT, int NHMAX, bool SYM = false>
+//
+// SPLIT (opt-in, general layers): dZ^T = W G^T on split-bf16 operands -- Wz then points to the three bf16 planes of the
+// slot-ordered weights (cin_pack_wzb_kernel), the lane's G row is split once into planes, and a tile is NHMAX/8 steps
+// of 6 bf16 MFMAs per row block (accumulator layout, slot order and the register contraction are unchanged).
+template <int MB, int JT, int NHMAX, bool SYM = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
                                                          const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                          const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
@@ -585,9 +622,34 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   if constexpr (SYM) __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
   const float4* wz = reinterpret_cast<const float4*>(Wz) + ((long)r * NCOL + half * NHMAX) / 4;
   constexpr long kTileStride = 32L * NCOL / 4;  // float4 per tile
-  float4 q[NQ];
+  constexpr int NT = NHMAX / 8;            // SPLIT: steps (of 16 reduction columns: 8 per wave half) per tile
+  constexpr int QD = 4;                    // SPLIT: A-operand queue depth in steps (divides NT)
+  constexpr int SPS = 16 / NT;             // SPLIT: contraction slots per step
+  float4 q[SPLIT ? 1 : NQ];
+  bf16x8 gpl[SPLIT ? MB : 1][SPLIT ? NT : 1][3];
+  u32x4 aq[SPLIT ? QD : 1][3];
+  const __amdgpu_buffer_rsrc_t rwz = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(Wz), 0, SPLIT ? (int)std::min<long>(((long)periods * P + 1) * NT * 3 * 1024, 0x7fffffffL) : 0, 0x00020000);
+  auto fetch_a = [&](int gs, u32x4 (&dst)[3]) {  // gs = global step = tile * NT + t (uniform)
 #pragma unroll
-  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[s4];
+    for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwz, lane * 16, (gs * 3 + pl) * 1024, 0));
+  };
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float p8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p8[e] = greg[mb][8 * t + e];
+        split3(p8, gpl[mb][t][0], gpl[mb][t][1], gpl[mb][t][2]);
+      }
+#pragma unroll
+    for (int t = 0; t < QD; ++t) fetch_a(t, aq[t]);
+  } else {
+#pragma unroll
+    for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[s4];
+  }
   float gx[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) gx[mb] = 0.f;
@@ -681,6 +743,31 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) d[mb][i] = 0.f;
+      if constexpr (SPLIT) {
+        const int gs0 = (per * P + tp) * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          bf16x8 a[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, aq[t % QD][pl]);
+          fetch_a(gs0 + t + QD, aq[t % QD]);   // (the stream is allocated one tile past the last one)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) d[mb] = mfma_split(a, gpl[mb][t], d[mb]);
+#pragma unroll
+          for (int qs = 0; qs < SPS; ++qs) {
+            const int sl = t * SPS + qs;   // previous tile's slot contracted behind this step
+            if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, sl);
+            else slot_apply(dprev, xcur, hbase, tp - 1, sl);
+            if (sl < 15) {
+              if (tp == 0) slot_fetch(hprev, P - 1, sl + 1);
+              else slot_fetch(hbase, tp - 1, sl + 1);
+            } else {
+              slot_fetch(hbase, tp, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int s4 = 0; s4 < NQ; ++s4) {
         const float4 w = q[s4];
@@ -704,6 +791,7 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) dprev[mb] = d[mb];

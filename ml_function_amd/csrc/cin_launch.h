@@ -24,7 +24,7 @@ inline size_t cin_wb_floats(int Hp, int JT, int chunks) { return (size_t)chunks 
 
 void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
                     const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,
-                    int accumulate, int M, int F, int Hp, int H, int periods);
+                    int accumulate, int M, int F, int Hp, int H, int periods, bool split = false);
 
 // MFMA data gradients of the last layer in mode 0 (L >= 2): see cin_last_bwd2_kernel
 void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn,
