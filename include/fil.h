@@ -86,9 +86,10 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) with the last layer contracted against
  *             sum_n W_L[c,n] (its feature map is only ever sum-pooled, so this is the same function at 1/H_L of the flops);
  *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
- *         + FIL_CIN_SPLIT_BF16 (2), opt-in and experimental: the forward GEMMs of the general layers l >= 1 run on
- *             split-bf16 operands (every fp32 value as three bf16 pieces, six bf16 MFMAs with fp32 accumulation per
- *             product: fp32-equivalent to ~1e-6, not the exact-fp32 chain of modes 0/1); backward unchanged.
+ *         + FIL_CIN_SPLIT_BF16 (2), opt-in and experimental: the three GEMMs (forward, dW, dZ) of the general layers
+ *             l >= 1 run on split-bf16 operands (every fp32 value as three bf16 pieces, six bf16 MFMAs with fp32
+ *             accumulation per product: the same measured error as modes 0/1, but not their exact-fp32 FMA chain);
+ *             the pair-symmetric first layer and the last-layer shortcut stay exact fp32.
  *   Limits: F <= 64, H_l <= 256, L <= 8, L*K <= 255, B*K <= 2^28.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);

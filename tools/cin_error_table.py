@@ -1,0 +1,21 @@
+"""Norm-relative / max-relative error of the CIN outputs and gradients against the fp64 oracle, for the exact-fp32
+modes (0, 1) and the split-bf16 modes (2, 3):  python tools/cin_error_table.py   (GPU)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ml_function_amd import synth, functional as Fn
+from oracle import closed
+def rel(a,b):
+    a=a.detach().cpu().double().numpy().ravel(); b=np.asarray(b,dtype=np.float64).ravel()
+    return float(np.linalg.norm(a-b)/np.linalg.norm(b)), float(np.abs(a-b).max()/np.abs(b).max())
+for dist in ["uniform","normal"]:
+    c=synth.cin_case(256,39,16,[128,128,128],dist=dist)
+    if dist=="uniform": c["x"]=(c["x"]*10).astype(np.float32)
+    want=closed.cin_fwd(c["x"],c["Ws"],c["bs"],c["dense_w"],c["dense_b"],1)
+    dx,dWs,dbs,ddw,ddb=closed.cin_bwd(c["x"],c["Ws"],c["bs"],c["dense_w"],c["g"],1)
+    for mode in [0,2,1,3]:
+        dev=lambda a: torch.tensor(a,dtype=torch.float32,device="cuda")
+        x=dev(c["x"]).requires_grad_(); Ws=[dev(w).requires_grad_() for w in c["Ws"]]; bs=[dev(b).requires_grad_() for b in c["bs"]]
+        dw,db=dev(c["dense_w"]).requires_grad_(),dev(c["dense_b"]).requires_grad_()
+        out=Fn.cin(x,Ws,bs,dw,db,output_dim=1,mode=mode); out.backward(dev(c["g"]))
+        print(dist,"mode",mode,"out %.2e/%.2e"%rel(out,want),"dx %.2e/%.2e"%rel(x.grad,dx)," ".join("dW%d %.2e/%.2e"%((l,)+rel(Ws[l].grad,dWs[l])) for l in range(3)))
