@@ -134,6 +134,26 @@ def side_benchmark(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()
+    graph_ms = None
+    if args.graph:
+        # the launch-bound shapes (FM / DCN at their BASELINE batch sizes): the same step captured once into a HIP graph
+        # (torch.cuda.CUDAGraph; the C ABI neither allocates nor synchronises) and replayed
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            step()
+        for _ in range(args.warmup):
+            gr.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gr.replay()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
     ks = {k: v for k, v in prof.items() if k in kernels}
     dom = max(ks, key=lambda k: ks[k]["total_ms"])
     d = ks[dom]
@@ -149,7 +169,8 @@ def side_benchmark(args):
         "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                      "traffic": None, "avg_launch_ms": d["avg_ms"]},
         "kernels": {k: dict(avg_ms=round(v["avg_ms"], 4), work=v["work"]) for k, v in sorted(ks.items())},
-        "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps}))
+        "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps,
+        "hipgraph_replay_ms_per_step": graph_ms}))
 
 
 def pmc_traffic(scope):
@@ -182,6 +203,7 @@ def main():
     ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint"],
                     help="cin = the headline benchmark (default); the others are single-GPU side benchmarks of the "
                          "remaining hot-path rows (BASELINE.json configs 2, 3, 5)")
+    ap.add_argument("--graph", action="store_true", help="side benchmarks: also time the step replayed from a HIP graph")
     ap.add_argument("--cin-mode", type=int, default=0, help="fil_cin mode bits (experiments; the headline is mode 0)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16_mfma"], help="AutoInt side benchmark only")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
