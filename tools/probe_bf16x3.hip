@@ -6,7 +6,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NV>
+template <int NV, int CHAIN = 1>
 __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, float seed) {
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i)
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, float see
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 24; ++m) {
-      acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m & 3], 0, 0, 0);
+      acc[(m / CHAIN) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[(m / CHAIN) & 3], 0, 0, 0);  // CHAIN consecutive MFMAs share an accumulator
 #pragma unroll
       for (int k = m * NV / 24; k < (m + 1) * NV / 24; ++k) v[k] = __builtin_fmaf(v[k], fb, fa);
     }
@@ -32,21 +32,21 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, float see
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NV>
+template <int NV, int CHAIN = 1>
 static void run(float* d, int iters) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  probe<NV><<<256, 256>>>(d, iters, 1.0f);
+  probe<NV, CHAIN><<<256, 256>>>(d, iters, 1.0f);
   hipEventRecord(e0);
-  probe<NV><<<256, 256>>>(d, iters, 1.0f);
+  probe<NV, CHAIN><<<256, 256>>>(d, iters, 1.0f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   // one iteration replaces 32 f32 MFMAs (4096 flop each per SIMD-wave) of the exact-fp32 kernels
   const double equiv = 256.0 * 4 * 32.0 * iters * 4096.0 / (ms * 1e-3) / 1e12;
-  printf("VALU per 24 bf16 MFMA: %3d   %.1f ns per group   fp32-equivalent %.0f TFLOP/s   (bf16 executed %.0f TFLOP/s)\n", NV,
+  printf("chain %d  VALU per 24 bf16 MFMA: %3d   %.1f ns per group   fp32-equivalent %.0f TFLOP/s   (bf16 executed %.0f TFLOP/s)\n", CHAIN, NV,
          ms * 1e6 / iters, equiv, 256.0 * 4 * 24.0 * iters * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
@@ -60,5 +60,8 @@ int main() {
   run<72>(d, iters);
   run<96>(d, iters);
   run<144>(d, iters);
+  run<0, 6>(d, iters);
+  run<48, 6>(d, iters);
+  run<0, 24>(d, iters);
   return 0;
 }
