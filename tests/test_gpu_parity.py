@@ -58,6 +58,13 @@ def test_cin_split_bf16_gemms(B, F, K, conv, mode):
     check("cin split dx", x.grad, dx, tol=2e-5)
     for l in range(len(conv)):
         check("cin split dW%d" % l, Ws[l].grad, dWs[l], tol=2e-5)
+    # deterministic like the exact kernels: a second run is bit-identical (no atomics, fixed reduction orders)
+    x2 = dev(c["x"]).requires_grad_()
+    W2 = [dev(w).requires_grad_() for w in c["Ws"]]
+    out2 = Fn.cin(x2, W2, bs, dw, db, output_dim=1, mode=mode)
+    out2.backward(dev(c["g"]))
+    assert torch.equal(out2.detach(), out.detach()) and torch.equal(x2.grad, x.grad)
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(W2, Ws))
 
 
 def test_cin_large_batch_rows_beyond_2_pow_21():
