@@ -492,7 +492,10 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     // dZ -> G^{l-1}, dX
     {
       const int NHMAX = HSl / 2;                  // 64 (H <= 128) or 128
-      const int MB = NHMAX == 128 ? 1 : mb_rows(M);
+      const int MB = NHMAX == 128 ? 1 : mb_rows(M);      // pair-symmetric first layer: 64 rows per wave measured best
+      // general dZ kernel: 32 rows per wave, two waves per SIMD -- the second wave covers the issue time of the first
+      // one's register contraction (c4: 0.715 -> 0.687 ms exact fp32, 0.436 -> 0.420 split-bf16); FIL_CIN_DZ_MB overrides
+      const int MBg = NHMAX == 128 ? 1 : (env_int("FIL_CIN_DZ_MB", 1) == 2 ? 2 : 1);
       const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
       if (l == 0 && sym_first_layer() && F >= 2) {
         // first layer over unordered field pairs (half the tiles); F = 1 would make both lane halves hit one word
@@ -515,7 +518,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
           hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
         }
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
-        cin_launch_dz3(st, MB, JT, NHMAX, dim3(cdiv((int)M, 128 * MB)), G, HSl, Wz, xT, xpT, xps, dPprev, (int)LK, K,
+        cin_launch_dz3(st, MBg, JT, NHMAX, dim3(cdiv((int)M, 128 * MBg)), G, HSl, Wz, xT, xpT, xps, dPprev, (int)LK, K,
                        l > 0 ? Gbuf[cur ^ 1] : nullptr, l > 0 ? s.HS(l - 1) : 0, l == 0 ? gx0T : nullptr, dxT, dx_started ? 1 : 0,
                        (int)M, F, Hp, Hl, periods, split);
       }
