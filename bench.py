@@ -186,7 +186,9 @@ def pmc_traffic(scope):
     prefix = {"fwd": "cin_fwd3_kernel", "bwd_dz": "cin_dz3_kernel", "bwd_dw": "cin_dw3_kernel<1,false"}[m.group(1)]
     with open(files[-1]) as fh:
         per = json.load(fh)["per_launch"]
-    hits = sorted((v["first_dispatch"], v["hbm_bytes"]) for k, v in per.items() if k.startswith(prefix))
+    # (template instantiations whose last argument is SPLIT = true belong to the split-bf16 experiment, not to the headline)
+    hits = sorted((v["first_dispatch"], v["hbm_bytes"]) for k, v in per.items()
+                  if k.startswith(prefix) and not k.split(" grid=")[0].endswith(",true>"))
     if len(hits) != 2:
         return None
     # two MFMA layers (l = 1, 2): the forward visits l1 then l2, the backward l2 then l1
