@@ -1199,9 +1199,17 @@ static __global__ __launch_bounds__(256) void cin_slice_sum_kernel(const float* 
 
 // dbias[n] = sum_p part[p] for every n < H
 static __global__ __launch_bounds__(256) void cin_fill_sum_kernel(const float* __restrict__ part, int parts, float* __restrict__ dbias, int H) {
+  __shared__ float red[256];
   float t = 0.f;
-  for (int p = 0; p < parts; ++p) t += part[p];
-  for (int n = threadIdx.x; n < H; n += 256) dbias[n] = t;
+  for (int p = threadIdx.x; p < parts; p += 256) t += part[p];   // (every thread used to walk all partials serially)
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float tot = red[0];
+  for (int n = threadIdx.x; n < H; n += 256) dbias[n] = tot;
 }
 
 // =================================================================================================
