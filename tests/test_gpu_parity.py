@@ -67,6 +67,29 @@ def test_cin_split_bf16_gemms(B, F, K, conv, mode):
     assert all(torch.equal(a.grad, b.grad) for a, b in zip(W2, Ws))
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_cin_wide_dynamic_range(mode):
+    """Fields and weight rows scaled over six decades (bf16 keeps fp32's exponent range, so the split-bf16 mode must
+    hold the same bar as the exact one): outputs 1e-5, gradients 2e-5 norm-relative to the fp64 oracle."""
+    from ml_function_amd import functional as Fn
+    B, F, K, conv = 48, 39, 16, [128, 128, 128]
+    c = synth.cin_case(B, F, K, conv, dist="normal")
+    rng = np.random.default_rng(11)
+    c["x"] = (c["x"] * 10.0 ** rng.uniform(-3, 3, size=(1, F, 1))).astype(np.float32)
+    c["Ws"] = [(w * 10.0 ** rng.uniform(-3, 3, size=(w.shape[0], 1))).astype(np.float32) for w in c["Ws"]]
+    x = dev(c["x"]).requires_grad_()
+    Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+    bs = [dev(b) for b in c["bs"]]
+    dw, db = dev(c["dense_w"]), dev(c["dense_b"])
+    out = Fn.cin(x, Ws, bs, dw, db, output_dim=1, mode=mode)
+    check("wide out", out, closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"], 1), tol=1e-5)
+    out.backward(dev(c["g"]))
+    dx, dWs, _, _, _ = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"], 1)
+    check("wide dx", x.grad, dx, tol=2e-5)
+    for l in range(3):
+        check("wide dW%d" % l, Ws[l].grad, dWs[l], tol=2e-5)
+
+
 def test_cin_large_batch_rows_beyond_2_pow_21():
     """B*K = 2.4 M rows (the dW kernel's buffer descriptors used to span the whole tensor: 2^21 rows at most).
     Size-independent checks: the first samples equal a small run bit for bit (batch independence), and the weight
