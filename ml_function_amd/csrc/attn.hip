@@ -18,6 +18,7 @@
 //
 // MFMA 16x16x4 f32 maps: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r = D[row=4*(l>>4)+r][col=l&15].
 #include "common.h"
+#include <cstdlib>
 
 namespace fil {
 
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj3_kernel(const floa
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
+  float* tsc = smem + NS * 16 * NC * kRS + wave * (2 * 16 * kRS);   // per-wave transpose tiles (behind the staged weights)
   f32x4 accw[kProjMaxSeg];
 #pragma unroll
   for (int u = 0; u < kProjMaxSeg; ++u) accw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -582,14 +584,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj3_kernel(const floa
       if (sgk < NS) {
         const int j = sgk / d.H, h = sgk - j * d.H;
         const float* Dp = Dj[j] + (long)h * R * d.A;
+        // the 16x16 block D[r0..r0+15][0..15] is needed in both orientations (dv: lane's row li, columns 4g..4g+3;
+        // dc: rows 4g..4g+3, lane's column li).  It is read from memory once (dv) and turned through a per-wave LDS
+        // tile for dc: reading it twice made this kernel move 1.26 GB per call at one wave per SIMD.
         float dv[4], dc[4];
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
           const int a = 4 * g + s2;
           dv[s2] = (rowi < R && a < d.A) ? Dp[rowi * d.A + a] : 0.f;
-          const long row = r0 + 4 * g + s2;
-          dc[s2] = (row < R && li < d.A) ? Dp[row * d.A + li] : 0.f;
         }
+        float* tw = tsc + (sgk & 1) * (16 * kRS);   // two tiles: the next segment's write cannot hit this one's reads
+        *reinterpret_cast<float4*>(tw + li * kRS + 4 * g) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) dc[s2] = tw[(4 * g + s2) * kRS + li];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int kt = 0; kt < NC; ++kt) {
           const float4 wb = *reinterpret_cast<const float4*>(smem + (sgk * 16 * NC + 16 * kt + li) * kRS + 4 * g);
@@ -694,7 +703,11 @@ static int proj_rows_per_block(const AttnDims& d) {
 }
 static int proj_blocks(const AttnDims& d) { return (int)(((long)d.B * d.F + proj_rows_per_block(d) - 1) / proj_rows_per_block(d)); }
 static bool proj_mfma_ok(const AttnDims& d) { return 3 * d.H * d.NC <= kProjMaxSeg; }
-static int proj3_blocks(const AttnDims& d) { return (int)std::max<long>(1, std::min<long>(((long)d.B * d.F + 63) / 64, 512)); }
+static int proj3_blocks(const AttnDims& d) {
+  const char* e = getenv("FIL_ATTN_PROJ_BLOCKS");   // tuning knob (results identical up to the partial-sum order)
+  const long cap = e != nullptr && atoi(e) > 0 ? atoi(e) : 512;
+  return (int)std::max<long>(1, std::min<long>(((long)d.B * d.F + 63) / 64, cap));
+}
 static int proj_parts(const AttnDims& d) { return proj_mfma_ok(d) ? 4 * proj3_blocks(d) : proj_blocks(d); }
 
 static size_t attn_bwd_ws(const AttnDims& d) {
@@ -848,7 +861,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     if (!proj_mfma_ok(d) && sh > 150 * 1024) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: projection tile needs %zu bytes of LDS", sh);
     ProfScope ps("attn_bwd_proj", st, (double)B * F * 4.0 * K * DW);
     if (proj_mfma_ok(d)) {
-      const size_t sh3 = (size_t)NJ * H * 16 * d.NC * kRS * sizeof(float);
+      const size_t sh3 = ((size_t)NJ * H * 16 * d.NC * kRS + 4 * 2 * 16 * kRS) * sizeof(float);
 #define CALL_PROJ3(N, P)                                                                                                    \
   allow_lds_attn(attn_bwd_proj3_kernel<N, P>, sh3);                                                                         \
   hipLaunchKernelGGL((attn_bwd_proj3_kernel<N, P>), dim3(proj3_blocks(d)), dim3(kAttnThreads), sh3, st, x, Wq, Wk, Wr, dq, dk, drsrc, \
