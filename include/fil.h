@@ -115,6 +115,9 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       y = LN(sigmoid(scale * q k^T) k),  res_out [H,B,F,A] = x Wr (may be NULL).
  *   bwd: dy [H,B,F,A] (and, when fuse_relu == 0 and Wr != NULL, dres_in [H,B,F,A] = gradient of res_out)
  *        -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
+ *   av_out (fwd, optional) [H,B,F,A]: the attention output before LayerNorm, saved for the backward; passing it back as
+ *       av_saved (and, when fuse_relu != 0, the forward's y as y_saved) lets the backward skip one of its three score
+ *       recomputations (the LayerNorm / ReLU backward becomes a memory-bound element-wise kernel).  NULL -> recompute.
  *   precision: FIL_PREC_F32 = every matrix product on the exact fp32 MFMA (1e-5 parity with the reference);
  *       FIL_PREC_F16_MFMA = BASELINE config 5 ("fp16 MFMA QK^T V"): the operands of every matrix product (projections,
  *       scores, weighted sums and their gradients) are rounded to fp16 and multiplied on v_mfma_f32_16x16x16_f16 with
@@ -127,12 +130,13 @@ enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A);
 int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                 const float* beta, float* y, float* res_out, int B, int F, int K, int H, int A, float scale,
-                 float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream);
+                 const float* beta, float* y, float* res_out, float* av_out, int B, int F, int K, int H, int A,
+                 float scale, float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream);
 int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                 const float* beta, const float* dy, const float* dres_in, float* dx, float* dWq, float* dWk,
-                 float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H, int A, float scale, float eps,
-                 int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream);
+                 const float* beta, const float* dy, const float* dres_in, const float* y_saved, const float* av_saved,
+                 float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H,
+                 int A, float scale, float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes,
+                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,

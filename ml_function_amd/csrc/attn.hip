@@ -189,8 +189,9 @@ template <int NC, bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                                 const float* __restrict__ Wk, const float* __restrict__ Wr,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ y, float* __restrict__ res_out, AttnDims d,
-                                                                float scale, float eps, int fuse_relu) {
+                                                                float* __restrict__ y, float* __restrict__ res_out,
+                                                                float* __restrict__ av_out, AttnDims d, float scale, float eps,
+                                                                int fuse_relu) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                    // [FP][XSS]
   float* kks = smem + d.FP * d.XSS;    // [FP][kRS]
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
       const int f = 16 * blk + 4 * g + r;
       if (f < d.F && avalid) {
         const long o = (((long)h * d.B + b) * d.F + f) * d.A + a;
+        if (av_out != nullptr) av_out[o] = av[r];   // saved for the backward (it then skips the score recomputation)
         if (fuse_relu) {
           y[o] = fmaxf(res[r] + ln.ln[r], 0.f);
         } else {
@@ -314,6 +316,63 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_kernel(
 #pragma unroll
     for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * 16 + aa];
     gb_part[((long)blockIdx.x * 2 + which) * 16 + aa] = t;
+  }
+}
+
+// ================================================================================================= backward: pre (saved av)
+// Same outputs as attn_bwd_pre_kernel, from the forward's saved av (and, in fused mode, its output y: the ReLU mask
+// is y > 0) instead of recomputing the scores: purely element-wise + 16-lane row reductions, memory-bound.
+// 16 lanes per row [.., a < 16]; a workgroup walks rows with a grid stride; gb_part[block][2][16].
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_saved_kernel(const float* __restrict__ av_s, const float* __restrict__ y_s,
+                                                                         const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                                         float* __restrict__ dav, float* __restrict__ dres,
+                                                                         float* __restrict__ gb_part, long rows, int A, float eps,
+                                                                         int fuse_relu) {
+  __shared__ float red[4][2][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a = lane & 15, g = lane >> 4;
+  const bool use_ln = gamma != nullptr;
+  const bool avalid = a < A;
+  const float gam = (use_ln && avalid) ? gamma[a] : 0.f;
+  const float inv_a = 1.0f / (float)A;
+  float dg = 0.f, db = 0.f;
+  const long rpb = 16;  // rows per workgroup pass: 4 waves x 4 lane groups
+  for (long row0 = (long)blockIdx.x * rpb; row0 < rows; row0 += (long)gridDim.x * rpb) {
+    const long row = row0 + wave * 4 + g;
+    const bool valid = row < rows && avalid;
+    const long o = row * A + a;
+    float dz = valid ? dy[o] : 0.f;
+    if (fuse_relu) {
+      if (!(valid && y_s[o] > 0.f)) dz = 0.f;
+      if (valid && dres != nullptr) dres[o] = dz;
+    }
+    float da = dz;
+    if (use_ln) {
+      const float v = valid ? av_s[o] : 0.f;
+      const float mu = row16_sum(v) * inv_a;
+      const float dv = valid ? v - mu : 0.f;
+      const float var = row16_sum(dv * dv) * inv_a;
+      const float rstd = 1.0f / sqrtf(var + eps);
+      const float xhat = dv * rstd;
+      dg = fmaf(dz, xhat, dg);
+      db += dz;
+      const float dxh = dz * gam;
+      const float m1 = row16_sum(dxh) * inv_a;
+      const float m2 = row16_sum(dxh * xhat) * inv_a;
+      da = rstd * (dxh - m1 - xhat * m2);
+    }
+    if (valid) dav[o] = da;
+  }
+  dg += __shfl_xor(dg, 16); dg += __shfl_xor(dg, 32);
+  db += __shfl_xor(db, 16); db += __shfl_xor(db, 32);
+  if (lane < 16) {
+    red[wave][0][lane] = dg;
+    red[wave][1][lane] = db;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int which = threadIdx.x >> 4, aa = threadIdx.x & 15;
+    gb_part[((long)blockIdx.x * 2 + which) * 16 + aa] = ((red[0][which][aa] + red[1][which][aa]) + red[2][which][aa]) + red[3][which][aa];
   }
 }
 
@@ -745,8 +804,9 @@ extern "C" size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A
 }
 
 extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                            const float* beta, float* y, float* res_out, int B, int F, int K, int H, int A, float scale,
-                            float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                            const float* beta, float* y, float* res_out, float* av_out, int B, int F, int K, int H, int A,
+                            float scale, float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   (void)workspace; (void)workspace_bytes;
   AttnDims d;
   int rc = make_dims("fil_attn_fwd", B, F, K, H, A, d);
@@ -764,8 +824,8 @@ extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, co
   ProfScope ps("attn_fwd", st, (double)B * H * (2.0 * F * K * A * (Wr ? 3 : 2) + 4.0 * F * (double)F * A));
 #define CALL_FWD(N, P)                                                                                                     \
   allow_lds_attn(attn_fwd_kernel<N, P>, sh);                                                                               \
-  hipLaunchKernelGGL((attn_fwd_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, d, \
-                     scale, eps, fuse_relu)
+  hipLaunchKernelGGL((attn_fwd_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, \
+                     av_out, d, scale, eps, fuse_relu)
   FIL_ATTN_NC(d.NC, CALL_FWD)
 #undef CALL_FWD
   FIL_CHECK_LAUNCH();
@@ -773,9 +833,10 @@ extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, co
 }
 
 extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                            const float* beta, const float* dy, const float* dres_in, float* dx, float* dWq, float* dWk,
-                            float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H, int A, float scale,
-                            float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                            const float* beta, const float* dy, const float* dres_in, const float* y_saved,
+                            const float* av_saved, float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta,
+                            int B, int F, int K, int H, int A, float scale, float eps, int fuse_relu, int precision,
+                            void* workspace, size_t workspace_bytes, void* stream) {
   AttnDims d;
   int rc = make_dims("fil_attn_bwd", B, F, K, H, A, d);
   if (rc != FIL_OK) return rc;
@@ -820,7 +881,16 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   if (sh_base + 2 * (size_t)d.FP * kRS * sizeof(float) > 160 * 1024)
     return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: F=%d K=%d needs more than 160 KiB of LDS", F, K);
   const double core = (double)B * H * 4.0 * F * (double)F * A;  // one score + one weighted-sum pass
-  {
+  // saved-av path: LayerNorm needs av; the fused ReLU mask needs y.  Anything missing -> recompute (original kernel).
+  const bool saved_path = (gamma == nullptr || av_saved != nullptr) && (!fuse_relu || y_saved != nullptr);
+  int gb_blocks = B * H;
+  if (saved_path) {
+    const long rows = (long)H * B * F;
+    gb_blocks = (int)std::min<long>((rows + 15) / 16, (long)B * H);   // gb_part holds B*H blocks of partials
+    ProfScope ps("attn_bwd_pre", st, (double)rows * A * 5 * sizeof(float));
+    hipLaunchKernelGGL(attn_bwd_pre_saved_kernel, dim3(gb_blocks), dim3(kAttnThreads), 0, st, av_saved, y_saved, gamma, dy, dav,
+                       (fuse_relu && has_res) ? dres : nullptr, gb_part, rows, A, eps, fuse_relu);
+  } else {
     const size_t sh = sh_base + 4 * 2 * 16 * sizeof(float);
     ProfScope ps("attn_bwd_pre", st, core);
 #define CALL_PRE(N, P)                                                                                                      \
@@ -832,7 +902,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   }
   FIL_CHECK_LAUNCH();
   if (gamma != nullptr) {
-    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, B * H, A);
+    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, gb_blocks, A);
     FIL_CHECK_LAUNCH();
   }
   {

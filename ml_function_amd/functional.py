@@ -5,6 +5,8 @@ in oracle/ and is test infrastructure only).  Tensors are made contiguous; dtype
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -230,9 +232,17 @@ class _AttnFn(torch.autograd.Function):
         res = None
         if not fuse_relu and Wr is not None:
             res = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
-        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), B, F, K, H, A,
+        # av (attention output before LayerNorm) is kept for the backward when LayerNorm is on: it then skips one of
+        # its three score recomputations (H*B*F*A extra floats; FIL_ATTN_SAVE_AV=0 trades them back for the recompute)
+        av = None
+        if gamma is not None and os.environ.get("FIL_ATTN_SAVE_AV", "1") != "0":
+            av = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
+        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), ptr(av), B, F, K, H, A,
                                float(scale), float(eps), int(bool(fuse_relu)), int(precision), None, 0, stream_ptr()), "fil_attn_fwd")
-        ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None])
+        keep_y = bool(fuse_relu) and (av is not None or gamma is None)   # the fused ReLU mask is y > 0
+        ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None],
+                              *([av] if av is not None else []), *([y] if keep_y else []))
+        ctx.extra = (av is not None, keep_y)
         ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu), int(precision))
         if fuse_relu:
             return y
@@ -249,6 +259,9 @@ class _AttnFn(torch.autograd.Function):
         Wr = rest.pop(0) if has_res else None
         gamma = rest.pop(0) if has_ln else None
         beta = rest.pop(0) if has_ln else None
+        has_av, has_y = ctx.extra
+        av_saved = rest.pop(0) if has_av else None
+        y_saved = rest.pop(0) if has_y else None
         B, F, K = x.shape
         _, H, A = Wq.shape
         lib = _lib.load()
@@ -263,7 +276,8 @@ class _AttnFn(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if has_ln else None
         nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A)
         ws = _workspace(nws, x.device)
-        check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(dx),
+        check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(y_saved),
+                               ptr(av_saved), ptr(dx),
                                ptr(dWq), ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps,
                                int(fuse_relu), precision, ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
         return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None, None

@@ -39,9 +39,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 9, H, 1, 0, None, 0, None) == -4
     Hbig = _lib.int_array([300])
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 1, Hbig, 1, 0, None, 0, None) == -4
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, None, 0, None) == -4
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, None, 0, None) == -4
     # unknown precision code
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, None, 0, None) == -1
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, None, 0, None) == -1
 
 
 def test_workspace_sizes(lib):
