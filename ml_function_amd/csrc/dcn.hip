@@ -9,6 +9,7 @@
 // lane in registers across the wave's samples, and reduces them in a fixed order:
 // registers -> LDS (waves of a block) -> partial[block] -> dcn_reduce_kernel.  No atomics.
 #include "common.h"
+#include <cstdlib>
 
 namespace fil {
 
@@ -289,7 +290,16 @@ __global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict
   }
 }
 
-static int dcn_grid(int B) { return std::max(1, std::min(cdiv(B, kDcnWaves), 512)); }
+// Workgroups: the forward likes many (1024: 20 us at c3), the backward few -- every workgroup writes one 2*L*D partial of
+// dw/db that the reduction has to read back (256: bwd + reduce 49 us at c3, 512: 67 us, 1024: 105 us).
+// FIL_DCN_GRID overrides both (tuning knob).
+static int dcn_grid_cap(int B, int cap) {
+  const char* e = getenv("FIL_DCN_GRID");
+  if (e != nullptr && atoi(e) > 0) cap = atoi(e);
+  return std::max(1, std::min(cdiv(B, kDcnWaves), cap));
+}
+static int dcn_grid(int B) { return dcn_grid_cap(B, 256); }        // backward (and its workspace sizing)
+static int dcn_grid_fwd(int B) { return dcn_grid_cap(B, 1024); }
 
 static int pick_npl(int D, bool vec) {
   const int menu[] = {8, 20, 32, 64};
@@ -353,7 +363,7 @@ extern "C" int fil_dcn_fwd(const float* x, const float* w, const float* b, float
   const int npl = pick_npl(D, vec);
   const size_t psz = (size_t)2 * L * D * sizeof(float);
   if (psz > kDcnLdsLimit) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: 2*L*D*4 = %zu bytes of w,b exceed the 160 KiB LDS", psz);
-  const int grid = dcn_grid(B);
+  const int grid = dcn_grid_fwd(B);
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("dcn_fwd", st, (double)B * 2.0 * D * sizeof(float));
 #define FWD_VEC(N) launch_fwd<N, 4>(grid, psz, st, x, w, b, y, s, B, D, L)
