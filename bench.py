@@ -288,7 +288,7 @@ def main():
             dt2 = float(tmax.item())
         split = {"note": "NOT the headline: fil_cin mode 2 = exact-fp32 kernels for the pair-symmetric first layer and the "
                          "last-layer shortcut, split-bf16 (3 bf16 pieces per fp32 operand, 6 bf16 MFMAs per product, fp32 "
-                         "accumulate) for the general layers' fwd/dW/dZ GEMMs; same 1e-5 parity bar (tools/cin_error_table.py)",
+                         "accumulate) for the general layers' fwd/dW/dZ GEMMs; same 1e-5 parity bar (tests/cin_error_table.py)",
                  "value": world * B_PER_GPU * args.steps / dt2, "unit": "samples/s", "ms_per_step": dt2 / args.steps * 1e3,
                  "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(prof2.items())}}
     # separate, untimed pass with every scope recorded: the per-kernel table of the small kernels

@@ -1,5 +1,6 @@
-"""Norm-relative / max-relative error of the CIN outputs and gradients against the fp64 oracle, for the exact-fp32
-modes (0, 1) and the split-bf16 modes (2, 3):  python tools/cin_error_table.py   (GPU)"""
+"""Test utility (lives under tests/ because it checks against oracle/): norm-relative / max-relative error of the CIN
+outputs and gradients against the fp64 oracle, for the exact-fp32 modes (0, 1) and the split-bf16 modes (2, 3).
+    python tests/cin_error_table.py   (needs a GPU)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
