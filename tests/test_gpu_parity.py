@@ -32,7 +32,8 @@ def check(name, got, want, tol=TOL):
 
 
 @pytest.mark.parametrize("B,F,K,conv", [(64, 39, 16, [128, 128, 128]), (9, 5, 8, [6, 7]), (16, 26, 16, [200, 200]), (130, 39, 16, [32, 64]),
-                                        (33, 38, 16, [64, 48, 8]), (7, 6, 5, [40, 33])])
+                                        (33, 38, 16, [64, 48, 8]), (7, 6, 5, [40, 33]), (4, 64, 4, [16, 16, 16]),
+                                        (8, 10, 4, [256, 256, 8]), (5, 3, 4, [5, 9, 2])])
 @pytest.mark.parametrize("mode", [2, 3])
 def test_cin_split_bf16_gemms(B, F, K, conv, mode):
     """Opt-in mode bit 1 (FIL_CIN_SPLIT_BF16): the general layers' forward and dW GEMMs on split-bf16 operands (three
