@@ -29,6 +29,36 @@ def first_tensor(inputs):
     return inputs
 
 
+def merge_packed_views(tensors):
+    """The reference passes F separate [B,1,K] tensors around; here they are usually the `split(1, dim=1)` views of ONE
+    packed [B,F,K] block (SparseEmbed).  Runs of such adjacent views are replaced by a single slice of their base, so that
+    re-packing them is a view instead of an F-way concatenation copy (same values, same autograd graph endpoints)."""
+    out, i, n = [], 0, len(tensors)
+    while i < n:
+        t = tensors[i]
+        base = getattr(t, "_base", None)
+        ok = (base is not None and base.dim() == 3 and t.dim() == 3 and t.shape[1] == 1 and t.shape[0] == base.shape[0]
+              and t.shape[2] == base.shape[2] and base.is_contiguous() and t.stride() == base.stride())
+        if not ok:
+            out.append(t)
+            i += 1
+            continue
+        k = base.shape[2]
+        first = (t.storage_offset() - base.storage_offset()) // k
+        j = i + 1
+        while (j < n and getattr(tensors[j], "_base", None) is base and tensors[j].shape == t.shape
+               and tensors[j].stride() == t.stride()
+               and tensors[j].storage_offset() == base.storage_offset() + (first + (j - i)) * k):
+            j += 1
+        if j - i == 1 or (t.storage_offset() - base.storage_offset()) % k != 0:
+            out.append(t)
+            i += 1
+        else:
+            out.append(base if (first == 0 and j - i == base.shape[1]) else base.narrow(1, first, j - i))
+            i = j
+    return out
+
+
 def glorot_uniform_(tensor, seed=None):
     """Keras glorot_uniform: U(-l, l), l = sqrt(6 / (fan_in + fan_out)); rank>2 uses the receptive-field rule.
     (TF's RNG stream cannot be matched; parity tests pass explicit weights.)"""

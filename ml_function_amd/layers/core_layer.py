@@ -4,7 +4,7 @@ Dense layers are plain GEMMs and go through torch (hipBLASLt); the AutoInt wrapp
 the fused attention kernel."""
 import torch
 
-from .base import Layer, glorot_uniform_
+from .base import Layer, merge_packed_views, glorot_uniform_
 from .behavior_layer import MultHeadAttentionLayer
 from .interactive_layer import InnerLayer
 
@@ -64,11 +64,15 @@ class StackLayer(Layer):
         self.axis = axis if axis else -1  # the reference treats axis=None/0 as the Concatenate default (-1)
 
     def call(self, inputs, **kwargs):
+        inputs = list(inputs)
+        if self.use_flat or self.axis == 1:
+            # F split views of one packed [B,F,K] block concatenate back into a slice of it: no copy
+            inputs = merge_packed_views(inputs)
         if self.use_flat:
             inputs = [t.reshape(t.shape[0], -1) for t in inputs]
         if len(inputs) == 1:
             return inputs[0]
-        return torch.cat(list(inputs), dim=self.axis)
+        return torch.cat(inputs, dim=self.axis)
 
 
 class ScoreLayer(Layer):

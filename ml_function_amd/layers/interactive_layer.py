@@ -8,13 +8,13 @@ Packed [B,F,K] is the native layout; the reference's Python lists of F tensors [
 import torch
 
 from .. import functional as Fn
-from .base import Layer, glorot_uniform_
+from .base import Layer, glorot_uniform_, merge_packed_views
 
 
 def pack_fields(inputs):
     """list of F tensors [B,1,K] (or [B,K]) -> [B,F,K]; a packed tensor passes through."""
     if isinstance(inputs, (list, tuple)):
-        ts = [t if t.dim() == 3 else t.unsqueeze(1) for t in inputs]
+        ts = merge_packed_views([t if t.dim() == 3 else t.unsqueeze(1) for t in inputs])
         return ts[0] if len(ts) == 1 else torch.cat(ts, dim=1)
     return inputs
 
