@@ -92,16 +92,19 @@ PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measure
 
 
 def deepfm_benchmark(args):
-    """BASELINE config 2: DeepFM (FM + 2-layer MLP), 39 fields, K=16, B=4096, bf16 -- the whole model step
-    (embedding gather, FM layer on bf16 embeddings, MLP under bf16 autocast, softmax head, BCE, backward incl. the
-    embedding scatter-add), eager and replayed from a HIP graph."""
+    """Whole-model steps.  deepfm = BASELINE config 2: DeepFM (FM + 2-layer MLP), 39 fields, K=16, B=4096, bf16 (embedding
+    gather, FM layer on bf16 embeddings, MLP under bf16 autocast, softmax head, BCE, backward incl. the embedding
+    scatter-add).  xdeepfm = the north-star layer inside its model (models.XDeepFM: linear + CIN 3x128 + 256-128-64 MLP,
+    fp32).  Eager and replayed from a HIP graph."""
     from ml_function_amd import models
     dev = torch.device("cuda", 0)
     B = args.batch or 4096
     rng = np.random.default_rng(2020)
     vocab = [int(v) for v in np.exp(rng.uniform(np.log(10), np.log(1e5), 39))]
-    fi = models.FeatureInput(sparseInfo=models.make_sparse_info(vocab, embed_dim=16), useLinear=True)
-    body = models.DeepFM(hidden_units=[256, 128])
+    xd = args.workload == "xdeepfm"
+    fi = models.FeatureInput(sparseInfo=models.make_sparse_info(vocab, embed_dim=16), useLinear=True, useAddLinear=xd,
+                             useFlattenLinear=xd)
+    body = models.XDeepFM(conv_size=[128, 128, 128]) if xd else models.DeepFM(hidden_units=[256, 128])
 
     class Bf16Body(torch.nn.Module):
         def __init__(self, inner):
@@ -117,7 +120,7 @@ def deepfm_benchmark(args):
                 return self.inner(fea).float()
 
     torch.manual_seed(0)
-    model = models.CTRModel(fi, Bf16Body(body)).to(dev)
+    model = models.CTRModel(fi, body if xd else Bf16Body(body)).to(dev)
     dense = torch.tensor(rng.random((B, 13), dtype=np.float32), device=dev)
     idx = torch.tensor(np.stack([rng.integers(0, v, B) for v in vocab], 1), device=dev)
     y = torch.tensor(rng.integers(0, 2, B), dtype=torch.float32, device=dev)
@@ -128,7 +131,7 @@ def deepfm_benchmark(args):
         for p in params:
             p.grad = None
         out = model(dense, idx)
-        torch.nn.functional.binary_cross_entropy(out[:, 1].clamp(1e-6, 1 - 1e-6), y).backward()
+        torch.nn.functional.binary_cross_entropy(out[:, -1].clamp(1e-6, 1 - 1e-6), y).backward()
 
     for _ in range(args.warmup):
         step()
@@ -157,10 +160,11 @@ def deepfm_benchmark(args):
             gr.replay()
         torch.cuda.synchronize()
         graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
-    name = "DeepFM (FM + MLP 256-128) whole-model fwd+bwd, 39 fields K=16, bf16, B=%d (BASELINE.json configs[1])" % B
+    name = ("xDeepFM whole model (linear + CIN 3x128 + MLP 256-128-64) fwd+bwd, 39 fields K=16, fp32, B=%d" % B if xd else
+            "DeepFM (FM + MLP 256-128) whole-model fwd+bwd, 39 fields K=16, bf16, B=%d (BASELINE.json configs[1])" % B)
     print(json.dumps({"metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (fp32 accumulate)", "data": "synthetic",
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f32" if xd else "bf16 (fp32 accumulate)", "data": "synthetic",
                       "config": {"workload": name}, "hipgraph_replay_ms_per_step": graph_ms,
                       "hipgraph_samples_per_s": (B / (graph_ms * 1e-3)) if graph_ms else None}))
 
@@ -276,7 +280,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint", "deepfm"],
+    ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint", "deepfm", "xdeepfm"],
                     help="cin = the headline benchmark (default); the others are single-GPU side benchmarks of the "
                          "remaining hot-path rows (BASELINE.json configs 2, 3, 5)")
     ap.add_argument("--graph", action="store_true", help="side benchmarks: also time the step replayed from a HIP graph")
@@ -284,7 +288,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16_mfma"], help="AutoInt side benchmark only")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
     args = ap.parse_args()
-    if args.workload == "deepfm":
+    if args.workload in ("deepfm", "xdeepfm"):
         return deepfm_benchmark(args)
     if args.workload != "cin":
         return side_benchmark(args)
