@@ -193,15 +193,19 @@ def side_benchmark(args):
         name, kernels, bound = "DCN 3 cross layers fwd+bwd D=1248 fp32 B=%d" % B, ("dcn_fwd", "dcn_bwd"), "hbm"
     else:
         B = args.batch or 4096
-        c = synth.attn_case(B, 200, 16, 4, 16)
-        p = {n: t(c[n]).requires_grad_() for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
+        Fa, Ka, Ha, Aa, L = 200, 16, 4, 16, args.layers
+        c = synth.attn_stack_case(B, Fa, Ka, Ha, Aa, L)
+        xin = t(c["x"]).requires_grad_()
+        layers = [tuple(t(p).requires_grad_() for p in lay) for lay in c["layers"]]
         dy = t(c["dy"])
         def step():
-            for v in p.values():
-                v.grad = None
-            Fn.autoint_interact(p["x"], p["Wq"], p["Wk"], p["Wr"], p["gamma"], p["beta"], precision=args.precision).backward(dy)
-        name, bound = "AutoInt interacting layer fwd+bwd F=200 K=16 H=4 A=16 %s B=%d" % (args.precision, B), "mfma"
-        kernels = ("attn_fwd", "attn_bwd_pre", "attn_bwd_dq", "attn_bwd_dk", "attn_bwd_proj")
+            xin.grad = None
+            for lay in layers:
+                for p in lay:
+                    p.grad = None
+            Fn.autoint_stack(xin, layers, precision=args.precision).backward(dy)
+        name = "AutoInt %d interacting layer%s fwd+bwd F=200 K=16 H=4 A=16 %s B=%d" % (L, "s" if L > 1 else "", args.precision, B)
+        bound, kernels = "hbm", ("attn_fwd", "attn_bwd")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -235,10 +239,32 @@ def side_benchmark(args):
     ks = {k: v for k, v in prof.items() if k in kernels}
     dom = max(ks, key=lambda k: ks[k]["total_ms"])
     d = ks[dom]
-    rate = d["work"] / (d["avg_ms"] * 1e-3)
     f16 = args.workload == "autoint" and args.precision == "f16_mfma"
-    mfma_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-    peak, unit, ach = (PEAK_HBM_GBPS, "GB/s", rate / 1e9) if bound == "hbm" else (mfma_peak, "TFLOP/s", rate / 1e12)
+    extra = {}
+    if args.workload == "autoint":
+        # What binds these kernels: HBM passes over the [H,B,F,A] tensors and the sigmoid issue rate,
+        # not the matrix pipe.  Algorithmic bytes per launch (fp32): forward = x in, y + saved av out; backward = x, av, y,
+        # dy in, dx out.  Averaged over the L layers of the stack (layers 2.. read K = H*A = 64 input features).
+        hbfa = Ha * B * Fa * Aa * 4.0
+        xin_b = [B * Fa * (Ka if l == 0 else Ha * Aa) * 4.0 for l in range(L)]
+        bytes_fwd = sum(xb + 2 * hbfa for xb in xin_b) / L
+        bytes_bwd = sum(2 * xb + 3 * hbfa for xb in xin_b) / L
+        nbytes = bytes_bwd if dom == "attn_bwd" else bytes_fwd
+        rate = nbytes / (d["avg_ms"] * 1e-3)
+        # transcendental roofline: one sigmoid = v_exp_f32 + v_rcp_f32, 8 issue cycles each per 64 lanes
+        # (MI355X_MICROARCH.md, cycle constants) -> 1024 SIMDs x 2.4 GHz x 64 / 16 sigmoids per second
+        sig_peak = 1024 * 2.4e9 * 64 / 16
+        sig = Ha * B * float(Fa) * Fa
+        extra = {"valu_roofline": {"what": "sigmoid evaluations (v_exp_f32 + v_rcp_f32) of one pass over the F x F scores",
+                                   "kernel": dom, "per_launch": sig, "achieved_per_s": sig / (d["avg_ms"] * 1e-3),
+                                   "peak_per_s": sig_peak, "frac": sig / (d["avg_ms"] * 1e-3) / sig_peak},
+                 "mfma_tflops": {k: v["work"] / (v["avg_ms"] * 1e-3) / 1e12 for k, v in ks.items()},
+                 "mfma_frac_of_peak": {k: v["work"] / (v["avg_ms"] * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS)
+                                       for k, v in ks.items()},
+                 "ms_per_layer": dt / args.steps * 1e3 / L}
+    else:
+        rate = d["work"] / (d["avg_ms"] * 1e-3)
+    peak, unit, ach = PEAK_HBM_GBPS, "GB/s", rate / 1e9
     print(json.dumps({
         "metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -246,6 +272,7 @@ def side_benchmark(args):
         "config": {"workload": name},
         "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                      "traffic": None, "avg_launch_ms": d["avg_ms"]},
+        **extra,
         "kernels": {k: dict(avg_ms=round(v["avg_ms"], 4), work=v["work"]) for k, v in sorted(ks.items())},
         "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps,
         "hipgraph_replay_ms_per_step": graph_ms}))
@@ -287,6 +314,7 @@ def main():
     ap.add_argument("--cin-mode", type=int, default=0, help="fil_cin mode bits (experiments; the headline is mode 0)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16_mfma"], help="AutoInt side benchmark only")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
+    ap.add_argument("--layers", type=int, default=3, help="AutoInt side benchmark: stacked interacting layers (config 5: 3)")
     args = ap.parse_args()
     if args.workload in ("deepfm", "xdeepfm"):
         return deepfm_benchmark(args)

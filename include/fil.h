@@ -36,7 +36,11 @@ typedef enum {
 
 typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 
-int fil_version(void);                 /* 10000*major + 100*minor + patch */
+/* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
+ * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
+ * header's, so a stale prebuilt .so can never be called with shifted arguments. */
+#define FIL_ABI_VERSION 200
+int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
 /* Opt-in per-kernel timing for bench.py's roofline line (off by default).  Between begin and end every major
@@ -65,7 +69,7 @@ int fil_fm_pairs_bwd(const float* emb, const float* gpairs, float* demb, int B, 
 /* ---------------------------------------------------------------------------------------------
  * A2  DCN cross network -- replaces CrossLayer.call, interactive_layer.py:275-282, all L layers fused.
  *   x [B,D], w [L,D], b [L,D] (the reference's L tensors [D,1] stacked), y [B,D], s [B,L] (saved dots).
- *   bwd: g [B,D] -> dx [B,D], dw [L,D], db [L,D].  Limits: D <= 4096, L <= 8.
+ *   bwd: g [B,D] -> dx [B,D], dw [L,D], db [L,D].  Limits: D <= 4096, L <= 6.
  */
 int fil_dcn_fwd(const float* x, const float* w, const float* b, float* y, float* s, int B, int D, int L, void* stream);
 size_t fil_dcn_bwd_workspace_bytes(int B, int D, int L);
@@ -115,28 +119,34 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       y = LN(sigmoid(scale * q k^T) k),  res_out [H,B,F,A] = x Wr (may be NULL).
  *   bwd: dy [H,B,F,A] (and, when fuse_relu == 0 and Wr != NULL, dres_in [H,B,F,A] = gradient of res_out)
  *        -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
- *   av_out (fwd, optional) [H,B,F,A]: the attention output before LayerNorm, saved for the backward; passing it back as
- *       av_saved (and, when fuse_relu != 0, the forward's y as y_saved) lets the backward skip one of its three score
- *       recomputations (the LayerNorm / ReLU backward becomes a memory-bound element-wise kernel).  NULL -> recompute.
+ *   av_out (fwd, optional) [H,B,F,A]: the attention output before LayerNorm, saved for the backward (its LayerNorm
+ *       backward needs it; the fused ReLU mask is y > 0, so pass the forward's y back as y_saved).  If either is NULL the
+ *       backward first re-runs the forward into its workspace (fil_attn_bwd_workspace_bytes(.., have_saved = 0)).
+ *   x_chunk: 0 = x (and dx) are [B,F,K].  c > 0 = head-major [K/c][B][F][c], i.e. the [H',B,F,A'] output of a previous
+ *       interacting layer read in place as its head-concat [B,F,H'*A'] (ESULayer's convention, behavior_layer.py:973):
+ *       a stack of interacting layers (BASELINE config 5: 3 layers) needs no transposes, and dx IS the dy of the layer below.
+ *   The backward is one kernel (one pass over the F x F scores): per-workgroup partial sums of dW* / dgamma / dbeta are
+ *   reduced afterwards in a fixed order (bit-identical repeats).
  *   precision: FIL_PREC_F32 = every matrix product on the exact fp32 MFMA (1e-5 parity with the reference);
  *       FIL_PREC_F16_MFMA = BASELINE config 5 ("fp16 MFMA QK^T V"): the operands of every matrix product (projections,
  *       scores, weighted sums and their gradients) are rounded to fp16 and multiplied on v_mfma_f32_16x16x16_f16 with
  *       fp32 accumulation; sigmoid, LayerNorm, residual, ReLU, all tensors in memory and all reductions stay fp32.
  *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
- *   Limits: K <= 64, A <= 16, F <= 512 (and the LDS footprint <= 160 KiB).
+ *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
 enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
-size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A);
+size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);
 int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                  const float* beta, float* y, float* res_out, float* av_out, int B, int F, int K, int H, int A,
-                 float scale, float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes, void* stream);
+                 float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
+                 size_t workspace_bytes, void* stream);
 int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                  const float* beta, const float* dy, const float* dres_in, const float* y_saved, const float* av_saved,
                  float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H,
-                 int A, float scale, float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes,
-                 void* stream);
+                 int A, float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,

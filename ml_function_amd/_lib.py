@@ -35,9 +35,9 @@ SIGNATURES = {
     "fil_cin_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
     "fil_cin_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
     "fil_attn_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
-    "fil_attn_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
-    "fil_attn_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _P, _Z, _P]),
-    "fil_attn_bwd": (_I, [_P] * 16 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _P, _Z, _P]),
+    "fil_attn_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "fil_attn_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
+    "fil_attn_bwd": (_I, [_P] * 16 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
     "fil_embed_gather": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_scatter_add": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
 }
@@ -57,6 +57,14 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(fil_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_abi_version():
+    """FIL_ABI_VERSION of include/fil.h (the version this binding's SIGNATURES table was written against)."""
+    m = re.search(r"#define\s+FIL_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read())
+    if m is None:
+        raise FilError("include/fil.h does not define FIL_ABI_VERSION")
+    return int(m.group(1))
+
+
 def load():
     """Loads libfil_hip.so (raises FilError if it has not been built: python -m ml_function_amd.build)."""
     global _lib
@@ -74,6 +82,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    want = header_abi_version()
+    if lib.fil_version() != want:
+        raise FilError("libfil_hip.so at %s has ABI version %d, include/fil.h says %d -- stale build, rebuild it "
+                       "(python -m ml_function_amd.build --force)" % (LIB_PATH, lib.fil_version(), want))
     _lib = lib
     return lib
 

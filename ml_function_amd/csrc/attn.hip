@@ -1,63 +1,146 @@
-// A4  AutoInt interacting layer (multi-head field attention) for gfx950, fp32 MFMA (v_mfma_f32_16x16x4_f32).
+// A4  AutoInt interacting layer (multi-head field attention) for gfx950.
 //
 // Replaces MultHeadAttentionLayer.call + ProductAttentionLayer.call (behavior_layer.py:292-311,356-377) and the
 // Add + ReLU of the DnnLayer wrapper (core_layer.py:204-216).  Reference quirks kept: the "softmax" is a sigmoid,
 // V is projected with key_w (so K == V), LayerNorm eps is Keras' 1e-3, output is head-major [H,B,F,A].
-// The [H,B,F,F] score tensor (2.6 GB at F=200, B=4096) is never materialised: a workgroup owns one (sample, head),
-// projects x -> q, k in-kernel (K is tiny), keeps k in LDS and streams 16x16 score tiles through registers:
-//     S' tile = sigmoid(scale * k_tile q_blk^T)   (accumulator layout: key f' on (lane>>4, reg), query f on lane&15)
-//     av_blk += S'^T k_tile                       (the S' accumulator IS the next MFMA's A operand, no LDS round trip;
-//                                                  the reduction order over f' is permuted to match: step s of lane group g
-//                                                  takes f' = 16t + 4g + s)
-// Backward recomputes the scores twice, once per orientation, so that both dq (reduce over keys) and dk (reduce
-// over queries) take their A operand straight from accumulators:
-//   attn_bwd_pre  recompute av, ReLU mask, LayerNorm backward -> dav, dres (global), dgamma/dbeta partials
-//   attn_bwd_dq   S', dS' = k dav^T (key-major)   -> dq  = (dS' S'(1-S') scale)^T k
-//   attn_bwd_dk   S,  dS  = dav k^T (query-major) -> dk  = (dS S(1-S) scale)^T q + S^T dav    (K and V share key_w)
-//   attn_bwd_proj dx = dq Wq^T + dk Wk^T + dres Wr^T (summed over heads), dW* = x^T d*  (block partials + fixed-order reduce)
 //
-// MFMA 16x16x4 f32 maps: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r = D[row=4*(l>>4)+r][col=l&15].
+// What bounds this layer (B=4096, F=200, H=4, A=16): every [H,B,F,A] tensor is 210 MB and a pass over the F x F scores
+// is 655 M sigmoids (v_exp_f32 + v_rcp_f32, quarter rate), so the design minimises (a) HBM passes over [H,B,F,A]
+// tensors and (b) sigmoid passes; the matrix pipe is nowhere near busy.  Two kernels:
+//
+//   attn_fwd_kernel   one workgroup = one sample, one wave = one head.  x is staged once for all heads; the wave projects
+//                     its k (== v) into a private LDS image and walks the 16x16 score tiles:
+//                         S'[key][query] = sigmoid(scale k_t q_i^T)      accumulator: key on (lane>>4, reg), query on lane&15
+//                         av^T[a][query] += k_t^T S'                     the S' accumulator IS the B operand, no LDS trip
+//                     av^T leaves the MFMA as [query on the lane][4 consecutive a] = one 16-byte store per lane, so y
+//                     and the saved av are written as whole 1-KB rows; LayerNorm + residual + ReLU in the epilogue.
+//   attn_bwd_kernel   ONE pass over the scores for the whole backward (the round-1 code made three).  Same
+//                     decomposition; the wave keeps dk of ALL its key tiles in accumulators (13 x 4 registers at F=200)
+//                     while it loops over the query blocks:
+//                         S [query][key] , dS = dav_i k_t^T ; dP = dS S (1-S)
+//                         dk_t^T[a][key] += q_i^T dP + dav_i^T S          S and dP accumulators are the B operands
+//                         dq_i^T[a][query] += k_t^T dP^T                  dP crosses LDS once (8-byte write + transposing
+//                                                                         ds_read_b64_tr_b16 in the f16 mode)
+//                     The LayerNorm/ReLU backward (from the saved av and y) is the prologue of each query block, and
+//                     the projection gradients are folded in: dW* accumulate in registers across the samples of a
+//                     persistent workgroup, dx of the heads is summed in an LDS tile (fixed order) and written once.
+//                     HBM traffic: x, av, y, dy in; dx out -- no dav/dq/dk/dres round trips.
+//
+// precision F32: every product on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains; 1e-5 parity mode), x fragments read from
+// global/L2.  F16_MFMA (BASELINE config 5): operands rounded to fp16 once when they enter LDS / registers, products on
+// v_mfma_f32_16x16x16_f16 with fp32 accumulation; sigmoid, LayerNorm, residual, ReLU, every reduction and every tensor
+// in HBM stay fp32.
+//
+// MFMA 16x16 maps: lane l supplies A[i=l&15][k=4(l>>4)+s], B[k=4(l>>4)+s][j=l&15], s=0..3; D reg r = D[4(l>>4)+r][l&15].
+// "row fragment" of a [16 x 16] tile T: lane (g,c) holds T[c][4g..4g+3]; "column fragment": lane (g,c) holds T[4g..4g+3][c].
 #include "common.h"
-#include <cstdlib>
+#include <algorithm>
+#include <mutex>
+#include <type_traits>
 
 namespace fil {
 
-constexpr int kAttnThreads = 256;
-constexpr int kRS = 20;       // LDS row stride of [rows][16] tiles: 16-byte aligned rows, conflict-free b128 row reads
-constexpr int kMaxNC = 4;     // K <= 64 (NC = ceil(K/16) chunks of 16 along the projection's reduction)
+constexpr int kMaxNC = 4;      // K <= 64 (NC = ceil(K/16) chunks of 16 along the projection's reduction)
+constexpr int kMaxHeads = 8;   // one wave per head, one workgroup per sample
 
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// Four reduction steps into one accumulator: lane group g = lane>>4 contributes the products a_s * b_s, s = 0..3.
-// F16 = false: four exact-fp32 16x16x4 MFMAs (the 1e-5 parity mode).  F16 = true (BASELINE config 5, "fp16 MFMA"):
-// operands rounded to fp16 (v_cvt_pk_f16_f32, round-to-nearest-even), ONE 16x16x16 f16 MFMA with fp32 accumulation --
-// lane group g supplies k = 4g..4g+3 of both operands, which is the same (s, g) pairing as the four fp32 steps.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
 template <bool F16>
-__device__ __forceinline__ f32x4 mma4(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3, f32x4 c) {
+struct Prec;
+template <>
+struct Prec<true> {
+  typedef _Float16 Elem;
+  typedef f16x4 Op;
+  static constexpr int RS = 16;   // LDS tile row stride (elements): 32-byte rows, 8-byte chunks XOR-swizzled
+};
+template <>
+struct Prec<false> {
+  typedef float Elem;
+  typedef f32x4 Op;
+  static constexpr int RS = 20;   // 80-byte rows: conflict-free b128 row reads and strided b32 column reads
+};
+
+// ---- one MFMA "step": 4 reduction indices per lane group ------------------------------------------------------------
+template <bool F16>
+__device__ __forceinline__ f32x4 mma(typename Prec<F16>::Op a, typename Prec<F16>::Op b, f32x4 c) {
   if constexpr (F16) {
-    const f32x4 av = {a0, a1, a2, a3}, bv = {b0, b1, b2, b3};
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_convertvector(av, f16x4), __builtin_convertvector(bv, f16x4), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
   } else {
-    c = mfma16(a0, b0, c);
-    c = mfma16(a1, b1, c);
-    c = mfma16(a2, b2, c);
-    c = mfma16(a3, b3, c);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
     return c;
   }
 }
 
-__device__ __forceinline__ float sigmoidf_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+template <bool F16>
+__device__ __forceinline__ typename Prec<F16>::Op to_op(f32x4 v) {
+  if constexpr (F16) {
+    return __builtin_convertvector(v, f16x4);
+  } else {
+    return v;
+  }
+}
 
-// sum over the 16 lanes that share lane>>4 (one row of a D tile)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
+// ---- LDS tile images: [rows][16] elements ------------------------------------------------------------------------------
+// f16: 32-byte rows; the four 8-byte chunks of rows 8..15 (mod 16) are stored XOR 2, which makes the 8-byte row reads of a
+// 32-lane half (16 rows x 2 chunks) and the transposing reads (8 rows x 4 chunks) hit 64 different banks.
+__device__ __forceinline__ int swz16(int row) { return ((row >> 3) & 1) << 1; }
+
+template <bool F16>
+__device__ __forceinline__ typename Prec<F16>::Op row_read(const typename Prec<F16>::Elem* img, int row, int g) {
+  if constexpr (F16) {
+    return *reinterpret_cast<const f16x4*>(img + row * 16 + 4 * (g ^ swz16(row)));
+  } else {
+    return *reinterpret_cast<const f32x4*>(img + row * 20 + 4 * g);
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ void row_write(typename Prec<F16>::Elem* img, int row, int g, typename Prec<F16>::Op v) {
+  if constexpr (F16) {
+    *reinterpret_cast<f16x4*>(img + row * 16 + 4 * (g ^ swz16(row))) = v;
+  } else {
+    *reinterpret_cast<f32x4*>(img + row * 20 + 4 * g) = v;
+  }
+}
+
+// column fragment of the 16-row block that starts at row0: element s = img[row0 + 4g + s][lane & 15].
+// f16: ds_read_b64_tr_b16 -- lane 4q+p of a 16-lane group supplies the address of (row q, chunk p) of the group's
+// 4 x 16 block and receives column (lane & 15) of its 4 rows.  EXEC must be all ones (call from wave-uniform code only).
+template <bool F16>
+__device__ __forceinline__ typename Prec<F16>::Op tr_read(const typename Prec<F16>::Elem* img, int row0, int lane) {
+  if constexpr (F16) {
+    const int li = lane & 15;
+    const int row = row0 + 4 * (lane >> 4) + (li >> 2);
+    const _Float16* p = img + row * 16 + 4 * ((li & 3) ^ swz16(row));
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(f16x4, r);
+  } else {
+    const float* p = img + (row0 + 4 * (lane >> 4)) * 20 + (lane & 15);
+    return f32x4{p[0], p[20], p[40], p[60]};
+  }
+}
+
+// sum over the four lanes {c, c+16, c+32, c+48} (the four 4-element pieces of one fragment row), result in all of them
+__device__ __forceinline__ float groups_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return lane_halves_sum(v);
+}
+
+// sum over the 16 lanes of a row (lanes 16g .. 16g+15), result in all of them: DPP only, no LDS crossbar
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_mov<0x140, 0xF>(v);  // row_mirror
   return v;
+}
+
+__device__ __forceinline__ float sigmoid_from_neg_log2(float t) {   // t = -log2(e) * score  ->  1 / (1 + exp(-score))
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 
 struct AttnDims {
@@ -65,663 +148,595 @@ struct AttnDims {
   int nblk;   // ceil(F/16)
   int FP;     // 16*nblk
   int NC;     // ceil(K/16)
-  int XSS;    // xs row stride = 16*NC + 4
+  int xcw;    // x chunk width: K for the plain [B,F,K] layout, c for the head-major layout [K/c][B][F][c]
+  long xcs;   // x chunk stride in elements (B*F*c; 0 for the plain layout)
 };
 
-// xs[f][k] = x[b,f,k], zero padded to [FP][16*NC]
-__device__ __forceinline__ void stage_x(const float* __restrict__ xb, float* xs, const AttnDims& d) {
-  const int Kpad = 16 * d.NC;
-  for (int idx = threadIdx.x; idx < d.FP * Kpad; idx += kAttnThreads) {
-    const int f = idx / Kpad, k = idx - f * Kpad;
-    xs[f * d.XSS + k] = (f < d.F && k < d.K) ? xb[f * d.K + k] : 0.f;
+__device__ __forceinline__ long x_off(const AttnDims& d, int b, int f, int kin) {
+  const int ch = kin / d.xcw;
+  return ch * d.xcs + ((long)b * d.F + f) * d.xcw + (kin - ch * d.xcw);
+}
+
+// ---- x fragments --------------------------------------------------------------------------------------------------------
+// XL = true (f16 mode): x[b] converted once into LDS images xs[NC][FP][16] (zero padded), fragments are LDS reads.
+// XL = false: fragments straight from global (L1/L2; x[b] is 13-51 KB and shared by the heads), converted on the fly.
+template <bool F16, bool XL>
+struct XSrc;
+
+template <>
+struct XSrc<true, true> {
+  const _Float16* xs;
+  int FP;
+  __device__ __forceinline__ void set_sample(const AttnDims&, int) {}
+  // row fragment: element s = x[16 blk + (lane&15)][16 ch + 4g + s]
+  __device__ __forceinline__ f16x4 row(int blk, int ch, int lane) const {
+    return row_read<true>(xs + ch * FP * 16, 16 * blk + (lane & 15), lane >> 4);
+  }
+  // column fragment: element s = x[16 blk + 4g + s][16 ch + (lane&15)]
+  __device__ __forceinline__ f16x4 col(int blk, int ch, int lane) const { return tr_read<true>(xs + ch * FP * 16, 16 * blk, lane); }
+};
+
+template <bool F16>
+struct XSrc<F16, false> {
+  const float* x;
+  AttnDims d;
+  int b;
+  bool vec;   // xcw % 4 == 0 && K % 4 == 0: four consecutive kin are one aligned 16-byte piece
+  __device__ __forceinline__ void set_sample(const AttnDims& dd, int bb) {
+    d = dd;
+    b = bb;
+    vec = (dd.xcw & 3) == 0 && (dd.K & 3) == 0;
+  }
+  __device__ __forceinline__ typename Prec<F16>::Op row(int blk, int ch, int lane) const {
+    const int f = 16 * blk + (lane & 15), k0 = 16 * ch + 4 * (lane >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const bool ok = f < d.F && k0 < d.K;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(x + (ok ? x_off(d, b, f, k0) : 0));
+      if (ok) v = t;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = f < d.F && k0 + s < d.K;
+        const float t = x[ok ? x_off(d, b, f, k0 + s) : 0];
+        if (ok) v[s] = t;
+      }
+    }
+    return to_op<F16>(v);
+  }
+  __device__ __forceinline__ typename Prec<F16>::Op col(int blk, int ch, int lane) const {
+    const int f0 = 16 * blk + 4 * (lane >> 4), kin = 16 * ch + (lane & 15);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = kin < d.K && f0 + s < d.F;
+      const float t = x[ok ? x_off(d, b, f0 + s, kin) : 0];
+      if (ok) v[s] = t;
+    }
+    return to_op<F16>(v);
+  }
+};
+
+// all threads: xs[ch][f][k] = (f16) x[b,f,16ch+k], zero padded
+__device__ __forceinline__ void stage_x_f16(const float* __restrict__ x, _Float16* xs, const AttnDims& d, int b, int nthreads) {
+  const bool vec = (d.xcw & 3) == 0 && (d.K & 3) == 0;
+  const int per_ch = d.FP * 4;
+  for (int idx = threadIdx.x; idx < d.NC * per_ch; idx += nthreads) {
+    const int ch = idx / per_ch, rem = idx - ch * per_ch;
+    const int f = rem >> 2, p = rem & 3, k0 = 16 * ch + 4 * p;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (f < d.F) {
+      if (vec) {
+        if (k0 < d.K) v = *reinterpret_cast<const f32x4*>(x + x_off(d, b, f, k0));
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (k0 + s < d.K) v[s] = x[x_off(d, b, f, k0 + s)];
+      }
+    }
+    *reinterpret_cast<f16x4*>(xs + ch * d.FP * 16 + f * 16 + 4 * (p ^ swz16(f))) = __builtin_convertvector(v, f16x4);
   }
 }
 
-// w[c][s] = W[k = 16c + 4g + s][h][a = lane&15]  (zero for k >= K or a >= A)
-template <int NC>
-__device__ __forceinline__ void load_w(const float* __restrict__ W, int h, const AttnDims& d, int lane, float (&w)[NC][4]) {
+// weight fragment in the "reduce over kin" role: element s = W[kin = 16c + 4g + s][h][a = lane&15]
+// (A operand of (x W)^T products, B operand of x W products)
+template <int NC, bool F16>
+__device__ __forceinline__ void load_w_kin(const float* __restrict__ W, int h, const AttnDims& d, int lane,
+                                           typename Prec<F16>::Op (&w)[NC]) {
   const int a = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+  for (int c = 0; c < NC; ++c) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = 16 * c + 4 * g + s;
-      w[c][s] = (W != nullptr && k < d.K && a < d.A) ? W[((long)k * d.H + h) * d.A + a] : 0.f;
+      if (W != nullptr && k < d.K && a < d.A) v[s] = W[((long)k * d.H + h) * d.A + a];
     }
-}
-
-// xr[c][s] = xs[16*blk + (lane&15)][16c + 4g + s]
-template <int NC>
-__device__ __forceinline__ void load_xfrag(const float* xs, int blk, const AttnDims& d, int lane, float (&xr)[NC][4]) {
-  const float* p = xs + (16 * blk + (lane & 15)) * d.XSS + 4 * (lane >> 4);
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const float4 t = *reinterpret_cast<const float4*>(p + 16 * c);
-    xr[c][0] = t.x; xr[c][1] = t.y; xr[c][2] = t.z; xr[c][3] = t.w;
+    w[c] = to_op<F16>(v);
   }
 }
 
-// rows form: D[row <-> f = 4g+r][col <-> a] = x_blk W
-template <int NC, bool F16>
-__device__ __forceinline__ f32x4 proj_rows(const float (&xr)[NC][4], const float (&w)[NC][4]) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+// k image of one head (== v): kimg[f][a] = (x Wk)[f][a], written as row fragments from the transposed product
+template <int NC, bool F16, typename XS>
+__device__ __forceinline__ void project_k(const XS& xsrc, typename Prec<F16>::Elem* kimg, const typename Prec<F16>::Op (&wk)[NC],
+                                          int nblk, int lane) {
+  for (int blk = 0; blk < nblk; ++blk) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc = mma4<F16>(xr[c][0], xr[c][1], xr[c][2], xr[c][3], w[c][0], w[c][1], w[c][2], w[c][3], acc);
-  return acc;
-}
-
-// transposed form: D[row <-> a = 4g+r][col <-> f] = (x_blk W)^T
-template <int NC, bool F16>
-__device__ __forceinline__ f32x4 proj_T(const float (&xr)[NC][4], const float (&w)[NC][4]) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < NC; ++c) acc = mma4<F16>(w[c][0], w[c][1], w[c][2], w[c][3], xr[c][0], xr[c][1], xr[c][2], xr[c][3], acc);
-  return acc;
-}
-
-// store a rows-form tile into an LDS [FP][kRS] array
-__device__ __forceinline__ void store_rows(float* arr, int blk, int lane, const f32x4& v) {
-  float* p = arr + (16 * blk + 4 * (lane >> 4)) * kRS + (lane & 15);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) p[r * kRS] = v[r];
-}
-
-__device__ __forceinline__ float4 lds_row4(const float* arr, int row, int g) {
-  return *reinterpret_cast<const float4*>(arr + row * kRS + 4 * g);
-}
-
-// all waves: arr[f][a] = (x W)[f][a] for every 16-row block (blocks dealt round-robin to the waves)
-template <int NC, bool F16>
-__device__ __forceinline__ void project_all(const float* xs, float* arr, const float (&w)[NC][4], const AttnDims& d, int wave,
-                                            int lane) {
-  for (int blk = wave; blk < d.nblk; blk += 4) {
-    float xr[NC][4];
-    load_xfrag<NC>(xs, blk, d, lane, xr);
-    store_rows(arr, blk, lane, proj_rows<NC, F16>(xr, w));
+    for (int c = 0; c < NC; ++c) acc = mma<F16>(wk[c], xsrc.row(blk, c, lane), acc);   // D[a 4g+r][f lane&15]
+    row_write<F16>(kimg, 16 * blk + (lane & 15), lane >> 4, to_op<F16>(acc));
   }
 }
 
-// av_blk = sum_t sigmoid(k_t q_blk^T)^T k_t  -- shared by forward and bwd_pre.  qT is pre-scaled.
-template <bool F16>
-__device__ __forceinline__ f32x4 attend_block(const float* kks, const f32x4& qT, int nblk, int lane) {
-  const int a = lane & 15, g = lane >> 4;
-  f32x4 av = {0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < nblk; ++t) {
-    const float4 kA = lds_row4(kks, 16 * t + a, g);
-    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-    sc = mma4<F16>(kA.x, kA.y, kA.z, kA.w, qT[0], qT[1], qT[2], qT[3], sc);
-    const float* kb = kks + (16 * t + 4 * g) * kRS + a;
-    av = mma4<F16>(sigmoidf_fast(sc[0]), sigmoidf_fast(sc[1]), sigmoidf_fast(sc[2]), sigmoidf_fast(sc[3]), kb[0], kb[kRS], kb[2 * kRS],
-                   kb[3 * kRS], av);
-  }
-  return av;
-}
-
-struct LnOut {
-  float xhat[4], rstd[4], ln[4];
-};
-
-// LayerNorm over a (the 16 lanes of a row), biased variance, only a < A counts
-__device__ __forceinline__ void layer_norm_rows(const f32x4& av, bool avalid, float inv_a, float eps, float gam, float bet,
-                                                bool use_ln, LnOut& o) {
+// Lane (g,c) of a 16-row block owns 4 consecutive a (a0 = 4g) of row f of an [F][A] slab (`base`, wave-uniform).
+// Loads are branch-free (clamped address + select) so that several of them issue back to back behind one s_waitcnt.
+__device__ __forceinline__ f32x4 load_a4(const float* __restrict__ base, int f, int A, int a0, bool fvalid, bool vecA) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (vecA) {
+    const bool ok = fvalid && a0 < A;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? f * A + a0 : 0));
+    if (ok) v = t;
+  } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (use_ln) {
-      const float v = avalid ? av[r] : 0.f;
-      const float mu = row16_sum(v) * inv_a;
-      const float dv = avalid ? v - mu : 0.f;
-      const float var = row16_sum(dv * dv) * inv_a;
-      const float rstd = 1.0f / sqrtf(var + eps);
-      o.rstd[r] = rstd;
-      o.xhat[r] = dv * rstd;
-      o.ln[r] = o.xhat[r] * gam + bet;
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = fvalid && a0 + s < A;
+      const float t = base[ok ? f * A + a0 + s : 0];
+      if (ok) v[s] = t;
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ void store_a4(float* __restrict__ base, int f, int A, int a0, bool fvalid, bool vecA, const f32x4& v) {
+  if (fvalid) {
+    if (vecA) {
+      if (a0 < A) *reinterpret_cast<f32x4*>(base + f * A + a0) = v;
     } else {
-      o.rstd[r] = 1.f;
-      o.xhat[r] = 0.f;
-      o.ln[r] = av[r];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (a0 + s < A) base[f * A + a0 + s] = v[s];
     }
   }
 }
+
+// workgroup barrier that orders LDS traffic only: global stores and prefetches stay in flight (a __syncthreads() also
+// drains vmcnt).  Inline asm: the waitcnt pass does not look inside, the "memory" clobber pins the compiler's own order.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ================================================================================================= forward
-// y[h,b,f,a] = fuse_relu ? relu(res + ln) : ln ; res_out (optional, !fuse_relu) = x Wr
+// grid = B, block = 64 H.  y[h,b,f,a] = fuse_relu ? relu(res + ln) : ln ; res_out (optional, !fuse_relu) = x Wr
 template <int NC, bool F16>
-__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
-                                                                const float* __restrict__ Wk, const float* __restrict__ Wr,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ y, float* __restrict__ res_out,
-                                                                float* __restrict__ av_out, AttnDims d, float scale, float eps,
-                                                                int fuse_relu) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                    // [FP][XSS]
-  float* kks = smem + d.FP * d.XSS;    // [FP][kRS]
-  const int b = blockIdx.x / d.H, h = blockIdx.x - b * d.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int a = lane & 15, g = lane >> 4;
-  stage_x(x + (long)b * d.F * d.K, xs, d);
-  float wq[NC][4], wk[NC][4], wr[NC][4];
-  load_w<NC>(Wq, h, d, lane, wq);
-  load_w<NC>(Wk, h, d, lane, wk);
-  load_w<NC>(Wr, h, d, lane, wr);
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
+                                                        const float* __restrict__ Wk, const float* __restrict__ Wr,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, float* __restrict__ res_out,
+                                                        float* __restrict__ av_out, AttnDims d, float scale, float eps,
+                                                        int fuse_relu) {
+  typedef typename Prec<F16>::Elem Elem;
+  typedef typename Prec<F16>::Op Op;
+  constexpr int RS = Prec<F16>::RS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
+  const int c = lane & 15, g = lane >> 4;
+  Elem* kimg;
+  XSrc<F16, F16> xsrc;
+  if constexpr (F16) {
+    _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);
+    stage_x_f16(x, xs, d, b, blockDim.x);
+    xsrc.xs = xs;
+    xsrc.FP = d.FP;
+    kimg = xs + d.NC * d.FP * 16 + h * d.FP * RS;
+    __syncthreads();
+  } else {
+    xsrc.x = x;
+    xsrc.set_sample(d, b);
+    kimg = reinterpret_cast<float*>(smem_raw) + h * d.FP * RS;
+  }
+  Op wq[NC], wk[NC], wr[NC];
+  load_w_kin<NC, F16>(Wq, h, d, lane, wq);
+  load_w_kin<NC, F16>(Wk, h, d, lane, wk);
+  load_w_kin<NC, F16>(Wr, h, d, lane, wr);
   const bool use_ln = gamma != nullptr;
-  const bool avalid = a < d.A;
-  const float gam = (use_ln && avalid) ? gamma[a] : 0.f, bet = (use_ln && avalid) ? beta[a] : 0.f;
+  const bool vecA = (d.A & 3) == 0;
   const float inv_a = 1.0f / (float)d.A;
-  __syncthreads();
-  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
-  __syncthreads();
-
-  for (int blk = wave; blk < d.nblk; blk += 4) {
-    float xr[NC][4];
-    load_xfrag<NC>(xs, blk, d, lane, xr);
-    f32x4 qT = proj_T<NC, F16>(xr, wq);
+  f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = {0.f, 0.f, 0.f, 0.f};
+  bool aval[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) qT[r] *= scale;
-    const f32x4 av = attend_block<F16>(kks, qT, d.nblk, lane);
-    LnOut ln;
-    layer_norm_rows(av, avalid, inv_a, eps, gam, bet, use_ln, ln);
-    f32x4 res = {0.f, 0.f, 0.f, 0.f};
-    if (Wr != nullptr) res = proj_rows<NC, F16>(xr, wr);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 16 * blk + 4 * g + r;
-      if (f < d.F && avalid) {
-        const long o = (((long)h * d.B + b) * d.F + f) * d.A + a;
-        if (av_out != nullptr) av_out[o] = av[r];   // saved for the backward (it then skips the score recomputation)
-        if (fuse_relu) {
-          y[o] = fmaxf(res[r] + ln.ln[r], 0.f);
-        } else {
-          y[o] = ln.ln[r];
-          if (res_out != nullptr) res_out[o] = res[r];
-        }
-      }
+  for (int s = 0; s < 4; ++s) {
+    aval[s] = 4 * g + s < d.A;
+    if (use_ln && aval[s]) {
+      gam[s] = gamma[4 * g + s];
+      bet[s] = beta[4 * g + s];
     }
   }
-}
+  project_k<NC, F16>(xsrc, kimg, wk, d.nblk, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 
-// ================================================================================================= backward: pre
-// Recomputes av; fused mode: dz = dy * (res + ln > 0), dres = dz; unfused: dz = dy (grad of ln), dres given separately.
-// Writes dav (LayerNorm backward of dz) and, in fused mode, dres; accumulates dgamma/dbeta partials per workgroup.
-template <int NC, bool F16>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_kernel(
-    const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
-    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ dy, float* __restrict__ dav,
-    float* __restrict__ dres, float* __restrict__ gb_part /* [blocks][2][16] */, AttnDims d, float scale, float eps,
-    int fuse_relu) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;
-  float* kks = smem + d.FP * d.XSS;
-  float* red = kks + d.FP * kRS;       // [4 waves][2][16]
-  const int b = blockIdx.x / d.H, h = blockIdx.x - b * d.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int a = lane & 15, g = lane >> 4;
-  stage_x(x + (long)b * d.F * d.K, xs, d);
-  float wq[NC][4], wk[NC][4], wr[NC][4];
-  load_w<NC>(Wq, h, d, lane, wq);
-  load_w<NC>(Wk, h, d, lane, wk);
-  load_w<NC>(Wr, h, d, lane, wr);
-  const bool use_ln = gamma != nullptr;
-  const bool avalid = a < d.A;
-  const float gam = (use_ln && avalid) ? gamma[a] : 0.f, bet = (use_ln && avalid) ? beta[a] : 0.f;
-  const float inv_a = 1.0f / (float)d.A;
-  __syncthreads();
-  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
-  __syncthreads();
-
-  float dg = 0.f, db = 0.f;
-  for (int blk = wave; blk < d.nblk; blk += 4) {
-    float xr[NC][4];
-    load_xfrag<NC>(xs, blk, d, lane, xr);
-    f32x4 qT = proj_T<NC, F16>(xr, wq);
+  const float qs = -scale * 1.4426950408889634f;
+  const long slab = ((long)h * d.B + b) * d.F * d.A;   // this (head, sample)'s [F][A] rows
+  float* yb = y + slab;
+  float* avb = av_out != nullptr ? av_out + slab : nullptr;
+  float* resb = res_out != nullptr ? res_out + slab : nullptr;
+  for (int i = 0; i < d.nblk; ++i) {
+    Op xr[NC];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) qT[r] *= scale;
-    const f32x4 av = attend_block<F16>(kks, qT, d.nblk, lane);
-    LnOut ln;
-    layer_norm_rows(av, avalid, inv_a, eps, gam, bet, use_ln, ln);
-    f32x4 res = {0.f, 0.f, 0.f, 0.f};
-    if (fuse_relu && Wr != nullptr) res = proj_rows<NC, F16>(xr, wr);
+    for (int cc = 0; cc < NC; ++cc) xr[cc] = xsrc.row(i, cc, lane);
+    f32x4 qT = {0.f, 0.f, 0.f, 0.f}, resT = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 16 * blk + 4 * g + r;
-      const bool valid = f < d.F && avalid;
-      const long o = (((long)h * d.B + b) * d.F + f) * d.A + a;
-      float dz = valid ? dy[o] : 0.f;
-      if (fuse_relu) {
-        if (!(res[r] + ln.ln[r] > 0.f)) dz = 0.f;
-        if (valid && dres != nullptr) dres[o] = dz;
-      }
-      float da = dz;
-      if (use_ln) {
-        dg = fmaf(dz, ln.xhat[r], dg);
-        db += dz;
-        const float dxh = dz * gam;
-        const float m1 = row16_sum(dxh) * inv_a;
-        const float m2 = row16_sum(dxh * ln.xhat[r]) * inv_a;
-        da = ln.rstd[r] * (dxh - m1 - ln.xhat[r] * m2);
-      }
-      if (valid) dav[o] = da;
+    for (int cc = 0; cc < NC; ++cc) qT = mma<F16>(wq[cc], xr[cc], qT);          // [a 4g+r][query c]
+    if (Wr != nullptr) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) resT = mma<F16>(wr[cc], xr[cc], resT);
     }
-  }
-  // dgamma/dbeta: lanes sharing a (4 groups) -> wave -> workgroup, fixed order
-  dg += __shfl_xor(dg, 16); dg += __shfl_xor(dg, 32);
-  db += __shfl_xor(db, 16); db += __shfl_xor(db, 32);
-  if (lane < 16) {
-    red[(wave * 2 + 0) * 16 + lane] = dg;
-    red[(wave * 2 + 1) * 16 + lane] = db;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const int which = threadIdx.x >> 4, aa = threadIdx.x & 15;
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * 16 + aa];
-    gb_part[((long)blockIdx.x * 2 + which) * 16 + aa] = t;
-  }
-}
-
-// ================================================================================================= backward: pre (saved av)
-// Same outputs as attn_bwd_pre_kernel, from the forward's saved av (and, in fused mode, its output y: the ReLU mask
-// is y > 0) instead of recomputing the scores: purely element-wise + 16-lane row reductions, memory-bound.
-// 16 lanes per row [.., a < 16]; a workgroup walks rows with a grid stride; gb_part[block][2][16].
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_pre_saved_kernel(const float* __restrict__ av_s, const float* __restrict__ y_s,
-                                                                         const float* __restrict__ gamma, const float* __restrict__ dy,
-                                                                         float* __restrict__ dav, float* __restrict__ dres,
-                                                                         float* __restrict__ gb_part, long rows, int A, float eps,
-                                                                         int fuse_relu) {
-  __shared__ float red[4][2][16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int a = lane & 15, g = lane >> 4;
-  const bool use_ln = gamma != nullptr;
-  const bool avalid = a < A;
-  const float gam = (use_ln && avalid) ? gamma[a] : 0.f;
-  const float inv_a = 1.0f / (float)A;
-  float dg = 0.f, db = 0.f;
-  const long rpb = 16;  // rows per workgroup pass: 4 waves x 4 lane groups
-  for (long row0 = (long)blockIdx.x * rpb; row0 < rows; row0 += (long)gridDim.x * rpb) {
-    const long row = row0 + wave * 4 + g;
-    const bool valid = row < rows && avalid;
-    const long o = row * A + a;
-    float dz = valid ? dy[o] : 0.f;
-    if (fuse_relu) {
-      if (!(valid && y_s[o] > 0.f)) dz = 0.f;
-      if (valid && dres != nullptr) dres[o] = dz;
-    }
-    float da = dz;
-    if (use_ln) {
-      const float v = valid ? av_s[o] : 0.f;
-      const float mu = row16_sum(v) * inv_a;
-      const float dv = valid ? v - mu : 0.f;
-      const float var = row16_sum(dv * dv) * inv_a;
-      const float rstd = 1.0f / sqrtf(var + eps);
-      const float xhat = dv * rstd;
-      dg = fmaf(dz, xhat, dg);
-      db += dz;
-      const float dxh = dz * gam;
-      const float m1 = row16_sum(dxh) * inv_a;
-      const float m2 = row16_sum(dxh * xhat) * inv_a;
-      da = rstd * (dxh - m1 - xhat * m2);
-    }
-    if (valid) dav[o] = da;
-  }
-  dg += __shfl_xor(dg, 16); dg += __shfl_xor(dg, 32);
-  db += __shfl_xor(db, 16); db += __shfl_xor(db, 32);
-  if (lane < 16) {
-    red[wave][0][lane] = dg;
-    red[wave][1][lane] = db;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const int which = threadIdx.x >> 4, aa = threadIdx.x & 15;
-    gb_part[((long)blockIdx.x * 2 + which) * 16 + aa] = ((red[0][which][aa] + red[1][which][aa]) + red[2][which][aa]) + red[3][which][aa];
-  }
-}
-
-// ================================================================================================= backward: dq
-// key-major orientation: S'[f'][f], dS'[f'][f] = k[f'] . dav[f];  dq_blk = sum_t (dS' S'(1-S') scale)^T k_t
-template <int NC, bool F16>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
-                                                                   const float* __restrict__ Wk, const float* __restrict__ dav,
-                                                                   float* __restrict__ dq, AttnDims d, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;
-  float* kks = smem + d.FP * d.XSS;
-  const int b = blockIdx.x / d.H, h = blockIdx.x - b * d.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int a = lane & 15, g = lane >> 4;
-  stage_x(x + (long)b * d.F * d.K, xs, d);
-  float wq[NC][4], wk[NC][4];
-  load_w<NC>(Wq, h, d, lane, wq);
-  load_w<NC>(Wk, h, d, lane, wk);
-  __syncthreads();
-  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
-  __syncthreads();
-  const float* davh = dav + ((long)h * d.B + b) * d.F * d.A;
-  float* dqh = dq + ((long)h * d.B + b) * d.F * d.A;
-
-  for (int blk = wave; blk < d.nblk; blk += 4) {
-    float xr[NC][4];
-    load_xfrag<NC>(xs, blk, d, lane, xr);
-    f32x4 qT = proj_T<NC, F16>(xr, wq);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) qT[r] *= scale;
-    // B operand of dS': lane (j = f = lane&15, k = g) needs dav[f][4g+s]
-    float dv[4];
-    {
-      const int f = 16 * blk + a;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int aa = 4 * g + s;
-        dv[s] = (f < d.F && aa < d.A) ? davh[(long)f * d.A + aa] : 0.f;
-      }
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const Op qn = to_op<F16>(qT * qs);
+    f32x4 avT = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < d.nblk; ++t) {
-      const float4 kA = lds_row4(kks, 16 * t + a, g);
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f};
-      sc = mma4<F16>(kA.x, kA.y, kA.z, kA.w, qT[0], qT[1], qT[2], qT[3], sc);
-      ds = mma4<F16>(kA.x, kA.y, kA.z, kA.w, dv[0], dv[1], dv[2], dv[3], ds);
-      const float* kb = kks + (16 * t + 4 * g) * kRS + a;
-      float dpre[4];
+      const Op kA = row_read<F16>(kimg, 16 * t + c, g);
+      const Op kT = tr_read<F16>(kimg, 16 * t, lane);
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+      sc = mma<F16>(kA, qn, sc);                                                  // [key 4g+r][query c], times -log2e*scale
+      f32x4 sg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sg[r] = sigmoid_from_neg_log2(sc[r]);
+      avT = mma<F16>(kT, to_op<F16>(sg), avT);                                    // [a 4g+r][query c]
+    }
+    // lane (g,c): av[query 16i+c][a 4g..4g+3]
+    const int f = 16 * i + c;
+    const bool fvalid = f < d.F;
+    f32x4 ln = avT;
+    if (use_ln) {
+      float sum = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sum += aval[s] ? avT[s] : 0.f;
+      const float mu = groups_sum(sum) * inv_a;
+      f32x4 dv;
+      float sq = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float sg = sigmoidf_fast(sc[s]);
-        dpre[s] = ds[s] * sg * (1.f - sg) * scale;
+        dv[s] = aval[s] ? avT[s] - mu : 0.f;
+        sq = fmaf(dv[s], dv[s], sq);
       }
-      acc = mma4<F16>(dpre[0], dpre[1], dpre[2], dpre[3], kb[0], kb[kRS], kb[2 * kRS], kb[3 * kRS], acc);
+      const float rstd = 1.0f / sqrtf(groups_sum(sq) * inv_a + eps);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ln[s] = dv[s] * rstd * gam[s] + bet[s];
     }
+    if (avb != nullptr) store_a4(avb, f, d.A, 4 * g, fvalid, vecA, avT);
+    if (fuse_relu) {
+      f32x4 o;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) o[s] = fmaxf(resT[s] + ln[s], 0.f);
+      store_a4(yb, f, d.A, 4 * g, fvalid, vecA, o);
+    } else {
+      store_a4(yb, f, d.A, 4 * g, fvalid, vecA, ln);
+      if (resb != nullptr) store_a4(resb, f, d.A, 4 * g, fvalid, vecA, resT);
+    }
+  }
+}
+
+// ================================================================================================= backward
+// Persistent: grid = G workgroups of 64 H threads (wave = head), workgroup w takes samples w, w+G, ...   NB = compile-time
+// bound on nblk (the dk accumulators of all key tiles live in registers).
+// LDS: [x image (f16 mode, K <= 32)] [k images: H] [tiles: H x 6] [weight table: 3 x H x NC tiles, built once]
+//   tiles of wave h: 0,1 = dP ping-pong (0 also turns dav);  2+2p / 3+2p = dq / dres of the step with parity p -- they turn
+//   the wave's own fragments AND are the hand-off to the wave that owns a 16-column chunk of dx (sum over the heads in
+//   MFMA accumulators: fixed order, no dx tile in LDS).  The dk part of dx is added in a second visit by the same lanes.
+// Outputs: dx, per-workgroup partials of dWq/dWk/dWr [G][3][K][H][A] and of dgamma/dbeta [G*H][2][16].
+template <int NC, bool F16, int NB>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
+    const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
+    const float* __restrict__ y_s, const float* __restrict__ av_s, float* __restrict__ dx, float* __restrict__ wpart,
+    float* __restrict__ gb_part, AttnDims d, float scale, float eps, int fuse_relu) {
+  typedef typename Prec<F16>::Elem Elem;
+  typedef typename Prec<F16>::Op Op;
+  constexpr int RS = Prec<F16>::RS;
+  constexpr int TS = 16 * RS;               // elements per 16-row tile
+  constexpr bool XL = F16 && NC <= 2;       // x image in LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;   // == H
+  const int c = lane & 15, g = lane >> 4;
+  unsigned char* sp = smem_raw;
+  XSrc<F16, XL> xsrc;
+  _Float16* xs16 = nullptr;
+  if constexpr (XL) {
+    xs16 = reinterpret_cast<_Float16*>(sp);
+    sp += (size_t)d.NC * d.FP * 16 * sizeof(_Float16);
+    xsrc.xs = xs16;
+    xsrc.FP = d.FP;
+  } else {
+    xsrc.x = x;
+  }
+  Elem* kimg0 = reinterpret_cast<Elem*>(sp);
+  Elem* kimg = kimg0 + h * d.FP * RS;
+  sp += (size_t)nw * d.FP * RS * sizeof(Elem);
+  Elem* tiles0 = reinterpret_cast<Elem*>(sp);
+  Elem* tiles = tiles0 + h * 6 * TS;
+  sp += (size_t)nw * 6 * TS * sizeof(Elem);
+  Elem* wtab = reinterpret_cast<Elem*>(sp);     // tile (m, hh, cc) at ((m*nw + hh)*NC + cc)*TS: rows = kin, columns = a
+
+  const bool use_ln = gamma != nullptr, has_res = Wr != nullptr;
+  const bool vecA = (d.A & 3) == 0;
+  const float inv_a = 1.0f / (float)d.A;
+  // ---- weight table: tile[kin][a] = W_m[16cc + kin][hh][a]; row reads give the "reduce over a" fragments, transposing
+  // reads the "reduce over kin" fragments
+  {
+    const float* Wm[3] = {Wq, Wk, Wr};
+    const int ntile = 3 * nw * NC;
+    for (int idx = threadIdx.x; idx < ntile * 64; idx += blockDim.x) {
+      const int tl = idx >> 6, kin_l = (idx >> 2) & 15, a4 = idx & 3;
+      const int m = tl / (nw * NC), rem = tl - m * nw * NC, hh = rem / NC, cc = rem - hh * NC;
+      const int kin = 16 * cc + kin_l;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (Wm[m] != nullptr && kin < d.K) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (4 * a4 + s < d.A) v[s] = Wm[m][((long)kin * d.H + hh) * d.A + 4 * a4 + s];
+      }
+      row_write<F16>(wtab + tl * TS, kin_l, a4, to_op<F16>(v));
+    }
+  }
+  f32x4 gam = {0.f, 0.f, 0.f, 0.f};
+  bool aval[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    aval[s] = 4 * g + s < d.A;
+    if (use_ln && aval[s]) gam[s] = gamma[4 * g + s];
+  }
+  f32x4 dWq[NC], dWk[NC], dWr[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) dWq[cc] = dWk[cc] = dWr[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
+  const float qs = -scale * 1.4426950408889634f;
+  const Elem* wq_t = wtab + ((0 * nw + h) * NC) * TS;
+  const Elem* wk_t = wtab + ((1 * nw + h) * NC) * TS;
+
+  for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+    __syncthreads();   // weight table built / the previous sample's k (dk) images and x image are no longer read
+    if constexpr (XL) {
+      stage_x_f16(x, xs16, d, b, blockDim.x);
+      __syncthreads();
+    } else {
+      xsrc.set_sample(d, b);
+    }
+    {
+      Op wk[NC];
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) wk[cc] = tr_read<F16>(wk_t + cc * TS, 0, lane);
+      project_k<NC, F16>(xsrc, kimg, wk, d.nblk, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4 dk[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long slab = ((long)h * d.B + b) * d.F * d.A;   // this (head, sample)'s [F][A] rows
+    const float* dyb = dy + slab;
+    const float* ysb = fuse_relu ? y_s + slab : nullptr;
+    const float* avb = use_ln ? av_s + slab : nullptr;
+    const float* drb = (!fuse_relu && has_res && dres_in != nullptr) ? dres_in + slab : nullptr;
+
+    // block inputs are fetched one query block ahead (they come from HBM)
+    f32x4 n_dy = load_a4(dyb, c, d.A, 4 * g, c < d.F, vecA);
+    f32x4 n_y = {0.f, 0.f, 0.f, 0.f}, n_av = {0.f, 0.f, 0.f, 0.f}, n_dr = {0.f, 0.f, 0.f, 0.f};
+    if (ysb != nullptr) n_y = load_a4(ysb, c, d.A, 4 * g, c < d.F, vecA);
+    if (avb != nullptr) n_av = load_a4(avb, c, d.A, 4 * g, c < d.F, vecA);
+    if (drb != nullptr) n_dr = load_a4(drb, c, d.A, 4 * g, c < d.F, vecA);
+
+    for (int i = 0; i < d.nblk; ++i) {
+      const int par = i & 1;
+      f32x4 dz = n_dy, dr = n_dr;
+      const f32x4 yv = n_y, avv = n_av;
+      if (i + 1 < d.nblk) {
+        const int fn = 16 * (i + 1) + c;
+        const bool fv = fn < d.F;
+        n_dy = load_a4(dyb, fn, d.A, 4 * g, fv, vecA);
+        if (ysb != nullptr) n_y = load_a4(ysb, fn, d.A, 4 * g, fv, vecA);
+        if (avb != nullptr) n_av = load_a4(avb, fn, d.A, 4 * g, fv, vecA);
+        if (drb != nullptr) n_dr = load_a4(drb, fn, d.A, 4 * g, fv, vecA);
+      }
+      // ---- LayerNorm / ReLU backward of query block i: lane (g,c) owns row f = 16i+c, a = 4g..4g+3
+      if (fuse_relu) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (!(yv[s] > 0.f)) dz[s] = 0.f;
+        dr = dz;
+      }
+      f32x4 dav = dz;
+      if (use_ln) {
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sum += aval[s] ? avv[s] : 0.f;
+        const float mu = groups_sum(sum) * inv_a;
+        f32x4 xh;
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          xh[s] = aval[s] ? avv[s] - mu : 0.f;
+          sq = fmaf(xh[s], xh[s], sq);
+        }
+        const float rstd = 1.0f / sqrtf(groups_sum(sq) * inv_a + eps);
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 dxh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          xh[s] *= rstd;
+          dgam[s] = fmaf(dz[s], xh[s], dgam[s]);
+          dbet[s] += dz[s];
+          dxh[s] = dz[s] * gam[s];
+          s1 += dxh[s];
+          s2 = fmaf(dxh[s], xh[s], s2);
+        }
+        const float m1 = groups_sum(s1) * inv_a, m2 = groups_sum(s2) * inv_a;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dav[s] = aval[s] ? rstd * (dxh[s] - m1 - xh[s] * m2) : 0.f;
+      }
+      const Op dav_r = to_op<F16>(dav);     // row fragments: [query c][a 4g+s]
+      const Op dr_r = to_op<F16>(dr);
+      row_write<F16>(tiles, c, g, dav_r);                       // tile 0
+      if (has_res) row_write<F16>(tiles + (3 + 2 * par) * TS, c, g, dr_r);
+      const Op dav_c = tr_read<F16>(tiles, 0, lane);            // column fragment [query 4g+s][a c]
+      // ---- q_i in both orientations
+      f32x4 qT = {0.f, 0.f, 0.f, 0.f}, qD = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        const Op xr = xsrc.row(i, cc, lane);
+        const Op wq = tr_read<F16>(wq_t + cc * TS, 0, lane);
+        qT = mma<F16>(wq, xr, qT);   // [a 4g+r][query c] -> row fragment of q_i
+        qD = mma<F16>(xr, wq, qD);   // [query 4g+r][a c] -> column fragment of q_i
+      }
+      const Op qn = to_op<F16>(qT * qs);     // scores come out as -log2(e) * scale * q.k
+      const Op qc = to_op<F16>(qD * scale);  // dk += dP^T (scale q)
+      f32x4 dqT = {0.f, 0.f, 0.f, 0.f};
+      // ---- the score tiles, software-pipelined: [reads + S, dS of tile j+1] [sigmoid, dk of tile j] [dq of tile j-1]
+      Op kT_cur, kT_prev = kT_cur = to_op<F16>(f32x4{0.f, 0.f, 0.f, 0.f});
+      f32x4 sc_n = {0.f, 0.f, 0.f, 0.f}, ds_n = {0.f, 0.f, 0.f, 0.f};
+      {
+        const Op kB = row_read<F16>(kimg, c, g);
+        kT_cur = tr_read<F16>(kimg, 0, lane);
+        sc_n = mma<F16>(qn, kB, sc_n);
+        ds_n = mma<F16>(dav_r, kB, ds_n);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j < d.nblk) {
+          const f32x4 sc = sc_n, ds = ds_n;
+          const Op kT_j = kT_cur;
+          if (j + 1 < NB && j + 1 < d.nblk) {
+            const Op kB = row_read<F16>(kimg, 16 * (j + 1) + c, g);   // k[key c][a 4g+s]
+            kT_cur = tr_read<F16>(kimg, 16 * (j + 1), lane);          // k[key 4g+s][a c]
+            sc_n = mma<F16>(qn, kB, f32x4{0.f, 0.f, 0.f, 0.f});       // [query 4g+r][key c]
+            ds_n = mma<F16>(dav_r, kB, f32x4{0.f, 0.f, 0.f, 0.f});    // dS = dav k^T
+          }
+          f32x4 sg, dp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sg[r] = sigmoid_from_neg_log2(sc[r]);
+            dp[r] = ds[r] * fmaf(-sg[r], sg[r], sg[r]);       // dS S (1-S); the 1/sqrt(A) factor rides on qc and dq
+          }
+          const Op dp_o = to_op<F16>(dp), sg_o = to_op<F16>(sg);
+          if (j > 0) {
+            const Op dpT = tr_read<F16>(tiles + ((j - 1) & 1) * TS, 0, lane);   // dP[query c][key 4g+s] of tile j-1
+            dqT = mma<F16>(kT_prev, dpT, dqT);                // dq^T[a 4g+r][query c] += k^T dP^T
+          }
+          row_write<F16>(tiles + (j & 1) * TS, c, g, dp_o);   // [key c][query 4g..4g+3]
+          dk[j] = mma<F16>(qc, dp_o, dk[j]);                  // dk^T[a 4g+r][key c] += (scale q)^T dP
+          dk[j] = mma<F16>(dav_c, sg_o, dk[j]);               //                     += dav^T S      (V == K)
+          kT_prev = kT_j;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const Op dpT = tr_read<F16>(tiles + ((d.nblk - 1) & 1) * TS, 0, lane);
+        dqT = mma<F16>(kT_prev, dpT, dqT);
+      }
+      const Op dq_r = to_op<F16>(dqT * scale);                // row fragment of dq_i
+      Elem* t_dq = tiles + (2 + 2 * par) * TS;
+      row_write<F16>(t_dq, c, g, dq_r);
+      const Op dq_c = tr_read<F16>(t_dq, 0, lane);
+      Op dr_c = dr_r;
+      if (has_res) dr_c = tr_read<F16>(tiles + (3 + 2 * par) * TS, 0, lane);
+      // ---- dW += x_i^T d*
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        const Op xc = xsrc.col(i, cc, lane);                  // x[query 4g+s][kin c]
+        dWq[cc] = mma<F16>(xc, dq_c, dWq[cc]);                // [kin 4g+r][a c]
+        if (has_res) dWr[cc] = mma<F16>(xc, dr_c, dWr[cc]);
+      }
+      lds_barrier();   // every head's dq / dres tile of this step is in LDS
+      // ---- dx_i[:, 16cc..] = sum_heads dq Wq^T + dres Wr^T, by the wave that owns chunk cc
+      for (int cc = h; cc < NC; cc += nw) {
+        f32x4 px = {0.f, 0.f, 0.f, 0.f};
+        for (int hh = 0; hh < nw; ++hh) {
+          const Elem* th = tiles0 + (hh * 6 + 2 + 2 * par) * TS;
+          px = mma<F16>(row_read<F16>(th, c, g), row_read<F16>(wtab + ((0 * nw + hh) * NC + cc) * TS, c, g), px);
+          if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), row_read<F16>(wtab + ((2 * nw + hh) * NC + cc) * TS, c, g), px);
+        }
+        const int kin = 16 * cc + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * i + 4 * g + r;
+          if (f < d.F && kin < d.K) dx[x_off(d, b, f, kin)] = px[r];      // [query 4g+r][kin c]
+        }
+      }
+    }
+    // ---- dk of this head: accumulators -> the (now dead) k image as row fragments [key][a]
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
+    lds_barrier();
+    for (int j = 0; j < d.nblk; ++j) {
+      const Op dk_c = tr_read<F16>(kimg, 16 * j, lane);       // dk[key 4g+s][a c]
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) dWk[cc] = mma<F16>(xsrc.col(j, cc, lane), dk_c, dWk[cc]);
+      for (int cc = h; cc < NC; cc += nw) {
+        f32x4 px = {0.f, 0.f, 0.f, 0.f};
+        for (int hh = 0; hh < nw; ++hh)
+          px = mma<F16>(row_read<F16>(kimg0 + hh * d.FP * RS, 16 * j + c, g),
+                        row_read<F16>(wtab + ((1 * nw + hh) * NC + cc) * TS, c, g), px);
+        const int kin = 16 * cc + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * j + 4 * g + r;
+          if (f < d.F && kin < d.K) dx[x_off(d, b, f, kin)] += px[r];     // the lanes that wrote the dq part add the dk part
+        }
+      }
+    }
+  }
+  // ---- per-workgroup partials of the parameter gradients
+  float* wp = wpart + (long)blockIdx.x * 3 * d.K * d.H * d.A;
+  const long wstride = (long)d.K * d.H * d.A;
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int f = 16 * blk + 4 * g + r;
-      if (f < d.F && a < d.A) dqh[(long)f * d.A + a] = acc[r];
+      const int kin = 16 * cc + 4 * g + r;
+      if (kin < d.K && c < d.A) {
+        const long o = ((long)kin * d.H + h) * d.A + c;
+        wp[o] = dWq[cc][r];
+        wp[wstride + o] = dWk[cc][r];
+        wp[2 * wstride + o] = dWr[cc][r];
+      }
+    }
+  if (use_ln) {
+    // lane (g,c) holds partial sums for a = 4g+s over its queries: sum the 16 lanes of the row
+    float* gp = gb_part + ((long)blockIdx.x * nw + h) * 32;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float tg = row16_allsum(dgam[s]), tb = row16_allsum(dbet[s]);
+      if (c == 0) {
+        gp[4 * g + s] = tg;
+        gp[16 + 4 * g + s] = tb;
+      }
     }
   }
 }
 
-// ================================================================================================= backward: dk
-// query-major orientation: S[f][f'], dS[f][f'] = dav[f] . k[f'];  waves split the key tiles.
-//   dk_t = sum_blk (dS S(1-S) scale)^T q_blk + S^T dav_blk
-template <int NC, bool F16>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dk_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
-                                                                   const float* __restrict__ Wk, const float* __restrict__ dav,
-                                                                   float* __restrict__ dk, AttnDims d, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;
-  float* kks = smem + d.FP * d.XSS;
-  float* qs = kks + d.FP * kRS;
-  float* davs = qs + d.FP * kRS;
-  const int b = blockIdx.x / d.H, h = blockIdx.x - b * d.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int a = lane & 15, g = lane >> 4;
-  stage_x(x + (long)b * d.F * d.K, xs, d);
-  const float* davh = dav + ((long)h * d.B + b) * d.F * d.A;
-  for (int idx = threadIdx.x; idx < d.FP * 16; idx += kAttnThreads) {
-    const int f = idx >> 4, aa = idx & 15;
-    davs[f * kRS + aa] = (f < d.F && aa < d.A) ? davh[(long)f * d.A + aa] : 0.f;
-  }
-  float wq[NC][4], wk[NC][4];
-  load_w<NC>(Wq, h, d, lane, wq);
-  load_w<NC>(Wk, h, d, lane, wk);
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wq[c][s] *= scale;  // q pre-scaled: scores = (scale q) . k
-  __syncthreads();
-  project_all<NC, F16>(xs, kks, wk, d, wave, lane);
-  project_all<NC, F16>(xs, qs, wq, d, wave, lane);
-  __syncthreads();
-  float* dkh = dk + ((long)h * d.B + b) * d.F * d.A;
-
-  for (int t = wave; t < d.nblk; t += 4) {
-    const float4 kB = lds_row4(kks, 16 * t + a, g);  // B operand: lane (j = f' = lane&15, k = g): k[f'][4g+s]
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int blk = 0; blk < d.nblk; ++blk) {
-      const float4 qA = lds_row4(qs, 16 * blk + a, g);     // A: (scale q)[f][4g+s]
-      const float4 dA = lds_row4(davs, 16 * blk + a, g);   // A: dav[f][4g+s]
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f};
-      sc = mma4<F16>(qA.x, qA.y, qA.z, qA.w, kB.x, kB.y, kB.z, kB.w, sc);
-      ds = mma4<F16>(dA.x, dA.y, dA.z, dA.w, kB.x, kB.y, kB.z, kB.w, ds);
-      // accumulators: row <-> f = 16 blk + 4g + r, col <-> f' = lane&15
-      const float* qb = qs + (16 * blk + 4 * g) * kRS + a;
-      const float* db = davs + (16 * blk + 4 * g) * kRS + a;
-      float sgv[4], dpre[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sgv[s] = sigmoidf_fast(sc[s]);
-        // qs holds scale*q: dpre (without the scale factor) times (scale q) == (dpre with scale) times q
-        dpre[s] = ds[s] * sgv[s] * (1.f - sgv[s]);
-      }
-      acc = mma4<F16>(dpre[0], dpre[1], dpre[2], dpre[3], qb[0], qb[kRS], qb[2 * kRS], qb[3 * kRS], acc);
-      acc = mma4<F16>(sgv[0], sgv[1], sgv[2], sgv[3], db[0], db[kRS], db[2 * kRS], db[3 * kRS], acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = 16 * t + 4 * g + r;
-      if (f < d.F && a < d.A) dkh[(long)f * d.A + a] = acc[r];
-    }
-  }
-}
-
-// ================================================================================================= backward: projections
-// rows R = B*F; D_j[row][h][a] for j in {dq, dk, dres};  dx[row][k] = sum_{j,h,a} D_j W_j[k][h][a];
-// dW_j[k][h][a] = sum_row x[row][k] D_j[row][h][a]  (workgroup partials over a chunk of rows, reduced afterwards).
-// One workgroup processes `rows_per_block` rows in tiles of 32 rows staged in LDS.
-constexpr int kProjTile = 32;
-
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
-                                                                     const float* __restrict__ Wk, const float* __restrict__ Wr,
-                                                                     const float* __restrict__ dq, const float* __restrict__ dk,
-                                                                     const float* __restrict__ dr, float* __restrict__ dx,
-                                                                     float* __restrict__ wpart /* [blocks][NJ][K][HA] */,
-                                                                     AttnDims d, int rows_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int HA = d.H * d.A;
-  const int NJ = dr != nullptr ? 3 : 2;
-  const int DW = NJ * HA;               // concatenated gradient width
-  const int DS = DW + 1;                // LDS row stride (odd)
-  const int KS = d.K + 1;
-  float* Wc = smem;                     // [K][DW]   concatenated weights  W_j[k][h*A+a]
-  float* Dt = Wc + d.K * DW;            // [tile][DS]
-  float* Xt = Dt + kProjTile * DS;      // [tile][KS]
-  const long R = (long)d.B * d.F;
-  const long row_lo = (long)blockIdx.x * rows_per_block;
-  const long row_hi = min(R, row_lo + rows_per_block);
-  const float* Wj[3] = {Wq, Wk, Wr};
-  const float* Dj[3] = {dq, dk, dr};
-  for (int idx = threadIdx.x; idx < d.K * DW; idx += kAttnThreads) {
-    const int k = idx / DW, c = idx - k * DW;
-    const int j = c / HA, ha = c - j * HA;
-    Wc[idx] = Wj[j][(long)k * HA + ha];
-  }
-  // dW accumulators: thread <-> (k = tid % K?, column group).  Outputs K*DW, dealt round-robin: o = tid + 256*u
-  constexpr int kMaxOut = 48;           // K*DW <= 64*768 would be too many; host restricts K*DW <= 256*kMaxOut
-  float acc[kMaxOut];
-#pragma unroll
-  for (int u = 0; u < kMaxOut; ++u) acc[u] = 0.f;
-  const int nout = d.K * DW;
-  __syncthreads();
-
-  for (long r0 = row_lo; r0 < row_hi; r0 += kProjTile) {
-    const int nr = (int)min((long)kProjTile, row_hi - r0);
-    // stage D tile: D_j[h][row][a] -> Dt[row][j*HA + h*A + a]
-    for (int idx = threadIdx.x; idx < kProjTile * DW; idx += kAttnThreads) {
-      const int row = idx / DW, c = idx - row * DW;
-      float v = 0.f;
-      if (row < nr) {
-        const int j = c / HA, ha = c - j * HA;
-        const int hh = ha / d.A, aa = ha - hh * d.A;
-        v = Dj[j][((long)hh * R + (r0 + row)) * d.A + aa];
-      }
-      Dt[row * DS + c] = v;
-    }
-    for (int idx = threadIdx.x; idx < kProjTile * d.K; idx += kAttnThreads) {
-      const int row = idx / d.K, k = idx - row * d.K;
-      Xt[row * KS + k] = row < nr ? x[(r0 + row) * d.K + k] : 0.f;
-    }
-    __syncthreads();
-    // dx[row][k] = sum_c Dt[row][c] Wc[k][c]
-    for (int idx = threadIdx.x; idx < kProjTile * d.K; idx += kAttnThreads) {
-      const int row = idx / d.K, k = idx - row * d.K;
-      if (row < nr) {
-        const float* dp = Dt + row * DS;
-        const float* wp = Wc + k * DW;
-        float t = 0.f;
-        for (int c = 0; c < DW; ++c) t = fmaf(dp[c], wp[c], t);
-        dx[(r0 + row) * d.K + k] = t;
-      }
-    }
-    // dW[k][c] += sum_row Xt[row][k] Dt[row][c]
-#pragma unroll
-    for (int u = 0; u < kMaxOut; ++u) {
-      const int o = threadIdx.x + u * kAttnThreads;
-      if (o < nout) {
-        const int k = o / DW, c = o - k * DW;
-        float t = acc[u];
-        for (int row = 0; row < kProjTile; ++row) t = fmaf(Xt[row * KS + k], Dt[row * DS + c], t);
-        acc[u] = t;
-      }
-    }
-    __syncthreads();
-  }
-  float* wp = wpart + (long)blockIdx.x * nout;
-#pragma unroll
-  for (int u = 0; u < kMaxOut; ++u) {
-    const int o = threadIdx.x + u * kAttnThreads;
-    if (o < nout) wp[o] = acc[u];
-  }
-}
-
-// MFMA form of the projection backward (used when NJ*H*NC <= kProjMaxSeg).  A wave walks 16-row tiles of the
-// flattened rows R = B*F; per (j,h) segment it issues
-//   dx_tile [16 x K]  += D_seg [16 x A] W_seg^T [A x K]     (A operand: D rows, 16-byte loads; B: W_seg from LDS)
-//   dW_seg  [K x A]   += x_tile^T [K x 16] D_seg [16 x A]   (A operand: x columns; B: D columns)
-// and keeps the dW accumulators in registers across all its tiles (per-wave partials, reduced afterwards).
-constexpr int kProjMaxSeg = 24;
-
-template <int NC, bool F16>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_proj3_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
-                                                                      const float* __restrict__ Wk, const float* __restrict__ Wr,
-                                                                      const float* __restrict__ dq, const float* __restrict__ dk,
-                                                                      const float* __restrict__ dr, float* __restrict__ dx,
-                                                                      float* __restrict__ wpart, AttnDims d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // Wl[NS][16*NC][kRS]
-  const int NJ = dr != nullptr ? 3 : 2;
-  const int NS = NJ * d.H, HA = d.H * d.A, DW = NJ * HA;
-  const long R = (long)d.B * d.F;
-  const float* Wj[3] = {Wq, Wk, Wr};
-  const float* Dj[3] = {dq, dk, dr};
-  for (int idx = threadIdx.x; idx < NS * 16 * NC * 16; idx += kAttnThreads) {
-    const int a = idx & 15, k = (idx >> 4) % (16 * NC), sg = idx / (16 * NC * 16);
-    const int j = sg / d.H, h = sg - j * d.H;
-    smem[(sg * 16 * NC + k) * kRS + a] = (k < d.K && a < d.A) ? Wj[j][((long)k * d.H + h) * d.A + a] : 0.f;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  float* tsc = smem + NS * 16 * NC * kRS + wave * (2 * 16 * kRS);   // per-wave transpose tiles (behind the staged weights)
-  f32x4 accw[kProjMaxSeg];
-#pragma unroll
-  for (int u = 0; u < kProjMaxSeg; ++u) accw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long ntiles = (R + 15) / 16;
-  const int wglob = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-  for (long tile = wglob; tile < ntiles; tile += nw) {
-    const long r0 = tile * 16;
-    float xa[NC][4];
-#pragma unroll
-    for (int kt = 0; kt < NC; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const long row = r0 + 4 * g + s2;
-        const int k = 16 * kt + li;
-        xa[kt][s2] = (row < R && k < d.K) ? x[row * d.K + k] : 0.f;
-      }
-    f32x4 accx[NC];
-#pragma unroll
-    for (int kt = 0; kt < NC; ++kt) accx[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const long rowi = r0 + li;
-#pragma unroll
-    for (int sgk = 0; sgk < kProjMaxSeg / NC; ++sgk) {
-      if (sgk < NS) {
-        const int j = sgk / d.H, h = sgk - j * d.H;
-        const float* Dp = Dj[j] + (long)h * R * d.A;
-        // the 16x16 block D[r0..r0+15][0..15] is needed in both orientations (dv: lane's row li, columns 4g..4g+3;
-        // dc: rows 4g..4g+3, lane's column li).  It is read from memory once (dv) and turned through a per-wave LDS
-        // tile for dc: reading it twice made this kernel move 1.26 GB per call at one wave per SIMD.
-        float dv[4], dc[4];
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          const int a = 4 * g + s2;
-          dv[s2] = (rowi < R && a < d.A) ? Dp[rowi * d.A + a] : 0.f;
-        }
-        float* tw = tsc + (sgk & 1) * (16 * kRS);   // two tiles: the next segment's write cannot hit this one's reads
-        *reinterpret_cast<float4*>(tw + li * kRS + 4 * g) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) dc[s2] = tw[(4 * g + s2) * kRS + li];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int kt = 0; kt < NC; ++kt) {
-          const float4 wb = *reinterpret_cast<const float4*>(smem + (sgk * 16 * NC + 16 * kt + li) * kRS + 4 * g);
-          accx[kt] = mma4<F16>(dv[0], dv[1], dv[2], dv[3], wb.x, wb.y, wb.z, wb.w, accx[kt]);
-          f32x4& aw = accw[sgk * NC + kt];
-          aw = mma4<F16>(xa[kt][0], xa[kt][1], xa[kt][2], xa[kt][3], dc[0], dc[1], dc[2], dc[3], aw);
-        }
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < NC; ++kt)
-#pragma unroll
-      for (int r2 = 0; r2 < 4; ++r2) {
-        const long row = r0 + 4 * g + r2;
-        const int k = 16 * kt + li;
-        if (row < R && k < d.K) dx[row * d.K + k] = accx[kt][r2];
-      }
-  }
-  float* wp = wpart + (long)wglob * d.K * DW;
-#pragma unroll
-  for (int sgk = 0; sgk < kProjMaxSeg / NC; ++sgk) {
-    if (sgk < NS) {
-#pragma unroll
-      for (int kt = 0; kt < NC; ++kt)
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2) {
-          const int k = 16 * kt + 4 * g + r2;
-          if (k < d.K && li < d.A) wp[(long)k * DW + sgk * d.A + li] = accw[sgk * NC + kt][r2];
-        }
-    }
-  }
-}
-
-// out[i] = sum_p part[p*n + i]  (fixed order): 64 outputs per workgroup, the 4 waves take every 4th partial
-__global__ __launch_bounds__(256) void attn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts) {
+// out_j[i] = sum_p part[(p*NJ + j)*n + i]  (fixed order): 64 outputs per workgroup, the 4 waves take every 4th partial
+__global__ __launch_bounds__(256) void attn_reduce_dw_kernel(const float* __restrict__ part, float* __restrict__ o0,
+                                                             float* __restrict__ o1, float* __restrict__ o2, int n, int parts) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
+  const int i = blockIdx.x * 64 + lane, j = blockIdx.y;
+  float* out = j == 0 ? o0 : (j == 1 ? o1 : o2);
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   if (i < n) {
+    const float* p0 = part + (long)j * n + i;
+    const long ps = 3L * n;
     int p = wave;
     for (; p + 12 < parts; p += 16) {
-      t0 += part[(long)p * n + i];
-      t1 += part[(long)(p + 4) * n + i];
-      t2 += part[(long)(p + 8) * n + i];
-      t3 += part[(long)(p + 12) * n + i];
+      t0 += p0[(long)p * ps];
+      t1 += p0[(long)(p + 4) * ps];
+      t2 += p0[(long)(p + 8) * ps];
+      t3 += p0[(long)(p + 12) * ps];
     }
-    for (; p < parts; p += 4) t0 += part[(long)p * n + i];
+    for (; p < parts; p += 4) t0 += p0[(long)p * ps];
   }
   red[wave][lane] = (t0 + t1) + (t2 + t3);
   __syncthreads();
-  if (wave == 0 && i < n) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-}
-
-// splits the reduced [NJ][K][HA]-as-[K][DW] buffer into dWq, dWk, dWr ([K][H][A] each)
-__global__ __launch_bounds__(256) void attn_split_dw_kernel(const float* __restrict__ red, float* __restrict__ dWq,
-                                                            float* __restrict__ dWk, float* __restrict__ dWr, int K, int HA, int NJ) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int DW = NJ * HA;
-  if (i >= K * DW) return;
-  const int k = i / DW, c = i - k * DW;
-  const int j = c / HA, ha = c - j * HA;
-  float* dst = j == 0 ? dWq : (j == 1 ? dWk : dWr);
-  dst[(long)k * HA + ha] = red[i];
+  if (wave == 0 && i < n && out != nullptr) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // dgamma/dbeta: sum the [blocks][2][16] partials; one workgroup per output, strided partial sums + fixed-order tree
@@ -741,45 +756,82 @@ __global__ __launch_bounds__(256) void attn_reduce_gb_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------- host
-static int make_dims(const char* fn, int B, int F, int K, int H, int A, AttnDims& d) {
+static int make_dims(const char* fn, int B, int F, int K, int H, int A, int x_chunk, AttnDims& d) {
   if (B < 0 || F < 1 || K < 1 || H < 1 || A < 1) return fail(FIL_ERR_ARG, "%s: bad shape B=%d F=%d K=%d H=%d A=%d", fn, B, F, K, H, A);
   if (K > 16 * kMaxNC) return fail(FIL_ERR_UNSUPPORTED, "%s: K=%d > %d", fn, K, 16 * kMaxNC);
   if (A > 16) return fail(FIL_ERR_UNSUPPORTED, "%s: attention_dim A=%d > 16", fn, A);
+  if (H > kMaxHeads) return fail(FIL_ERR_UNSUPPORTED, "%s: H=%d > %d heads", fn, H, kMaxHeads);
   if (F > 512) return fail(FIL_ERR_UNSUPPORTED, "%s: F=%d > 512 fields", fn, F);
+  if (x_chunk < 0 || (x_chunk > 0 && K % x_chunk != 0)) return fail(FIL_ERR_ARG, "%s: x_chunk=%d does not divide K=%d", fn, x_chunk, K);
   d.B = B; d.F = F; d.K = K; d.H = H; d.A = A;
   d.nblk = cdiv(F, 16);
   d.FP = 16 * d.nblk;
   d.NC = cdiv(K, 16);
-  d.XSS = 16 * d.NC + 4;
+  d.xcw = x_chunk > 0 ? x_chunk : K;
+  d.xcs = x_chunk > 0 ? (long)B * F * x_chunk : 0;
   return FIL_OK;
 }
 
-static int proj_rows_per_block(const AttnDims& d) {
-  const long R = (long)d.B * d.F;
-  long rpb = cdiv((int)std::min<long>(R, 1L << 30), 1024);
-  rpb = std::max<long>(kProjTile, (rpb + kProjTile - 1) / kProjTile * kProjTile);
-  return (int)rpb;
+static size_t fwd_lds(const AttnDims& d, bool f16) {
+  return f16 ? ((size_t)d.NC * d.FP * 16 + (size_t)d.H * d.FP * 16) * sizeof(_Float16) : (size_t)d.H * d.FP * 20 * sizeof(float);
 }
-static int proj_blocks(const AttnDims& d) { return (int)(((long)d.B * d.F + proj_rows_per_block(d) - 1) / proj_rows_per_block(d)); }
-static bool proj_mfma_ok(const AttnDims& d) { return 3 * d.H * d.NC <= kProjMaxSeg; }
-static int proj3_blocks(const AttnDims& d) {
-  const char* e = getenv("FIL_ATTN_PROJ_BLOCKS");   // tuning knob (results identical up to the partial-sum order)
-  const long cap = e != nullptr && atoi(e) > 0 ? atoi(e) : 512;
-  return (int)std::max<long>(1, std::min<long>(((long)d.B * d.F + 63) / 64, cap));
+static size_t bwd_lds(const AttnDims& d, bool f16) {
+  const size_t tiles = (size_t)d.H * 6 + 3 * (size_t)d.H * d.NC;   // per-wave tiles + the weight table
+  if (f16) {
+    const size_t ximg = d.NC <= 2 ? (size_t)d.NC * d.FP * 16 : 0;
+    return (ximg + (size_t)d.H * d.FP * 16 + tiles * 256) * sizeof(_Float16);
+  }
+  return ((size_t)d.H * d.FP * 20 + tiles * 320) * sizeof(float);
 }
-static int proj_parts(const AttnDims& d) { return proj_mfma_ok(d) ? 4 * proj3_blocks(d) : proj_blocks(d); }
+constexpr size_t kLdsCap = 160 * 1024;
+constexpr int kMaxBwdGrid = 1024;   // persistent workgroups (the workspace holds this many partial sums)
 
-static size_t attn_bwd_ws(const AttnDims& d) {
-  const size_t act = align_up((size_t)d.H * d.B * d.F * d.A * sizeof(float), 256);
-  size_t t = 4 * act;                                                                  // dav, dres, dq, dk
-  t += align_up((size_t)d.B * d.H * 2 * 16 * sizeof(float), 256);                       // dgamma/dbeta partials
-  t += align_up((size_t)(proj_parts(d) + 1) * 3 * d.K * d.H * d.A * sizeof(float), 256);  // dW partials + reduced
+// persistent backward grid: `per_cu` resident workgroups on each of the 256 CUs, sized so that every workgroup takes the
+// same number of samples (+-1)
+static int bwd_grid(const AttnDims& d, int per_cu) {
+  const long cap = std::min<long>(kMaxBwdGrid, 256L * std::max(1, per_cu));
+  const long rounds = ((long)d.B + cap - 1) / cap;
+  return (int)std::max<long>(1, ((long)d.B + rounds - 1) / std::max<long>(rounds, 1));
+}
+
+static size_t attn_bwd_ws(const AttnDims& d, bool have_saved) {
+  const long G = std::min<long>(kMaxBwdGrid, std::max(d.B, 1));
+  size_t t = align_up((size_t)G * 3 * d.K * d.H * d.A * sizeof(float), 256);       // dW partials
+  t += align_up((size_t)G * d.H * 32 * sizeof(float), 256);                         // dgamma/dbeta partials
+  if (!have_saved) t += 2 * align_up((size_t)d.H * d.B * d.F * d.A * sizeof(float), 256);   // av / y recomputed
   return t;
 }
 
 template <typename KernelT>
-static void allow_lds_attn(KernelT kernel, size_t sh) {
-  if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+static int allow_lds_attn(KernelT kernel, size_t sh) {
+  if (sh > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      (void)hipGetLastError();
+      return FIL_ERR_HIP;
+    }
+  }
+  return FIL_OK;
+}
+
+// resident workgroups per CU of a kernel at this block size / dynamic LDS size (register-, LDS- and wave-limited);
+// asked once per (kernel, launch shape) and remembered: the launch path stays free of runtime queries
+template <typename KernelT>
+static int resident_blocks(KernelT kernel, int threads, size_t sh) {
+  struct Memo { const void* k; int threads; size_t sh; int n; };
+  static Memo memo[64];
+  static int used = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  const void* key = reinterpret_cast<const void*>(kernel);
+  for (int i = 0; i < used; ++i)
+    if (memo[i].k == key && memo[i].threads == threads && memo[i].sh == sh) return memo[i].n;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, sh) != hipSuccess || n < 1) {
+    (void)hipGetLastError();
+    n = 1;
+  }
+  if (used < 64) memo[used++] = Memo{key, threads, sh, n};
+  return n;
 }
 
 // CALL(NC, F16) for the runtime (NC, precision) pair; `f16` must be in scope
@@ -791,25 +843,44 @@ static void allow_lds_attn(KernelT kernel, size_t sh) {
     case 4: { if (f16) { CALL(4, true); } else { CALL(4, false); } } break;  \
   }
 
+static int launch_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma, const float* beta,
+                      float* y, float* res_out, float* av_out, const AttnDims& d, float scale, float eps, int fuse_relu,
+                      bool f16, hipStream_t st) {
+  const size_t sh = fwd_lds(d, f16);
+  if (sh > kLdsCap) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_fwd: F=%d K=%d H=%d needs %zu bytes of LDS (> 160 KiB)", d.F, d.K, d.H, sh);
+  const dim3 grid(d.B), block(64 * d.H);
+  int rc = FIL_OK;
+#define CALL_FWD(N, P)                                                                                                     \
+  rc = allow_lds_attn(attn_fwd_kernel<N, P>, sh);                                                                          \
+  if (rc == FIL_OK)                                                                                                        \
+    hipLaunchKernelGGL((attn_fwd_kernel<N, P>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, d,   \
+                       scale, eps, fuse_relu)
+  FIL_ATTN_NC(d.NC, CALL_FWD)
+#undef CALL_FWD
+  if (rc != FIL_OK) return fail(rc, "fil_attn_fwd: cannot reserve %zu bytes of LDS", sh);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
 }  // namespace fil
 
 using namespace fil;
 
 extern "C" size_t fil_attn_fwd_workspace_bytes(int, int, int, int, int) { return 0; }
 
-extern "C" size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A) {
+extern "C" size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved) {
   AttnDims d;
-  if (make_dims("fil_attn_bwd_workspace_bytes", B, F, K, H, A, d) != FIL_OK || B == 0) return 0;
-  return attn_bwd_ws(d);
+  if (make_dims("fil_attn_bwd_workspace_bytes", B, F, K, H, A, 0, d) != FIL_OK || B == 0) return 0;
+  return attn_bwd_ws(d, have_saved != 0);
 }
 
 extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                             const float* beta, float* y, float* res_out, float* av_out, int B, int F, int K, int H, int A,
-                            float scale, float eps, int fuse_relu, int precision, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   (void)workspace; (void)workspace_bytes;
   AttnDims d;
-  int rc = make_dims("fil_attn_fwd", B, F, K, H, A, d);
+  int rc = make_dims("fil_attn_fwd", B, F, K, H, A, x_chunk, d);
   if (rc != FIL_OK) return rc;
   if (precision != FIL_PREC_F32 && precision != FIL_PREC_F16_MFMA) return fail(FIL_ERR_ARG, "fil_attn_fwd: precision=%d", precision);
   const bool f16 = precision == FIL_PREC_F16_MFMA;
@@ -817,28 +888,18 @@ extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, co
   FIL_CHECK_ARG(x && Wq && Wk && y);
   FIL_CHECK_ARG((gamma == nullptr) == (beta == nullptr));
   hipStream_t st = (hipStream_t)stream;
-  const size_t sh = ((size_t)d.FP * d.XSS + (size_t)d.FP * kRS) * sizeof(float);
-  if (sh > 160 * 1024) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_fwd: F=%d K=%d needs %zu bytes of LDS (> 160 KiB)", F, K, sh);
-  const dim3 grid(B * H);
-  // flops: projections 2*F*K*A*(2 or 3) + scores and weighted sum 2*2*F*F*A, per (b,h)
+  // algorithmic flops: projections 2*F*K*A*(2 or 3) + scores and weighted sum 2*2*F*F*A, per (b,h)
   ProfScope ps("attn_fwd", st, (double)B * H * (2.0 * F * K * A * (Wr ? 3 : 2) + 4.0 * F * (double)F * A));
-#define CALL_FWD(N, P)                                                                                                     \
-  allow_lds_attn(attn_fwd_kernel<N, P>, sh);                                                                               \
-  hipLaunchKernelGGL((attn_fwd_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, \
-                     av_out, d, scale, eps, fuse_relu)
-  FIL_ATTN_NC(d.NC, CALL_FWD)
-#undef CALL_FWD
-  FIL_CHECK_LAUNCH();
-  return FIL_OK;
+  return launch_fwd(x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, d, scale, eps, fuse_relu, f16, st);
 }
 
 extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                             const float* beta, const float* dy, const float* dres_in, const float* y_saved,
                             const float* av_saved, float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta,
                             int B, int F, int K, int H, int A, float scale, float eps, int fuse_relu, int precision,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            int x_chunk, void* workspace, size_t workspace_bytes, void* stream) {
   AttnDims d;
-  int rc = make_dims("fil_attn_bwd", B, F, K, H, A, d);
+  int rc = make_dims("fil_attn_bwd", B, F, K, H, A, x_chunk, d);
   if (rc != FIL_OK) return rc;
   if (precision != FIL_PREC_F32 && precision != FIL_PREC_F16_MFMA) return fail(FIL_ERR_ARG, "fil_attn_bwd: precision=%d", precision);
   const bool f16 = precision == FIL_PREC_F16_MFMA;
@@ -857,96 +918,61 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     return FIL_OK;
   }
   FIL_CHECK_ARG(x && dy && dx);
-  if (workspace == nullptr || workspace_bytes < attn_bwd_ws(d))
-    return fail(FIL_ERR_WORKSPACE, "fil_attn_bwd: workspace %zu < %zu bytes", workspace_bytes, attn_bwd_ws(d));
-  // unfused mode: the residual branch's gradient arrives separately (dres_in); fused: produced by the pre kernel
+  // the LayerNorm backward needs av, the fused ReLU mask needs y: whatever the caller did not keep is recomputed
+  const bool need_av = gamma != nullptr && av_saved == nullptr, need_y = fuse_relu && y_saved == nullptr;
+  const size_t need_ws = attn_bwd_ws(d, !(need_av || need_y));
+  if (workspace == nullptr || workspace_bytes < need_ws)
+    return fail(FIL_ERR_WORKSPACE, "fil_attn_bwd: workspace %zu < %zu bytes", workspace_bytes, need_ws);
+  // unfused mode: the residual branch's gradient arrives separately (dres_in)
   const bool has_res = Wr != nullptr;
   if (!fuse_relu && has_res && dres_in == nullptr) return fail(FIL_ERR_ARG, "fil_attn_bwd: dres is required when fuse_relu == 0 and Wr != NULL");
-  const int NJ = has_res ? 3 : 2;
-  if ((long)K * NJ * H * A > 256L * 48) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: K*%d*H*A = %ld > 12288", NJ, (long)K * NJ * H * A);
+  const size_t sh = bwd_lds(d, f16);
+  if (sh > kLdsCap)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: F=%d K=%d H=%d needs %zu bytes of LDS (> 160 KiB)%s", F, K, H, sh,
+                f16 ? "" : "; the f16-MFMA precision needs less than half of that");
+  const long Gws = std::min<long>(kMaxBwdGrid, B);
   Carver ws(workspace);
+  float* wpart = ws.take<float>((size_t)Gws * 3 * K * H * A);
+  float* gb_part = ws.take<float>((size_t)Gws * H * 32);
+  int G = 1;
   const size_t nact = (size_t)H * B * F * A;
-  float* dav = ws.take<float>(nact);
-  float* dres = ws.take<float>(nact);
-  float* dq = ws.take<float>(nact);
-  float* dk = ws.take<float>(nact);
-  float* gb_part = ws.take<float>((size_t)B * H * 2 * 16);
-  const int pblocks = proj_parts(d);
-  const int nout = K * NJ * H * A;
-  float* wpart = ws.take<float>((size_t)(pblocks + 1) * 3 * K * H * A);
-  float* wred = wpart + (size_t)pblocks * nout;
-
-  const dim3 grid(B * H);
-  const size_t sh_base = ((size_t)d.FP * d.XSS + (size_t)d.FP * kRS) * sizeof(float);
-  if (sh_base + 2 * (size_t)d.FP * kRS * sizeof(float) > 160 * 1024)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: F=%d K=%d needs more than 160 KiB of LDS", F, K);
-  const double core = (double)B * H * 4.0 * F * (double)F * A;  // one score + one weighted-sum pass
-  // saved-av path: LayerNorm needs av; the fused ReLU mask needs y.  Anything missing -> recompute (original kernel).
-  const bool saved_path = (gamma == nullptr || av_saved != nullptr) && (!fuse_relu || y_saved != nullptr);
-  int gb_blocks = B * H;
-  if (saved_path) {
-    const long rows = (long)H * B * F;
-    gb_blocks = (int)std::min<long>((rows + 15) / 16, (long)B * H);   // gb_part holds B*H blocks of partials
-    ProfScope ps("attn_bwd_pre", st, (double)rows * A * 5 * sizeof(float));
-    hipLaunchKernelGGL(attn_bwd_pre_saved_kernel, dim3(gb_blocks), dim3(kAttnThreads), 0, st, av_saved, y_saved, gamma, dy, dav,
-                       (fuse_relu && has_res) ? dres : nullptr, gb_part, rows, A, eps, fuse_relu);
-  } else {
-    const size_t sh = sh_base + 4 * 2 * 16 * sizeof(float);
-    ProfScope ps("attn_bwd_pre", st, core);
-#define CALL_PRE(N, P)                                                                                                      \
-  allow_lds_attn(attn_bwd_pre_kernel<N, P>, sh);                                                                            \
-  hipLaunchKernelGGL((attn_bwd_pre_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, gamma, beta, dy, dav,    \
-                     (fuse_relu && has_res) ? dres : nullptr, gb_part, d, scale, eps, fuse_relu)
-    FIL_ATTN_NC(d.NC, CALL_PRE)
-#undef CALL_PRE
+  if (need_av || need_y) {
+    float* av_ws = ws.take<float>(nact);
+    float* y_ws = ws.take<float>(nact);
+    ProfScope ps("attn_bwd_recompute", st, (double)B * H * (2.0 * F * K * A * 3 + 4.0 * F * (double)F * A));
+    rc = launch_fwd(x, Wq, Wk, Wr, gamma, beta, y_ws, nullptr, need_av ? av_ws : nullptr, d, scale, eps, fuse_relu, f16, st);
+    if (rc != FIL_OK) return rc;
+    if (need_av) av_saved = av_ws;
+    if (need_y) y_saved = y_ws;
   }
+  {
+    // algorithmic flops of the score pass: S, dS, dq, 2 x dk = 5 products of 2*F*F*A, plus projections and their gradients
+    ProfScope ps("attn_bwd", st, (double)B * H * (10.0 * F * (double)F * A + 2.0 * F * K * A * (has_res ? 9 : 7)));
+    const dim3 block(64 * H);
+    int lrc = FIL_OK;
+#define CALL_BWD_NB(N, P, NBV)                                                                                              \
+  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV>, sh);                                                                     \
+  if (lrc == FIL_OK) {                                                                                                      \
+    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV>, 64 * H, sh));                                               \
+    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved,    \
+                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu);                                            \
+  }
+#define CALL_BWD(N, P)                                  \
+  if (d.nblk <= 4) { CALL_BWD_NB(N, P, 4); }            \
+  else if (d.nblk <= 8) { CALL_BWD_NB(N, P, 8); }       \
+  else if (d.nblk <= 13) { CALL_BWD_NB(N, P, 13); }     \
+  else { CALL_BWD_NB(N, P, 32); }
+    FIL_ATTN_NC(d.NC, CALL_BWD)
+#undef CALL_BWD
+#undef CALL_BWD_NB
+    if (lrc != FIL_OK) return fail(lrc, "fil_attn_bwd: cannot reserve %zu bytes of LDS", sh);
+    FIL_CHECK_LAUNCH();
+  }
+  const int n = K * H * A;
+  hipLaunchKernelGGL(attn_reduce_dw_kernel, dim3(cdiv(n, 64), 3), dim3(256), 0, st, wpart, dWq, dWk, dWr, n, G);
   FIL_CHECK_LAUNCH();
   if (gamma != nullptr) {
-    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, gb_blocks, A);
-    FIL_CHECK_LAUNCH();
-  }
-  {
-    ProfScope ps("attn_bwd_dq", st, core * 1.5);
-#define CALL_DQ(N, P)                                                                                                       \
-  allow_lds_attn(attn_bwd_dq_kernel<N, P>, sh_base);                                                                        \
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<N, P>), grid, dim3(kAttnThreads), sh_base, st, x, Wq, Wk, dav, dq, d, scale)
-    FIL_ATTN_NC(d.NC, CALL_DQ)
-#undef CALL_DQ
-  }
-  FIL_CHECK_LAUNCH();
-  {
-    const size_t sh = sh_base + 2 * (size_t)d.FP * kRS * sizeof(float);
-    ProfScope ps("attn_bwd_dk", st, core * 2.0);
-#define CALL_DK(N, P)                                                                                                       \
-  allow_lds_attn(attn_bwd_dk_kernel<N, P>, sh);                                                                             \
-  hipLaunchKernelGGL((attn_bwd_dk_kernel<N, P>), grid, dim3(kAttnThreads), sh, st, x, Wq, Wk, dav, dk, d, scale)
-    FIL_ATTN_NC(d.NC, CALL_DK)
-#undef CALL_DK
-  }
-  FIL_CHECK_LAUNCH();
-  {
-    const float* drsrc = has_res ? (fuse_relu ? dres : dres_in) : nullptr;
-    const int DW = NJ * H * A;
-    const size_t sh = ((size_t)K * DW + (size_t)kProjTile * (DW + 1) + (size_t)kProjTile * (K + 1)) * sizeof(float);
-    if (!proj_mfma_ok(d) && sh > 150 * 1024) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: projection tile needs %zu bytes of LDS", sh);
-    ProfScope ps("attn_bwd_proj", st, (double)B * F * 4.0 * K * DW);
-    if (proj_mfma_ok(d)) {
-      const size_t sh3 = ((size_t)NJ * H * 16 * d.NC * kRS + 4 * 2 * 16 * kRS) * sizeof(float);
-#define CALL_PROJ3(N, P)                                                                                                    \
-  allow_lds_attn(attn_bwd_proj3_kernel<N, P>, sh3);                                                                         \
-  hipLaunchKernelGGL((attn_bwd_proj3_kernel<N, P>), dim3(proj3_blocks(d)), dim3(kAttnThreads), sh3, st, x, Wq, Wk, Wr, dq, dk, drsrc, \
-                     dx, wpart, d)
-      FIL_ATTN_NC(d.NC, CALL_PROJ3)
-#undef CALL_PROJ3
-    } else {
-      allow_lds_attn(attn_bwd_proj_kernel, sh);
-      hipLaunchKernelGGL(attn_bwd_proj_kernel, dim3(pblocks), dim3(kAttnThreads), sh, st, x, Wq, Wk, Wr, dq, dk, drsrc, dx, wpart, d,
-                         proj_rows_per_block(d));
-    }
-    FIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_reduce_kernel, dim3(cdiv(nout, 64)), dim3(256), 0, st, wpart, wred, nout, pblocks);
-    FIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_split_dw_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, wred, dWq, dWk, dWr, K, H * A, NJ);
+    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, G * H, A);
     FIL_CHECK_LAUNCH();
   }
   return FIL_OK;

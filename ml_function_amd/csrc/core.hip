@@ -133,5 +133,5 @@ extern "C" size_t fil_profile_end(char* buf, size_t cap) {
   return out.size() + 1;
 }
 
-extern "C" int fil_version(void) { return 100; }  // 0.1.0
+extern "C" int fil_version(void) { return FIL_ABI_VERSION; }
 extern "C" const char* fil_last_error(void) { return fil::g_err; }

@@ -219,31 +219,42 @@ def cin(x, Ws, bs, dense_w=None, dense_b=None, output_dim=1, mode=0):
 
 # --------------------------------------------------------------------------------------------- A4  AutoInt
 class _AttnFn(torch.autograd.Function):
-    """fuse_relu=True: returns y = relu(res + LN(av)); fuse_relu=False: returns (LN(av), res)."""
+    """fuse_relu=True: returns y = relu(res + LN(av)); fuse_relu=False: returns (LN(av), res).
+    head_major=True: x is the [H',B,F,A'] output of a previous interacting layer, read in place as its head-concat
+    [B,F,H'*A'] (fil.h: x_chunk = A'); the gradient comes back in the same layout."""
 
     @staticmethod
-    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps, fuse_relu, precision=0):
+    def forward(ctx, x, Wq, Wk, Wr, gamma, beta, scale, eps, fuse_relu, precision=0, head_major=False):
         _require_cuda(x, Wq, Wk, Wr, gamma, beta)
         x, Wq, Wk, Wr, gamma, beta = [_f32c(t) for t in (x, Wq, Wk, Wr, gamma, beta)]
-        B, F, K = x.shape
-        _, H, A = Wq.shape
+        if head_major:
+            Hp, B, F, Ap = x.shape
+            K, x_chunk = Hp * Ap, Ap
+        else:
+            B, F, K = x.shape
+            x_chunk = 0
+        Kw, H, A = Wq.shape
+        if Kw != K:
+            raise FilError("attention: weights are [%d,H,A] but the input has %d features" % (Kw, K))
         lib = _lib.load()
         y = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
         res = None
         if not fuse_relu and Wr is not None:
             res = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
-        # av (attention output before LayerNorm) is kept for the backward when LayerNorm is on: it then skips one of
-        # its three score recomputations (H*B*F*A extra floats; FIL_ATTN_SAVE_AV=0 trades them back for the recompute)
+        # av (attention output before LayerNorm) is kept for the backward's LayerNorm gradient (H*B*F*A floats);
+        # FIL_ATTN_SAVE_AV=0 drops it and makes the backward re-run the forward into its workspace instead
         av = None
-        if gamma is not None and os.environ.get("FIL_ATTN_SAVE_AV", "1") != "0":
+        if gamma is not None and _SAVE_AV:
             av = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
         check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), ptr(av), B, F, K, H, A,
-                               float(scale), float(eps), int(bool(fuse_relu)), int(precision), None, 0, stream_ptr()), "fil_attn_fwd")
+                               float(scale), float(eps), int(bool(fuse_relu)), int(precision), x_chunk, None, 0, stream_ptr()),
+              "fil_attn_fwd")
         keep_y = bool(fuse_relu) and (av is not None or gamma is None)   # the fused ReLU mask is y > 0
         ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None],
                               *([av] if av is not None else []), *([y] if keep_y else []))
         ctx.extra = (av is not None, keep_y)
-        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu), int(precision))
+        ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu), int(precision), x_chunk,
+                   (B, F, K))
         if fuse_relu:
             return y
         if res is None:
@@ -252,7 +263,7 @@ class _AttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dres=None):
-        has_res, has_ln, scale, eps, fuse_relu, precision = ctx.cfg
+        has_res, has_ln, scale, eps, fuse_relu, precision, x_chunk, (B, F, K) = ctx.cfg
         sv = list(ctx.saved_tensors)
         x, Wq, Wk = sv[:3]
         rest = sv[3:]
@@ -262,7 +273,6 @@ class _AttnFn(torch.autograd.Function):
         has_av, has_y = ctx.extra
         av_saved = rest.pop(0) if has_av else None
         y_saved = rest.pop(0) if has_y else None
-        B, F, K = x.shape
         _, H, A = Wq.shape
         lib = _lib.load()
         dy = _f32c(dy) if dy is not None else torch.zeros((H, B, F, A), dtype=torch.float32, device=x.device)
@@ -274,13 +284,17 @@ class _AttnFn(torch.autograd.Function):
         dWr = torch.empty_like(Wr) if has_res else None
         dgamma = torch.empty_like(gamma) if has_ln else None
         dbeta = torch.empty_like(beta) if has_ln else None
-        nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A)
+        have_saved = int((not has_ln or av_saved is not None) and (not fuse_relu or y_saved is not None))
+        nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A, have_saved)
         ws = _workspace(nws, x.device)
         check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(y_saved),
                                ptr(av_saved), ptr(dx),
                                ptr(dWq), ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps,
-                               int(fuse_relu), precision, ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
-        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None, None
+                               int(fuse_relu), precision, x_chunk, ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
+        return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None, None, None
+
+
+_SAVE_AV = os.environ.get("FIL_ATTN_SAVE_AV", "1") != "0"   # read once at import
 
 
 def _attn_scale(Wq, use_scale):
@@ -296,10 +310,22 @@ def _precision(p):
     return PRECISIONS[p]
 
 
-def autoint_interact(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3, precision="f32"):
+def autoint_interact(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3, precision="f32", head_major=False):
     """x [B,F,K], W* [K,H,A] -> y [H,B,F,A] = relu(x Wr + LN(sigmoid(scale q k^T) k))  (V == K projection).
-    precision "f16_mfma": matrix products on the fp16 MFMA with fp32 accumulation (include/fil.h, fil_precision)."""
-    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, True, _precision(precision))
+    precision "f16_mfma": matrix products on the fp16 MFMA with fp32 accumulation (include/fil.h, fil_precision).
+    head_major=True: x is a previous layer's [H',B,F,A'] output, consumed as its head-concat [B,F,H'*A'] without a copy."""
+    return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, True, _precision(precision),
+                         bool(head_major))
+
+
+def autoint_stack(x, layers, use_scale=True, eps=1e-3, precision="f32"):
+    """A stack of interacting layers (BASELINE config 5: 3 layers).  layers: list of (Wq, Wk, Wr, gamma, beta); layer l > 0
+    takes the head-concat [B,F,H*A] of layer l-1 (ESULayer's convention, reference behavior_layer.py:973) -- read in
+    place from the head-major output.  Returns the last layer's [H,B,F,A]."""
+    y = x
+    for l, (Wq, Wk, Wr, gamma, beta) in enumerate(layers):
+        y = autoint_interact(y, Wq, Wk, Wr, gamma, beta, use_scale=use_scale, eps=eps, precision=precision, head_major=l > 0)
+    return y
 
 
 def mult_head_attention(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=True, eps=1e-3, precision="f32"):

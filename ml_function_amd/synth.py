@@ -67,3 +67,17 @@ def attn_case(B, F, K, H, A, seed=SEED, dist="uniform"):
                 gamma=(1.0 + 0.1 * rng.standard_normal(A)).astype(np.float32),
                 beta=(0.1 * rng.standard_normal(A)).astype(np.float32),
                 dy=rng.standard_normal((H, B, F, A)).astype(np.float32))
+
+
+def attn_stack_case(B, F, K, H, A, L, seed=SEED, dist="uniform"):
+    """L stacked interacting layers (BASELINE config 5: L=3): layer 0 reads [B,F,K], layers l > 0 the head-concat
+    [B,F,H*A] of the layer below.  Returns x, layers = [(Wq, Wk, Wr, gamma, beta)], dy [H,B,F,A]."""
+    rng = np.random.default_rng(seed)
+    x = embeddings(rng, B, F, K, dist)
+    layers, kin = [], K
+    for _ in range(L):
+        mk = lambda: glorot_uniform(rng, (kin, H, A), fan_in=H * kin, fan_out=A * kin)
+        layers.append((mk(), mk(), mk(), (1.0 + 0.1 * rng.standard_normal(A)).astype(np.float32),
+                       (0.1 * rng.standard_normal(A)).astype(np.float32)))
+        kin = H * A
+    return dict(x=x, layers=layers, dy=rng.standard_normal((H, B, F, A)).astype(np.float32))

@@ -232,6 +232,43 @@ def attn_bwd(x, Wq, Wk, Wr, gamma, beta, dy, use_scale=True, use_res=True, use_l
     return dx, dWq, dWk, dWr, dgamma, dbeta
 
 
+def head_concat(y):
+    """[H,B,F,A] -> [B,F,H*A] (feature h*A + a), behavior_layer.py:973."""
+    H, B, F, A = y.shape
+    return np.transpose(y, (1, 2, 0, 3)).reshape(B, F, H * A)
+
+
+def head_split(xg, H):
+    """inverse of head_concat for gradients: [B,F,H*A] -> [H,B,F,A]."""
+    B, F, HA = xg.shape
+    return np.transpose(xg.reshape(B, F, H, HA // H), (2, 0, 1, 3))
+
+
+def attn_stack_fwd(x, layers, return_inputs=False):
+    """Stack of interacting layers (extension, see oracle/graph.py:autoint_stack).  layers: list of
+    (Wq, Wk, Wr, gamma, beta); returns the last [H,B,F,A] (and every layer's input when return_inputs)."""
+    xs, y = [], None
+    for (Wq, Wk, Wr, gamma, beta) in layers:
+        xs.append(np.asarray(x, F64))
+        y = attn_fwd(x, Wq, Wk, Wr, gamma, beta)
+        x = head_concat(y)
+    return (y, xs) if return_inputs else y
+
+
+def attn_stack_bwd(x, layers, dy):
+    """dy [H,B,F,A] of the last layer -> (dx, [per-layer (dWq, dWk, dWr, dgamma, dbeta)])."""
+    _, xs = attn_stack_fwd(x, layers, return_inputs=True)
+    grads = [None] * len(layers)
+    g = np.asarray(dy, F64)
+    for l in range(len(layers) - 1, -1, -1):
+        Wq, Wk, Wr, gamma, beta = layers[l]
+        dx, dWq, dWk, dWr, dg, db = attn_bwd(xs[l], Wq, Wk, Wr, gamma, beta, g)
+        grads[l] = (dWq, dWk, dWr, dg, db)
+        if l > 0:
+            g = head_split(dx, np.asarray(layers[l - 1][0]).shape[1])
+    return dx, grads
+
+
 # --------------------------------------------------------------------------- field-index work (N1)
 def label_encode(column):
     """data_prepare.py:91-93 -- fillna('-1') -> astype(str) -> sklearn LabelEncoder: rank in the

@@ -177,6 +177,24 @@ def autoint_interacting(x, query_w, key_w, res_w, ln_gamma, ln_beta, use_scale=T
     return torch.relu(y)  # ResActivateLayer with bn/ln off, :216
 
 
+def head_concat(y):
+    """[H,B,F,A] -> [B,F,H*A], feature index h*A + a: the reference's own way of feeding multi-head output onward,
+    ESULayer.call, behavior_layer.py:973 (tf.split on the head axis, tf.concat on the last axis, tf.squeeze)."""
+    return torch.cat(torch.split(y, 1, dim=0), dim=-1).squeeze(0)
+
+
+def autoint_stack(x, layers, use_scale=True, use_res=True, use_ln=True):
+    """BASELINE config 5 ("AutoInt 3-layer"): a stack of interacting layers.  EXTENSION -- the reference builds ONE
+    layer (models.py:159-163; a literal second MultHeadAttentionLayer on the [H,B,F,A] output would transpose a rank-5
+    tensor at behavior_layer.py:358).  Defined per SURVEY.md section 8 A4: layer l+1 reads head_concat(layer l output).
+    layers: list of (query_w, key_w, res_w, ln_gamma, ln_beta).  Returns the last layer's [H,B,F,A]."""
+    y = None
+    for (qw, kw, rw, gam, bet) in layers:
+        y = autoint_interacting(x, qw, kw, rw, gam, bet, use_scale=use_scale, use_res=use_res, use_ln=use_ln)
+        x = head_concat(y)
+    return y
+
+
 def autoint_flatten(y):
     """models.py:162 -- [squeeze(h) for h in split(atten_vec, H)] -> StackLayer(use_flat=True, axis=-1): [B, H*F*A]."""
     heads = [h.squeeze(0) for h in torch.split(y, 1, dim=0)]

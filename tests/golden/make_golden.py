@@ -78,6 +78,22 @@ def attn(tag, B, F, K, H, A):
     save("attn_%s.npz" % tag, **arrays)
 
 
+def attn_stack(tag, B, F, K, H, A, L):
+    """BASELINE config 5 as written (3 stacked interacting layers; the stacking rule is the documented extension of
+    oracle/graph.py:autoint_stack -- head-concat per the reference's ESULayer, behavior_layer.py:973)."""
+    c = synth.attn_stack_case(B, F, K, H, A, L, dist="normal")
+    x = T(c["x"])
+    layers = [tuple(T(p) for p in lay) for lay in c["layers"]]
+    y = graph.autoint_stack(x, layers)
+    y.backward(torch.tensor(c["dy"], dtype=torch.float64))
+    arrays = dict(x=c["x"], dy=c["dy"], y=y.detach().numpy(), dx=x.grad.numpy(), L=np.asarray(L))
+    for l, lay in enumerate(layers):
+        for n, p, raw in zip(["Wq", "Wk", "Wr", "gamma", "beta"], lay, c["layers"][l]):
+            arrays["%s%d" % (n, l)] = raw
+            arrays["d%s%d" % (n, l)] = p.grad.numpy()
+    save("attn_stack_%s.npz" % tag, **arrays)
+
+
 def label_encode():
     import pandas as pd
     from sklearn.preprocessing import LabelEncoder
@@ -110,4 +126,5 @@ if __name__ == "__main__":
     cin("tiny", 2, 5, 8, [6, 7])
     attn("c5_small", 2, 200, 16, 4, 16)       # config 5 layer shape, small batch
     attn("default", 2, 39, 16, 3, 8)          # reference defaults: attention_dim=8, 3 heads
+    attn_stack("c5_small", 2, 200, 16, 4, 16, 3)   # config 5: 3 layers, 4 heads, F=200, K=16, A=16, small batch
     label_encode()

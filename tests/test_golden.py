@@ -67,6 +67,19 @@ def test_oracle_attn(name):
         assert rel(got, g[n]) < 1e-5, n  # float32-stored fixture of a kinked (ReLU) function
 
 
+def test_oracle_attn_stack():
+    g = load("attn_stack_c5_small.npz")
+    L = int(g["L"])
+    layers = [tuple(g["%s%d" % (n, l)] for n in ["Wq", "Wk", "Wr", "gamma", "beta"]) for l in range(L)]
+    assert L == 3 and layers[1][0].shape == (64, 4, 16)          # BASELINE config 5: 3 layers, 4 heads, A=16
+    assert rel(closed.attn_stack_fwd(g["x"], layers), g["y"]) < 1e-6
+    dx, grads = closed.attn_stack_bwd(g["x"], layers, g["dy"])
+    assert rel(dx, g["dx"]) < 1e-5
+    for l in range(L):
+        for got, n in zip(grads[l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
+            assert rel(got, g["%s%d" % (n, l)]) < 1e-5, (l, n)
+
+
 def test_label_encode_golden_from_sklearn():
     g = load("label_encode.npz")
     for f, n in enumerate(["C1", "C2", "C3"]):
@@ -172,6 +185,27 @@ def test_gpu_autoint(name):
     av, res = att(x.detach())
     assert av.shape == g["y"].shape and res.shape == g["y"].shape
     assert rel(torch.relu(av + res), g["y"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol_y,tol_g", [("f32", 1e-5, 5e-5), ("f16_mfma", 5e-3, 0.25)])
+def test_gpu_autoint_stack(precision, tol_y, tol_g):
+    """BASELINE config 5 as written: 3 stacked interacting layers, 4 heads, F=200, K=16, A=16; layers 2 and 3 read the
+    head-major output of the layer below in place (no head-concat copy).  fp32 mode at the 1e-5 bar on the output (5e-5
+    on gradients: three ReLU/LN kinks deep); the labelled f16-MFMA mode at 5e-3 / 0.25 (kink flips, see
+    test_attn_f16_mfma_mode)."""
+    from ml_function_amd import functional as Fn
+    g = load("attn_stack_c5_small.npz")
+    L = int(g["L"])
+    x = dev(g["x"]).requires_grad_()
+    layers = [tuple(dev(g["%s%d" % (n, l)]).requires_grad_() for n in ["Wq", "Wk", "Wr", "gamma", "beta"]) for l in range(L)]
+    y = Fn.autoint_stack(x, layers, precision=precision)
+    assert y.shape == g["y"].shape and rel(y, g["y"]) < tol_y
+    y.backward(dev(g["dy"]))
+    assert rel(x.grad, g["dx"]) < tol_g
+    for l in range(L):
+        for p, n in zip(layers[l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
+            assert rel(p.grad, g["%s%d" % (n, l)]) < tol_g, (l, n)
 
 
 @pytest.mark.gpu

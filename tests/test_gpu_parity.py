@@ -398,6 +398,83 @@ def test_attn_f16_mfma_mode(B, F, K, H, A, fused):
             check("attn f16 unfused " + name, a, b.detach().cpu().numpy(), tol=2e-2)
 
 
+@pytest.mark.parametrize("B,F,Hp,Ap,H,A", [(3, 39, 3, 8, 2, 8), (2, 200, 4, 16, 4, 16), (2, 21, 2, 5, 3, 4)])
+@pytest.mark.parametrize("precision", ["f32", "f16_mfma"])
+def test_attn_head_major_input(B, F, Hp, Ap, H, A, precision):
+    """x given as a previous layer's [H',B,F,A'] output (fil.h: x_chunk = A') == the same layer on the materialised
+    head-concat [B,F,H'*A'] (reference ESULayer convention, behavior_layer.py:973), bit for bit, forward and backward;
+    the input gradient comes back head-major."""
+    from ml_function_amd import functional as Fn
+    K = Hp * Ap
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    xh = np.ascontiguousarray(np.transpose(c["x"].reshape(B, F, Hp, Ap), (2, 0, 1, 3)))      # [H',B,F,A']
+    assert np.array_equal(closed.head_concat(xh), c["x"])
+    outs = []
+    for head_major in (False, True):
+        t = {n: dev(c[n]).requires_grad_() for n in ["Wq", "Wk", "Wr", "gamma", "beta"]}
+        x = dev(xh if head_major else c["x"]).requires_grad_()
+        y = Fn.autoint_interact(x, t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"], precision=precision, head_major=head_major)
+        y.backward(dev(c["dy"]))
+        dx = x.grad if not head_major else x.grad.permute(1, 2, 0, 3).reshape(B, F, K)
+        outs.append([y.detach(), dx] + [t[n].grad for n in ["Wq", "Wk", "Wr", "gamma", "beta"]])
+    for a, b2 in zip(*outs):
+        assert torch.equal(a, b2)
+    if precision == "f32":
+        check("head-major y", outs[1][0], closed.attn_fwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], c["beta"]))
+
+
+@pytest.mark.parametrize("B,F,K,H,A,L", [(3, 200, 16, 4, 16, 3), (5, 39, 16, 2, 8, 2), (2, 50, 8, 8, 4, 2)])
+def test_attn_stack(B, F, K, H, A, L):
+    """Stack of interacting layers (BASELINE config 5: L=3) against the fp64 oracle, fp32 mode."""
+    from ml_function_amd import functional as Fn
+    c = synth.attn_stack_case(B, F, K, H, A, L, dist="normal")
+    x = dev(c["x"]).requires_grad_()
+    layers = [tuple(dev(p).requires_grad_() for p in lay) for lay in c["layers"]]
+    y = Fn.autoint_stack(x, layers)
+    check("stack y", y, closed.attn_stack_fwd(c["x"], c["layers"]))
+    y.backward(dev(c["dy"]))
+    dx, grads = closed.attn_stack_bwd(c["x"], c["layers"], c["dy"])
+    check("stack dx", x.grad, dx, tol=5e-5)
+    for l in range(L):
+        for p, want, n in zip(layers[l], grads[l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
+            check("stack %s%d" % (n, l), p.grad, want, tol=5e-5)
+
+
+def test_attn_backward_without_saved_tensors():
+    """fil_attn_bwd with av_saved = y_saved = NULL re-runs the forward into its workspace: same gradients, bit for bit."""
+    from ml_function_amd import functional as Fn
+    c = synth.attn_case(5, 39, 16, 3, 8, dist="normal")
+    res = []
+    for save in (True, False):
+        old = Fn._SAVE_AV
+        Fn._SAVE_AV = save
+        try:
+            t = {n: dev(c[n]).requires_grad_() for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
+            Fn.autoint_interact(t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"]).backward(dev(c["dy"]))
+            res.append([t[n].grad for n in t])
+        finally:
+            Fn._SAVE_AV = old
+    for a, b2 in zip(*res):
+        assert torch.equal(a, b2)
+
+
+def test_attn_repeatable_and_batch_independent():
+    """Fixed-order reductions: repeated calls are bit-identical; the rows of a sample do not depend on its batch."""
+    from ml_function_amd import functional as Fn
+    c = synth.attn_case(700, 39, 16, 4, 16, dist="normal")    # more samples than persistent workgroups take one each
+    def run(sl):
+        t = {n: dev(c[n]).requires_grad_() for n in ["Wq", "Wk", "Wr", "gamma", "beta"]}
+        x = dev(c["x"][sl]).requires_grad_()
+        y = Fn.autoint_interact(x, t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"], precision="f16_mfma")
+        y.backward(dev(c["dy"][:, sl]))
+        return [y.detach(), x.grad] + [t[n].grad for n in t]
+    a, b2 = run(slice(None)), run(slice(None))
+    for u, v in zip(a, b2):
+        assert torch.equal(u, v)
+    part = run(slice(100, 164))
+    assert torch.equal(part[0], a[0][:, 100:164]) and torch.equal(part[1], a[1][100:164])
+
+
 def test_attn_unfused_matches_reference_layer_outputs():
     """MultHeadAttentionLayer.call returns [atten_v, res] (behavior_layer.py:377); gradients flow through both."""
     from ml_function_amd import functional as Fn

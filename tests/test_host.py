@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol(lib):
     for s in syms:
         assert hasattr(lib, s), "libfil_hip.so does not export %s" % s
     assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
-    assert lib.fil_version() >= 100
+    assert lib.fil_version() == _lib.header_abi_version() >= 200   # a stale .so is refused by _lib.load()
 
 
 def test_argument_validation_without_gpu(lib):
@@ -39,9 +39,12 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 9, H, 1, 0, None, 0, None) == -4
     Hbig = _lib.int_array([300])
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 1, Hbig, 1, 0, None, 0, None) == -4
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, None, 0, None) == -4
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
     # unknown precision code
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, None, 0, None) == -1
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, 0, None, 0, None) == -1
+    # head-major input: the chunk width must divide K; more than 8 heads is outside the one-wave-per-head design
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 64, 4, 16, 0.25, 1e-3, 1, 0, 24, None, 0, None) == -1
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
 
 
 def test_workspace_sizes(lib):
@@ -54,7 +57,10 @@ def test_workspace_sizes(lib):
     assert lib.fil_cin_bwd_workspace_bytes(B, F, K, 3, H) > 2 * M * 128 * 4
     assert lib.fil_cin_saved_bytes(B, F, K, 1, H) == M * F * 4
     assert lib.fil_dcn_bwd_workspace_bytes(8192, 1248, 3) > 0
-    assert lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16) >= 4 * 4 * 16 * 200 * 16 * 4
+    # saved av / y: only the per-workgroup partial sums; otherwise room to re-run the forward (av and y, [H,B,F,A] each)
+    small = lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 1)
+    assert 0 < small < 1 << 20
+    assert lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 0) >= small + 2 * 4 * 16 * 200 * 16 * 4
     assert lib.fil_cin_bwd_workspace_bytes(0, F, K, 3, H) >= 0
 
 

@@ -163,6 +163,29 @@ def test_attn_graph_vs_closed(B, F, K, H, A, use_res, use_ln):
     assert torch.equal(flat[:, F * A:2 * F * A], y.detach()[1].reshape(B, F * A))
 
 
+@pytest.mark.parametrize("B,F,K,H,A,L", [(2, 5, 4, 2, 4, 2), (2, 9, 8, 3, 8, 3), (1, 39, 16, 4, 16, 3)])
+def test_attn_stack_graph_vs_closed(B, F, K, H, A, L):
+    """BASELINE config 5's stack (extension: head-concat between layers, behavior_layer.py:973): the op-for-op graph
+    under autograd == the closed-form per-layer forward/backward chained through head_concat / head_split."""
+    c = synth.attn_stack_case(B, F, K, H, A, L, dist="normal")
+    x = T(c["x"]).requires_grad_()
+    layers = [tuple(T(p).requires_grad_() for p in lay) for lay in c["layers"]]
+    y = graph.autoint_stack(x, layers)
+    assert y.shape == (H, B, F, A) and layers[1][0].shape == (H * A, H, A)
+    assert rel(y.detach(), closed.attn_stack_fwd(c["x"], c["layers"])) < 1e-12
+    # head_concat: feature h*A + a of the next input is y[h, :, :, a]
+    y0 = graph.autoint_interacting(x, *layers[0])
+    hc = graph.head_concat(y0)
+    assert hc.shape == (B, F, H * A) and torch.equal(hc[:, :, A:2 * A], y0[1])
+    assert np.array_equal(closed.head_split(closed.head_concat(y0.detach().numpy()), H), y0.detach().numpy())
+    y.backward(T(c["dy"]))
+    dx, grads = closed.attn_stack_bwd(c["x"], c["layers"], c["dy"])
+    assert rel(x.grad, dx) < 1e-9
+    for l in range(L):
+        for got, want in zip(layers[l], grads[l]):
+            assert rel(got.grad, want) < 1e-9, l
+
+
 def test_attn_kat():
     B, F, K, H, A = 2, 5, 4, 2, 4
     c = synth.attn_case(B, F, K, H, A, dist="normal")
