@@ -85,9 +85,12 @@ __device__ __forceinline__ typename Prec<F16>::Op to_op(f32x4 v) {
 }
 
 // ---- LDS tile images: [rows][16] elements ------------------------------------------------------------------------------
-// f16: 32-byte rows; the four 8-byte chunks of rows 8..15 (mod 16) are stored XOR 2, which makes the 8-byte row reads of a
-// 32-lane half (16 rows x 2 chunks) and the transposing reads (8 rows x 4 chunks) hit 64 different banks.
-__device__ __forceinline__ int swz16(int row) { return ((row >> 3) & 1) << 1; }
+// f16: 32-byte rows; the four 8-byte chunks of row r are stored at chunk ^ ((r >> 2) & 3).  Conflict-free for all three
+// access shapes: 8-byte row reads (a 32-lane half = 16 rows x 2 chunks over 64 banks: rows r and r+8 share their bank
+// group and get chunk sets {f, f^1} vs {f^2, f^3}), transposing reads (8 rows x 4 chunks = 64 different dwords), and
+// 8-byte row writes (16 lanes = 16 rows x 1 chunk over 32 banks: rows r, r+4, r+8, r+12 collide in 8r mod 32 and take
+// four different chunks) -- the plain layout made the writes 4-way (SQ_LDS_BANK_CONFLICT 27 % of the LDS cycles).
+__device__ __forceinline__ int swz16(int row) { return (row >> 2) & 3; }
 
 template <bool F16>
 __device__ __forceinline__ typename Prec<F16>::Op row_read(const typename Prec<F16>::Elem* img, int row, int g) {
@@ -149,12 +152,34 @@ struct AttnDims {
   int FP;     // 16*nblk
   int NC;     // ceil(K/16)
   int xcw;    // x chunk width: K for the plain [B,F,K] layout, c for the head-major layout [K/c][B][F][c]
-  long xcs;   // x chunk stride in elements (B*F*c; 0 for the plain layout)
+  int xcs;    // x chunk stride in elements (B*F*c; 0 for the plain layout)
+  int xrcp;   // ceil(2^16 / xcw) (0 for the plain layout): kin / xcw == (kin * xrcp) >> 16 for kin < 64
 };
 
-__device__ __forceinline__ long x_off(const AttnDims& d, int b, int f, int kin) {
-  const int ch = kin / d.xcw;
-  return ch * d.xcs + ((long)b * d.F + f) * d.xcw + (kin - ch * d.xcw);
+// element offset of x[b, f, kin] (the host guarantees B*F*K < 2^29, so offsets and byte offsets fit 32 bits)
+__device__ __forceinline__ int x_off(const AttnDims& d, int b, int f, int kin) {
+  const int ch = (kin * d.xrcp) >> 16;
+  return ch * d.xcs + (b * d.F + f) * d.xcw + (kin - ch * d.xcw);
+}
+
+// raw buffer access: a lane whose byte offset is >= the descriptor's size reads 0 / stores nothing, so masked lanes cost
+// neither a branch nor a select (kOOB is added to the offset of lanes that must not touch memory)
+constexpr int kOOB = 0x40000000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(bytes < 0x3fffffffL ? bytes : 0x3fffffffL), 0x00020000);
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, byte_off, 0, 0);
 }
 
 // ---- x fragments --------------------------------------------------------------------------------------------------------
@@ -178,41 +203,32 @@ struct XSrc<true, true> {
 
 template <bool F16>
 struct XSrc<F16, false> {
-  const float* x;
+  __amdgpu_buffer_rsrc_t rx;   // the whole x tensor
   AttnDims d;
   int b;
   bool vec;   // xcw % 4 == 0 && K % 4 == 0: four consecutive kin are one aligned 16-byte piece
-  __device__ __forceinline__ void set_sample(const AttnDims& dd, int bb) {
+  __device__ __forceinline__ void init(const float* x, const AttnDims& dd) {
     d = dd;
-    b = bb;
+    rx = make_rsrc(x, (long)dd.B * dd.F * dd.K * 4);
     vec = (dd.xcw & 3) == 0 && (dd.K & 3) == 0;
   }
+  __device__ __forceinline__ void set_sample(const AttnDims&, int bb) { b = bb; }
   __device__ __forceinline__ typename Prec<F16>::Op row(int blk, int ch, int lane) const {
     const int f = 16 * blk + (lane & 15), k0 = 16 * ch + 4 * (lane >> 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v;
     if (vec) {
-      const bool ok = f < d.F && k0 < d.K;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(x + (ok ? x_off(d, b, f, k0) : 0));
-      if (ok) v = t;
+      v = buf_load4(rx, (f < d.F && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB);
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bool ok = f < d.F && k0 + s < d.K;
-        const float t = x[ok ? x_off(d, b, f, k0 + s) : 0];
-        if (ok) v[s] = t;
-      }
+      for (int s = 0; s < 4; ++s) v[s] = buf_load1(rx, (f < d.F && k0 + s < d.K) ? 4 * x_off(d, b, f, k0 + s) : kOOB);
     }
     return to_op<F16>(v);
   }
   __device__ __forceinline__ typename Prec<F16>::Op col(int blk, int ch, int lane) const {
     const int f0 = 16 * blk + 4 * (lane >> 4), kin = 16 * ch + (lane & 15);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool ok = kin < d.K && f0 + s < d.F;
-      const float t = x[ok ? x_off(d, b, f0 + s, kin) : 0];
-      if (ok) v[s] = t;
-    }
+    for (int s = 0; s < 4; ++s) v[s] = buf_load1(rx, (kin < d.K && f0 + s < d.F) ? 4 * x_off(d, b, f0 + s, kin) : kOOB);
     return to_op<F16>(v);
   }
 };
@@ -268,35 +284,34 @@ __device__ __forceinline__ void project_k(const XS& xsrc, typename Prec<F16>::El
   }
 }
 
-// Lane (g,c) of a 16-row block owns 4 consecutive a (a0 = 4g) of row f of an [F][A] slab (`base`, wave-uniform).
-// Loads are branch-free (clamped address + select) so that several of them issue back to back behind one s_waitcnt.
-__device__ __forceinline__ f32x4 load_a4(const float* __restrict__ base, int f, int A, int a0, bool fvalid, bool vecA) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (vecA) {
-    const bool ok = fvalid && a0 < A;
-    const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? f * A + a0 : 0));
-    if (ok) v = t;
-  } else {
+// Lane (g,c) of a 16-row block owns 4 consecutive a (a0 = 4g) of row f of one (head, sample)'s [F][A] slab.  The slab is
+// a raw buffer of F*A*4 bytes: rows f >= F fall outside it by themselves, columns a >= A are pushed out with kOOB.
+struct SlabLane {
+  int A4;        // A * 4 (row pitch in bytes)
+  int off[4];    // byte offset of element a0 + s inside a row, or kOOB
+  bool vecA;     // A % 4 == 0: the four elements are one aligned 16-byte piece (off[0] covers them)
+  __device__ __forceinline__ void init(int A, int a0) {
+    A4 = 4 * A;
+    vecA = (A & 3) == 0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool ok = fvalid && a0 + s < A;
-      const float t = base[ok ? f * A + a0 + s : 0];
-      if (ok) v[s] = t;
-    }
+    for (int s = 0; s < 4; ++s) off[s] = a0 + s < A ? 4 * (a0 + s) : kOOB;
   }
-  return v;
-}
-__device__ __forceinline__ void store_a4(float* __restrict__ base, int f, int A, int a0, bool fvalid, bool vecA, const f32x4& v) {
-  if (fvalid) {
+  __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, int f) const {
+    if (vecA) return buf_load4(r, f * A4 + off[0]);
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = buf_load1(r, f * A4 + off[s]);
+    return v;
+  }
+  __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int f, const f32x4& v) const {
     if (vecA) {
-      if (a0 < A) *reinterpret_cast<f32x4*>(base + f * A + a0) = v;
+      buf_store4(r, f * A4 + off[0], v);
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        if (a0 + s < A) base[f * A + a0 + s] = v[s];
+      for (int s = 0; s < 4; ++s) buf_store1(r, f * A4 + off[s], v[s]);
     }
   }
-}
+};
 
 // workgroup barrier that orders LDS traffic only: global stores and prefetches stay in flight (a __syncthreads() also
 // drains vmcnt).  Inline asm: the waitcnt pass does not look inside, the "memory" clobber pins the compiler's own order.
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     kimg = xs + d.NC * d.FP * 16 + h * d.FP * RS;
     __syncthreads();
   } else {
-    xsrc.x = x;
+    xsrc.init(x, d);
     xsrc.set_sample(d, b);
     kimg = reinterpret_cast<float*>(smem_raw) + h * d.FP * RS;
   }
@@ -337,7 +352,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
   load_w_kin<NC, F16>(Wk, h, d, lane, wk);
   load_w_kin<NC, F16>(Wr, h, d, lane, wr);
   const bool use_ln = gamma != nullptr;
-  const bool vecA = (d.A & 3) == 0;
+  SlabLane sl;
+  sl.init(d.A, 4 * g);
   const float inv_a = 1.0f / (float)d.A;
   f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = {0.f, 0.f, 0.f, 0.f};
   bool aval[4];
@@ -355,9 +371,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 
   const float qs = -scale * 1.4426950408889634f;
   const long slab = ((long)h * d.B + b) * d.F * d.A;   // this (head, sample)'s [F][A] rows
-  float* yb = y + slab;
-  float* avb = av_out != nullptr ? av_out + slab : nullptr;
-  float* resb = res_out != nullptr ? res_out + slab : nullptr;
+  const long slab_bytes = (long)d.F * d.A * 4;
+  const __amdgpu_buffer_rsrc_t r_y = make_rsrc(y + slab, slab_bytes);
+  const __amdgpu_buffer_rsrc_t r_av = make_rsrc(av_out != nullptr ? av_out + slab : y, av_out != nullptr ? slab_bytes : 0);
+  const __amdgpu_buffer_rsrc_t r_res = make_rsrc(res_out != nullptr ? res_out + slab : y, res_out != nullptr ? slab_bytes : 0);
   for (int i = 0; i < d.nblk; ++i) {
     Op xr[NC];
 #pragma unroll
@@ -383,7 +400,6 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     }
     // lane (g,c): av[query 16i+c][a 4g..4g+3]
     const int f = 16 * i + c;
-    const bool fvalid = f < d.F;
     f32x4 ln = avT;
     if (use_ln) {
       float sum = 0.f;
@@ -401,15 +417,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int s = 0; s < 4; ++s) ln[s] = dv[s] * rstd * gam[s] + bet[s];
     }
-    if (avb != nullptr) store_a4(avb, f, d.A, 4 * g, fvalid, vecA, avT);
+    sl.store(r_av, f, avT);          // a zero-size descriptor drops the stores when av is not kept
     if (fuse_relu) {
       f32x4 o;
 #pragma unroll
       for (int s = 0; s < 4; ++s) o[s] = fmaxf(resT[s] + ln[s], 0.f);
-      store_a4(yb, f, d.A, 4 * g, fvalid, vecA, o);
+      sl.store(r_y, f, o);
     } else {
-      store_a4(yb, f, d.A, 4 * g, fvalid, vecA, ln);
-      if (resb != nullptr) store_a4(resb, f, d.A, 4 * g, fvalid, vecA, resT);
+      sl.store(r_y, f, ln);
+      sl.store(r_res, f, resT);
     }
   }
 }
@@ -446,7 +462,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
     xsrc.xs = xs16;
     xsrc.FP = d.FP;
   } else {
-    xsrc.x = x;
+    xsrc.init(x, d);
   }
   Elem* kimg0 = reinterpret_cast<Elem*>(sp);
   Elem* kimg = kimg0 + h * d.FP * RS;
@@ -457,8 +473,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
   Elem* wtab = reinterpret_cast<Elem*>(sp);     // tile (m, hh, cc) at ((m*nw + hh)*NC + cc)*TS: rows = kin, columns = a
 
   const bool use_ln = gamma != nullptr, has_res = Wr != nullptr;
-  const bool vecA = (d.A & 3) == 0;
+  SlabLane sl;
+  sl.init(d.A, 4 * g);
   const float inv_a = 1.0f / (float)d.A;
+  const __amdgpu_buffer_rsrc_t r_dx = make_rsrc(dx, (long)d.B * d.F * d.K * 4);
   // ---- weight table: tile[kin][a] = W_m[16cc + kin][hh][a]; row reads give the "reduce over a" fragments, transposing
   // reads the "reduce over kin" fragments
   {
@@ -512,30 +530,28 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
     f32x4 dk[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const long slab = ((long)h * d.B + b) * d.F * d.A;   // this (head, sample)'s [F][A] rows
-    const float* dyb = dy + slab;
-    const float* ysb = fuse_relu ? y_s + slab : nullptr;
-    const float* avb = use_ln ? av_s + slab : nullptr;
-    const float* drb = (!fuse_relu && has_res && dres_in != nullptr) ? dres_in + slab : nullptr;
+    // this (head, sample)'s [F][A] rows as raw buffers; a tensor that is not used gets a zero-size descriptor (reads 0)
+    const long slab = ((long)h * d.B + b) * d.F * d.A;
+    const long slab_bytes = (long)d.F * d.A * 4;
+    const bool use_dr = !fuse_relu && has_res && dres_in != nullptr;
+    const __amdgpu_buffer_rsrc_t r_dy = make_rsrc(dy + slab, slab_bytes);
+    const __amdgpu_buffer_rsrc_t r_ys = make_rsrc(fuse_relu ? y_s + slab : dy, fuse_relu ? slab_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_avs = make_rsrc(use_ln ? av_s + slab : dy, use_ln ? slab_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_dr = make_rsrc(use_dr ? dres_in + slab : dy, use_dr ? slab_bytes : 0);
 
     // block inputs are fetched one query block ahead (they come from HBM)
-    f32x4 n_dy = load_a4(dyb, c, d.A, 4 * g, c < d.F, vecA);
-    f32x4 n_y = {0.f, 0.f, 0.f, 0.f}, n_av = {0.f, 0.f, 0.f, 0.f}, n_dr = {0.f, 0.f, 0.f, 0.f};
-    if (ysb != nullptr) n_y = load_a4(ysb, c, d.A, 4 * g, c < d.F, vecA);
-    if (avb != nullptr) n_av = load_a4(avb, c, d.A, 4 * g, c < d.F, vecA);
-    if (drb != nullptr) n_dr = load_a4(drb, c, d.A, 4 * g, c < d.F, vecA);
+    f32x4 n_dy = sl.load(r_dy, c), n_y = sl.load(r_ys, c), n_av = sl.load(r_avs, c), n_dr = sl.load(r_dr, c);
 
     for (int i = 0; i < d.nblk; ++i) {
       const int par = i & 1;
       f32x4 dz = n_dy, dr = n_dr;
       const f32x4 yv = n_y, avv = n_av;
-      if (i + 1 < d.nblk) {
-        const int fn = 16 * (i + 1) + c;
-        const bool fv = fn < d.F;
-        n_dy = load_a4(dyb, fn, d.A, 4 * g, fv, vecA);
-        if (ysb != nullptr) n_y = load_a4(ysb, fn, d.A, 4 * g, fv, vecA);
-        if (avb != nullptr) n_av = load_a4(avb, fn, d.A, 4 * g, fv, vecA);
-        if (drb != nullptr) n_dr = load_a4(drb, fn, d.A, 4 * g, fv, vecA);
+      {
+        const int fn = 16 * (i + 1) + c;    // past the last block every lane is out of range and reads zeros
+        n_dy = sl.load(r_dy, fn);
+        n_y = sl.load(r_ys, fn);
+        n_av = sl.load(r_avs, fn);
+        n_dr = sl.load(r_dr, fn);
       }
       // ---- LayerNorm / ReLU backward of query block i: lane (g,c) owns row f = 16i+c, a = 4g..4g+3
       if (fuse_relu) {
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * i + 4 * g + r;
-          if (f < d.F && kin < d.K) dx[x_off(d, b, f, kin)] = px[r];      // [query 4g+r][kin c]
+          buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);      // [query 4g+r][kin c]
         }
       }
     }
@@ -680,7 +696,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * j + 4 * g + r;
-          if (f < d.F && kin < d.K) dx[x_off(d, b, f, kin)] += px[r];     // the lanes that wrote the dq part add the dk part
+          const int o = (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB;
+          buf_store1(r_dx, o, buf_load1(r_dx, o) + px[r]);     // the lanes that wrote the dq part add the dk part
         }
       }
     }
@@ -767,8 +784,10 @@ static int make_dims(const char* fn, int B, int F, int K, int H, int A, int x_ch
   d.nblk = cdiv(F, 16);
   d.FP = 16 * d.nblk;
   d.NC = cdiv(K, 16);
+  if ((long)B * F * K >= (1L << 29)) return fail(FIL_ERR_UNSUPPORTED, "%s: B*F*K = %ld >= 2^29 (32-bit buffer offsets)", fn, (long)B * F * K);
   d.xcw = x_chunk > 0 ? x_chunk : K;
-  d.xcs = x_chunk > 0 ? (long)B * F * x_chunk : 0;
+  d.xcs = x_chunk > 0 ? B * F * x_chunk : 0;
+  d.xrcp = x_chunk > 0 ? (65536 + x_chunk - 1) / x_chunk : 0;
   return FIL_OK;
 }
 
