@@ -3,9 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (for N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`).
+One process per GPU.  For N > 1 either launch it with `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`, or just run `python bench.py --gpus N`: without WORLD_SIZE in the environment the parent starts the N ranks
+itself (fresh child processes through torch.distributed.run, before anything in the parent touches a GPU) and relays
+rank 0's JSON line and the exit code.
 A step = CIN forward + backward over one synthetic batch of B=4096 samples per GPU (F=39, K=16, 3x128 feature
-maps, fp32, all parameter and input gradients) + (N > 1) one RCCL all-reduce of the flat parameter-gradient bucket.
+maps, fp32, all parameter and input gradients) + (N > 1) the RCCL all-reduce of the parameter gradients, issued per
+layer on a side stream as each layer's gradients become final (dp.LayerwiseAllReduce), joined before the step ends.
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement),
 including `roofline` for the dominant kernel (HIP-event timing on the launch stream via fil_profile_begin/_end)
 and `cpu_baseline` (the oracle's op-for-op torch-CPU restatement of the reference TF2 graph, timed on this host).
@@ -28,28 +32,30 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256
 PEAK_F16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md dense fp16/bf16 MFMA peak (16x the fp32 matrix rate)
 
 
-def make_inputs(rank, device):
+def make_inputs(rank, device, batch=B_PER_GPU, conv=CONV, fields=F, embed=K):
     from ml_function_amd import synth
-    c = synth.cin_case(B_PER_GPU, F, K, CONV, seed=synth.SEED)            # parameters: identical on every rank
-    d = synth.cin_case(B_PER_GPU, F, K, CONV, seed=synth.SEED + 1 + rank)  # data shard: per rank
+    c = synth.cin_case(batch, fields, embed, conv, seed=synth.SEED)            # parameters: identical on every rank
+    d = synth.cin_case(batch, fields, embed, conv, seed=synth.SEED + 1 + rank)  # data shard: per rank
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
     return dict(x=t(d["x"]), g=t(d["g"][:, 0]), Ws=[t(w) for w in c["Ws"]], bs=[t(b) for b in c["bs"]],
                 dense_w=t(c["dense_w"]), dense_b=t(c["dense_b"]))
 
 
 def make_bucket(inp, device):
-    """One flat fp32 gradient bucket; dW/db/ddense are views into it (a single all-reduce, no copies)."""
-    sizes = [w.numel() for w in inp["Ws"]] + [b.numel() for b in inp["bs"]] + [inp["dense_w"].numel(), 1]
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
-    views, off = [], 0
-    for n in sizes:
-        views.append(flat[off:off + n])
-        off += n
+    """One flat fp32 gradient bucket laid out in the order the backward finishes the gradients ([head | top layer | ...
+    | layer 1], dp.cin_bucket_layout); dW/db/ddense are views into it (kernels write in place, no packing copies).
+    Returns (flat, grads dict for Fn.cin_backward_raw, segments for dp.LayerwiseAllReduce)."""
+    from ml_function_amd import dp
     L = len(inp["Ws"])
+    sizes, segments, index = dp.cin_bucket_layout([w.shape for w in inp["Ws"]], [b.shape for b in inp["bs"]],
+                                                  [inp["dense_w"].shape, (1,)])
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    view = lambda key: flat[offs[index[key]]:offs[index[key] + 1]]
     grads = dict(dx=torch.empty_like(inp["x"]),
-                 dW=[v.view_as(w) for v, w in zip(views[:L], inp["Ws"])],
-                 db=views[L:2 * L], ddw=views[2 * L].view(-1, 1), ddb=views[2 * L + 1])
-    return flat, grads
+                 dW=[view(("W", l)).view_as(inp["Ws"][l]) for l in range(L)],
+                 db=[view(("b", l)) for l in range(L)], ddw=view(("head", 0)).view(-1, 1), ddb=view(("head", 1)))
+    return flat, grads, segments
 
 
 def usable_cpus():
@@ -279,15 +285,16 @@ def side_benchmark(args):
 
 
 def pmc_traffic(scope):
-    """HBM bytes per launch of the kernel behind profiler scope `scope`, from the newest committed PMC summary
-    (profiles/r*_pmc_traffic.json, written by tools/pmc_traffic.py from two separate rocprofv3 --pmc passes of this
-    same command; counters cannot be read from inside the timed run).  None when no summary matches."""
+    """(HBM bytes per launch of the kernel behind profiler scope `scope`, name of the file they come from).  Hardware
+    counters cannot be read from inside the timed run: the number is a LOOKUP in the newest committed PMC summary
+    (profiles/r*_pmc_traffic.json, written by tools/pmc_traffic.py from two separate rocprofv3 --pmc passes of this same
+    command by tools/profile_round.sh) and is labelled as such in the JSON line.  (None, None) when no summary matches."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
     m = re.match(r"cin_(fwd|bwd_dz|bwd_dw)_l(\d)$", scope)
     if not files or not m:
-        return None
+        return None, None
     prefix = {"fwd": "cin_fwd3_kernel", "bwd_dz": "cin_dz3_kernel", "bwd_dw": "cin_dw3_kernel<1,false"}[m.group(1)]
     with open(files[-1]) as fh:
         per = json.load(fh)["per_launch"]
@@ -295,10 +302,73 @@ def pmc_traffic(scope):
     hits = sorted((v["first_dispatch"], v["hbm_bytes"]) for k, v in per.items()
                   if k.startswith(prefix) and not k.split(" grid=")[0].endswith(",true>"))
     if len(hits) != 2:
-        return None
+        return None, None
     # two MFMA layers (l = 1, 2): the forward visits l1 then l2, the backward l2 then l1
     first_is_l1 = m.group(1) == "fwd"
-    return hits[0 if (m.group(2) == "1") == first_is_l1 else 1][1]
+    return hits[0 if (m.group(2) == "1") == first_is_l1 else 1][1], "committed profile " + os.path.basename(files[-1])
+
+
+def mfma_util(scope):
+    """MFMA-pipe utilisation of the kernel behind `scope` from the newest committed SQ-counter summary
+    (profiles/r*_mfma_util.json, tools/profile_round.sh); a lookup like pmc_traffic().  None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_mfma_util.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        per = json.load(fh)
+    e = per.get("by_scope", {}).get(scope)
+    if not e:
+        return None
+    return {"mfma_busy_frac": e.get("mfma_busy_frac"), "hbm_frac": e.get("hbm_frac"),
+            "util_source": "committed profile " + os.path.basename(files[-1])}
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh children through torch.distributed.run.
+    The parent has not touched a GPU (no HIP call, no torch.cuda query) and never will; it relays rank 0's JSON line
+    and propagates the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(r.stdout)
+    return r.returncode if r.returncode != 0 or lines else 1
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on the C-level stdout when the first communicator comes up; the contract of this
+    script is ONE JSON line on stdout, so file descriptor 1 points at stderr while the process group initialises."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def timed_steps(step, fence, steps):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -315,135 +385,198 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16_mfma"], help="AutoInt side benchmark only")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of a side benchmark")
     ap.add_argument("--layers", type=int, default=3, help="AutoInt side benchmark: stacked interacting layers (config 5: 3)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: B=4096 per GPU (default); strong: global B=4096 split over the GPUs")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole bucket after the backward")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group and run the collectives even at world size 1 (plumbing check on one GPU)")
+    ap.add_argument("--stub", default="", help=argparse.SUPPRESS)   # tests: module with install(namespace) -> CPU/gloo stand-ins
     args = ap.parse_args()
     if args.workload in ("deepfm", "xdeepfm"):
         return deepfm_benchmark(args)
     if args.workload != "cin":
         return side_benchmark(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
-    if world > 1:
+    from ml_function_amd import dp
+    ns = dict(backend="nccl", device=None, Fn=None, profile=True, shape=dict(batch=B_PER_GPU, conv=CONV, fields=F, embed=K))
+    if args.stub:   # CPU/gloo stand-ins for the kernels (tests/test_dp_gloo.py drives the launcher and the step logic with them)
+        import importlib
+        importlib.import_module(args.stub).install(ns)
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        ns["device"] = torch.device("cuda", local_rank)
+        from ml_function_amd import functional as Fn
+        ns["Fn"] = Fn
+    device, Fn = ns["device"], ns["Fn"]
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = dict(device_id=device) if device.type == "cuda" else {}
+        with stdout_to_stderr():
+            dist.init_process_group(ns["backend"], rank=rank, world_size=world, **kw)
+            dist.barrier()      # first collective: the communicator (and RCCL's banner) comes up here
 
-    from ml_function_amd import _lib
-    from ml_function_amd import functional as Fn
-    inp = make_inputs(rank, device)
-    flat, grads = make_bucket(inp, device)
+    shape = dict(ns["shape"])
+    if args.scaling == "strong":
+        lo, hi = dp.shard_bounds(shape["batch"], rank, world)
+        shape["batch"] = hi - lo
+    inp = make_inputs(rank, device, **shape)
+    flat, grads, segments = make_bucket(inp, device)
+    reducer = dp.LayerwiseAllReduce(flat, segments if not args.no_overlap else [(0, flat.numel())])
+    L = len(inp["Ws"])
+    # event i of the reducer <-> the library's grad_ready slot: segment 0 = head + top layer (ready with layer L-1), ...
+    ready = None
+    if device.type == "cuda" and use_dist and not args.no_overlap:
+        ready = [None] * (L + 1)
+        for i in range(L):
+            ready[L - 1 - i] = reducer.events[i]
 
-    def step():
-        out, pooled, saved = Fn.cin_forward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], inp["dense_b"], 1, args.cin_mode)
-        Fn.cin_backward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], pooled, saved, inp["g"], 1, args.cin_mode, grads=grads)
-        if world > 1:
-            dist.all_reduce(flat)  # sum of layer gradients over the data-parallel ranks (RCCL over xGMI)
+    def compute(mode):
+        out, pooled, saved = Fn.cin_forward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], inp["dense_b"], 1, mode)
+        Fn.cin_backward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], pooled, saved, inp["g"], 1, mode, grads=grads,
+                            ready_events=ready)
+        return out
+
+    def step(mode=args.cin_mode, comm=True):
+        out = compute(mode)
+        if use_dist and comm:
+            if ready is None and device.type == "cuda":   # --no-overlap: the whole bucket after the backward
+                reducer.events[0].record()
+            reducer.launch()   # sum of layer gradients over the data-parallel ranks (RCCL over xGMI)
+            reducer.wait()
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if not use_dist:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    prof_on = ns["profile"]
+    if prof_on:
+        from ml_function_amd import _lib
+    GEMMS = "cin_fwd_l,cin_bwd_dw_l,cin_bwd_dz_l"
     for _ in range(args.warmup):
         step()
-    fence()
     # timed region: HIP events around the three GEMM kernels of every layer only (an event pair costs ~5 us of
     # stream time; with all 13 scopes recorded the step is 2.3 % slower)
-    os.environ["FIL_PROFILE_FILTER"] = "cin_fwd_l,cin_bwd_dw_l,cin_bwd_dz_l"
-    _lib.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = _lib.profile_end()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if prof_on:
+        _lib.profile_begin(GEMMS)
+    dt = max_over_ranks(timed_steps(step, fence, args.steps))
+    prof = _lib.profile_end() if prof_on else {}
+
+    # collective evidence: the same steps without the all-reduce (exposed = difference) and the collectives alone
+    rccl = None
+    if use_dist:
+        dt_nocomm = max_over_ranks(timed_steps(lambda: step(comm=False), fence, args.steps))
+        def comm_only():
+            if device.type == "cuda":
+                for ev in reducer.events:
+                    ev.record()
+            reducer.launch()
+            reducer.wait()
+        for _ in range(2):
+            comm_only()
+        dt_comm = max_over_ranks(timed_steps(comm_only, fence, args.steps))
+        rccl = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                "nccl_version": ".".join(map(str, torch.cuda.nccl.version())) if device.type == "cuda" else None,
+                "allreduce_bytes": int(flat.numel() * 4), "segments_bytes": [int((b - a) * 4) for a, b in reducer.segments],
+                "overlap": "per layer on a side stream, from the top layer down (fil.h grad_ready_events)" if not args.no_overlap
+                           else "none: one all-reduce after the backward",
+                "allreduce_alone_ms": dt_comm / args.steps * 1e3,
+                "step_without_allreduce_ms": dt_nocomm / args.steps * 1e3,
+                "exposed_allreduce_ms": (dt - dt_nocomm) / args.steps * 1e3}
+
     # opt-in experiment, reported beside the headline, never as it: the same step with the general layers' three GEMMs
     # on split-bf16 operands (fil_cin mode bit 1; fp32-equivalent results)
     split = None
-    if args.cin_mode == 0:
-        def step_split():
-            out, pooled, saved = Fn.cin_forward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], inp["dense_b"], 1, 2)
-            Fn.cin_backward_raw(inp["x"], inp["Ws"], inp["bs"], inp["dense_w"], pooled, saved, inp["g"], 1, 2, grads=grads)
-            if world > 1:
-                dist.all_reduce(flat)
+    if args.cin_mode == 0 and prof_on:
         for _ in range(2):
-            step_split()
-        fence()
-        os.environ["FIL_PROFILE_FILTER"] = "cin_fwd_l,cin_bwd_dw_l,cin_bwd_dz_l"
-        _lib.profile_begin()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_split()
-        fence()
-        dt2 = time.perf_counter() - t1
+            step(mode=2)
+        _lib.profile_begin(GEMMS)
+        dt2 = max_over_ranks(timed_steps(lambda: step(mode=2), fence, args.steps))
         prof2 = _lib.profile_end()
-        if world > 1:
-            tmax = torch.tensor([dt2], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt2 = float(tmax.item())
-        split = {"note": "NOT the headline: fil_cin mode 2 = exact-fp32 kernels for the pair-symmetric first layer and the "
-                         "last-layer shortcut, split-bf16 (3 bf16 pieces per fp32 operand, 6 bf16 MFMAs per product, fp32 "
-                         "accumulate) for the general layers' fwd/dW/dZ GEMMs; same 1e-5 parity bar (tests/cin_error_table.py)",
-                 "value": world * B_PER_GPU * args.steps / dt2, "unit": "samples/s", "ms_per_step": dt2 / args.steps * 1e3,
+        split = {"note": "NOT the headline: fil_cin mode 2 = split-bf16 GEMMs (3 bf16 pieces per fp32 operand, 6 bf16 MFMAs per "
+                         "product, fp32 accumulate) for the general layers' fwd/dW/dZ; same 1e-5 parity bar (DESIGN.md 4.1)",
+                 "value": world * shape["batch"] * args.steps / dt2 if args.scaling == "weak" else ns["shape"]["batch"] * args.steps / dt2,
+                 "unit": "samples/s", "ms_per_step": dt2 / args.steps * 1e3,
                  "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(prof2.items())}}
     # separate, untimed pass with every scope recorded: the per-kernel table of the small kernels
-    os.environ["FIL_PROFILE_FILTER"] = ""
-    _lib.profile_begin()
-    for _ in range(max(2, args.steps // 4)):
-        step()
-    fence()
-    prof_all = _lib.profile_end()
-    n_all = max(2, args.steps // 4)
+    prof_all, n_all = {}, max(2, args.steps // 4)
+    if prof_on:
+        _lib.profile_begin(None)
+        for _ in range(n_all):
+            step()
+        fence()
+        prof_all = _lib.profile_end()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * B_PER_GPU * args.steps / dt
-        # dominant kernel = largest total time among the MFMA kernels
-        mf = {k: v for k, v in prof.items() if k.startswith(("cin_fwd_l", "cin_bwd_dw_l", "cin_bwd_dz_l"))}
-        dom = max(mf, key=lambda k: mf[k]["total_ms"])
-        d = mf[dom]
-        achieved = d["work"] / (d["avg_ms"] * 1e-3) / 1e12
-        kernels = {k: dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / n_all,
-                           tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2) if k in mf else None)
-                   for k, v in sorted(prof_all.items())}
-        for k, v in mf.items():  # the GEMM kernels: numbers of the timed region itself
-            kernels[k] = dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / args.steps,
-                              tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2))
-        gpu_ms = sum(v["total_ms"] for v in prof_all.values()) / n_all
+        global_batch = world * shape["batch"] if args.scaling == "weak" else ns["shape"]["batch"]
+        value = global_batch * args.steps / dt
         res = {
             "metric": "samples/sec fwd+bwd xDeepFM-CIN B=4096,F=39,K=16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.cin_mode < 2 else "f32 (forward GEMMs: split-bf16 x3, fp32-equivalent; experiment)", "data": "synthetic",
-            "config": {"workload": "xDeepFM CIN 3x128 feature maps fwd+bwd, F=39 K=16, B=4096 per GPU, fp32 "
-                                   "(BASELINE.json configs[3])", "global_batch": world * B_PER_GPU,
-                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if world > 1 else 0},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
-                         "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["work"]},
-            "kernels": kernels, "gpu_kernel_ms_per_step": gpu_ms,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.cin_mode < 2 else "f32 (GEMMs: split-bf16 x3, fp32-equivalent; experiment)", "data": "synthetic",
+            "config": {"workload": "xDeepFM CIN 3x128 feature maps fwd+bwd, F=39 K=16, B=%d per GPU, fp32 "
+                                   "(BASELINE.json configs[3])" % shape["batch"], "global_batch": global_batch,
+                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if use_dist else 0},
         }
+        if prof:
+            # dominant kernel = largest total time among the MFMA kernels
+            mf = {k: v for k, v in prof.items() if k.startswith(("cin_fwd_l", "cin_bwd_dw_l", "cin_bwd_dz_l"))}
+            dom = max(mf, key=lambda k: mf[k]["total_ms"])
+            d = mf[dom]
+            achieved = d["work"] / (d["avg_ms"] * 1e-3) / 1e12
+            kernels = {k: dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / n_all,
+                               tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2) if k in mf else None)
+                       for k, v in sorted(prof_all.items())}
+            for k, v in mf.items():  # the GEMM kernels: numbers of the timed region itself
+                kernels[k] = dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / args.steps,
+                                  tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2))
+            traffic, traffic_src = pmc_traffic(dom)
+            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_source": traffic_src, "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["work"]}
+            util = mfma_util(dom)
+            if util is not None:
+                res["roofline"].update(util)
+            res["kernels"] = kernels
+            res["gpu_kernel_ms_per_step"] = sum(v["total_ms"] for v in prof_all.values()) / n_all
+        if rccl is not None:
+            res["rccl"] = rccl
         if split is not None:
             res["experiment_split_bf16_gemms"] = split
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
+        if not args.no_cpu_baseline and world == 1 and not args.stub:  # reported at N=1 only (rank 0)
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res))
-    if world > 1:
+        print(json.dumps(res), flush=True)
+    if ns.get("on_done") is not None:   # tests: hand out the bucket of one clean step (the comm-only timing passes re-reduce it)
+        step()
+        fence()
+        ns["on_done"](flat=flat, rank=rank, world=world)
+    if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

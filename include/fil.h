@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 200
+#define FIL_ABI_VERSION 201
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -48,7 +48,7 @@ const char* fil_last_error(void);      /* thread-local, never NULL */
  * fil_profile_end synchronises those events and writes one text line per kernel name into buf:
  *   "<name> <launches> <total_ms> <algorithmic work per launch: flops for MFMA kernels, bytes for streaming>\n"
  * and returns the number of bytes needed (including the NUL).  Not for use under graph capture. */
-int fil_profile_begin(void);
+int fil_profile_begin(const char* filter);   /* filter: "substr[,substr...]" of kernel names to time, NULL = all */
 size_t fil_profile_end(char* buf, size_t cap);
 
 /* ---------------------------------------------------------------------------------------------
@@ -94,6 +94,13 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *             l >= 1 run on split-bf16 operands (every fp32 value as three bf16 pieces, six bf16 MFMAs with fp32
  *             accumulation per product: the same measured error as modes 0/1, but not their exact-fp32 FMA chain);
  *             the pair-symmetric first layer and the last-layer shortcut stay exact fp32.
+ *         + FIL_CIN_MB2 (4) / FIL_CIN_NOSYM (8): per-call launch-shape overrides (64-row waves in the row-parallel kernels,
+ *             i.e. the launch configuration large batches get by themselves; symmetric first-layer kernels off).  Same
+ *             function up to summation order; they exist so that tests can reach every instantiation at small sizes.
+ *   grad_ready_events (bwd; may be NULL): L+1 hipEvent_t handles (entries may be NULL).  [l] is recorded on `stream` once
+ *       dW[l] and dbias[l] are final, [L] once the dense head's gradients are -- from the top layer down, each before the
+ *       data-gradient kernel of its layer starts -- so a data-parallel caller can start the all-reduce of a layer's
+ *       gradients on another stream while the rest of the backward is still running.
  *   Limits: F <= 64, H_l <= 256, L <= 8, L*K <= 255, B*K <= 2^28.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
@@ -105,7 +112,8 @@ int fil_cin_fwd(const float* x, const float* const* W, const float* const* bias,
 int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias, const float* dense_w,
                 const float* pooled, const float* saved, const float* g, float* dx, float* const* dW,
                 float* const* dbias, float* ddense_w, float* ddense_b, int B, int F, int K, int L, const int* H,
-                int output_dim, int mode, void* workspace, size_t workspace_bytes, void* stream);
+                int output_dim, int mode, void* const* grad_ready_events, void* workspace, size_t workspace_bytes,
+                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A4  AutoInt interacting layer -- replaces MultHeadAttentionLayer.call + ProductAttentionLayer.call
@@ -134,7 +142,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
-enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2 };
+enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);

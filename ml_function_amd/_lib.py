@@ -20,7 +20,7 @@ _F = _c.c_float
 SIGNATURES = {
     "fil_version": (_I, []),
     "fil_last_error": (_c.c_char_p, []),
-    "fil_profile_begin": (_I, []),
+    "fil_profile_begin": (_I, [_c.c_char_p]),
     "fil_profile_end": (_Z, [_c.c_char_p, _Z]),
     "fil_fm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fil_fm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -33,7 +33,7 @@ SIGNATURES = {
     "fil_cin_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _P]),
     "fil_cin_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _P]),
     "fil_cin_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
-    "fil_cin_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
+    "fil_cin_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _Z, _P]),
     "fil_attn_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "fil_attn_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "fil_attn_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
@@ -114,8 +114,9 @@ def ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def profile_begin():
-    load().fil_profile_begin()
+def profile_begin(filter=None):
+    """Start per-kernel event timing; filter = "substr,substr" restricts it to the scopes whose name contains one."""
+    load().fil_profile_begin(None if not filter else filter.encode())
 
 
 def profile_end():

@@ -233,24 +233,36 @@ struct XSrc<F16, false> {
   }
 };
 
-// all threads: xs[ch][f][k] = (f16) x[b,f,16ch+k], zero padded
+// all threads: xs[ch][f][k] = (f16) x[b,f,16ch+k], zero padded.  Four 16-byte pieces per thread are fetched before the
+// first is converted (branch-free raw buffer loads: one HBM latency per pass, not one per piece).
 __device__ __forceinline__ void stage_x_f16(const float* __restrict__ x, _Float16* xs, const AttnDims& d, int b, int nthreads) {
   const bool vec = (d.xcw & 3) == 0 && (d.K & 3) == 0;
-  const int per_ch = d.FP * 4;
-  for (int idx = threadIdx.x; idx < d.NC * per_ch; idx += nthreads) {
-    const int ch = idx / per_ch, rem = idx - ch * per_ch;
-    const int f = rem >> 2, p = rem & 3, k0 = 16 * ch + 4 * p;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (f < d.F) {
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)d.B * d.F * d.K * 4);
+  const int per_ch = d.FP * 4, total = d.NC * per_ch;
+  for (int base = threadIdx.x; base < total; base += 4 * nthreads) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * nthreads;
+      const int ch = idx / per_ch, rem = idx - ch * per_ch;
+      const int f = rem >> 2, k0 = 16 * ch + 4 * (rem & 3);
+      const bool rowok = idx < total && f < d.F;
       if (vec) {
-        if (k0 < d.K) v = *reinterpret_cast<const f32x4*>(x + x_off(d, b, f, k0));
+        v[u] = buf_load4(rx, (rowok && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB);
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (k0 + s < d.K) v[s] = x[x_off(d, b, f, k0 + s)];
+        for (int s = 0; s < 4; ++s) v[u][s] = buf_load1(rx, (rowok && k0 + s < d.K) ? 4 * x_off(d, b, f, k0 + s) : kOOB);
       }
     }
-    *reinterpret_cast<f16x4*>(xs + ch * d.FP * 16 + f * 16 + 4 * (p ^ swz16(f))) = __builtin_convertvector(v, f16x4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * nthreads;
+      if (idx < total) {
+        const int ch = idx / per_ch, rem = idx - ch * per_ch;
+        const int f = rem >> 2, p = rem & 3;
+        *reinterpret_cast<f16x4*>(xs + ch * d.FP * 16 + f * 16 + 4 * (p ^ swz16(f))) = __builtin_convertvector(v[u], f16x4);
+      }
+    }
   }
 }
 
@@ -310,6 +322,49 @@ struct SlabLane {
 #pragma unroll
       for (int s = 0; s < 4; ++s) buf_store1(r, f * A4 + off[s], v[s]);
     }
+  }
+};
+
+// Weight fragments of the backward.  f16 mode: an LDS table of 16x16 tiles, tile (m, hh, cc)[kin][a] = W_m[16cc+kin][hh][a]
+// (m = 0 q, 1 k, 2 res), built once per workgroup; row reads give the "reduce over a" fragments, transposing reads the
+// "reduce over kin" ones.  f32 mode: the table would not fit beside the fp32 images, fragments come from global / L1.
+template <bool F16>
+struct WTab;
+template <>
+struct WTab<true> {
+  const _Float16* tab;
+  int nw, NC;
+  __device__ __forceinline__ f16x4 kin(int m, int hh, int cc, int lane) const {          // W[16cc + 4g + s][hh][a = lane&15]
+    return tr_read<true>(tab + ((m * nw + hh) * NC + cc) * 256, 0, lane);
+  }
+  __device__ __forceinline__ f16x4 arole(int m, int hh, int cc, int lane) const {        // W[16cc + (lane&15)][hh][a = 4g + s]
+    return row_read<true>(tab + ((m * nw + hh) * NC + cc) * 256, lane & 15, lane >> 4);
+  }
+};
+template <>
+struct WTab<false> {
+  __amdgpu_buffer_rsrc_t rw[3];
+  int H, A, K;
+  __device__ __forceinline__ void init(const float* Wq, const float* Wk, const float* Wr, const AttnDims& d) {
+    const long bytes = (long)d.K * d.H * d.A * 4;
+    rw[0] = make_rsrc(Wq, bytes);
+    rw[1] = make_rsrc(Wk, bytes);
+    rw[2] = make_rsrc(Wr != nullptr ? Wr : Wq, Wr != nullptr ? bytes : 0);
+    H = d.H; A = d.A; K = d.K;
+  }
+  __device__ __forceinline__ f32x4 kin(int m, int hh, int cc, int lane) const {
+    const int a = lane & 15, k0 = 16 * cc + 4 * (lane >> 4);
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = buf_load1(rw[m], (a < A && k0 + s < K) ? 4 * (((k0 + s) * H + hh) * A + a) : kOOB);
+    return v;
+  }
+  __device__ __forceinline__ f32x4 arole(int m, int hh, int cc, int lane) const {
+    const int kin_ = 16 * cc + (lane & 15), a0 = 4 * (lane >> 4);
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = buf_load1(rw[m], (kin_ < K && a0 + s < A) ? 4 * ((kin_ * H + hh) * A + a0 + s) : kOOB);
+    return v;
   }
 };
 
@@ -413,7 +468,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
         dv[s] = aval[s] ? avT[s] - mu : 0.f;
         sq = fmaf(dv[s], dv[s], sq);
       }
-      const float rstd = 1.0f / sqrtf(groups_sum(sq) * inv_a + eps);
+      const float rstd = __builtin_amdgcn_rsqf(groups_sum(sq) * inv_a + eps);   // v_rsq_f32, 1 ulp
 #pragma unroll
       for (int s = 0; s < 4; ++s) ln[s] = dv[s] * rstd * gam[s] + bet[s];
     }
@@ -438,8 +493,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 //   the wave's own fragments AND are the hand-off to the wave that owns a 16-column chunk of dx (sum over the heads in
 //   MFMA accumulators: fixed order, no dx tile in LDS).  The dk part of dx is added in a second visit by the same lanes.
 // Outputs: dx, per-workgroup partials of dWq/dWk/dWr [G][3][K][H][A] and of dgamma/dbeta [G*H][2][16].
+#ifndef FIL_ATTN_XL_MAXNC
+#define FIL_ATTN_XL_MAXNC 4
+#endif
+#ifndef FIL_ATTN_BWD_WPE
+#define FIL_ATTN_BWD_WPE(NC, F16) 2
+#endif
 template <int NC, bool F16, int NB>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BWD_WPE(NC, F16)))) void attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
     const float* __restrict__ y_s, const float* __restrict__ av_s, float* __restrict__ dx, float* __restrict__ wpart,
@@ -448,7 +509,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
   typedef typename Prec<F16>::Op Op;
   constexpr int RS = Prec<F16>::RS;
   constexpr int TS = 16 * RS;               // elements per 16-row tile
-  constexpr bool XL = F16 && NC <= 2;       // x image in LDS
+  constexpr bool XL = F16 && NC <= FIL_ATTN_XL_MAXNC;   // x image in LDS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;   // == H
@@ -464,22 +525,24 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
   } else {
     xsrc.init(x, d);
   }
+  const int KIS = (d.FP + 16) * RS;           // k image of one head: FP rows + one zero tile (the pipeline reads one tile ahead)
   Elem* kimg0 = reinterpret_cast<Elem*>(sp);
-  Elem* kimg = kimg0 + h * d.FP * RS;
-  sp += (size_t)nw * d.FP * RS * sizeof(Elem);
+  Elem* kimg = kimg0 + h * KIS;
+  sp += (size_t)nw * KIS * sizeof(Elem);
   Elem* tiles0 = reinterpret_cast<Elem*>(sp);
   Elem* tiles = tiles0 + h * 6 * TS;
   sp += (size_t)nw * 6 * TS * sizeof(Elem);
-  Elem* wtab = reinterpret_cast<Elem*>(sp);     // tile (m, hh, cc) at ((m*nw + hh)*NC + cc)*TS: rows = kin, columns = a
-
   const bool use_ln = gamma != nullptr, has_res = Wr != nullptr;
   SlabLane sl;
   sl.init(d.A, 4 * g);
   const float inv_a = 1.0f / (float)d.A;
   const __amdgpu_buffer_rsrc_t r_dx = make_rsrc(dx, (long)d.B * d.F * d.K * 4);
-  // ---- weight table: tile[kin][a] = W_m[16cc + kin][hh][a]; row reads give the "reduce over a" fragments, transposing
-  // reads the "reduce over kin" fragments
-  {
+  WTab<F16> wt;
+  if constexpr (F16) {
+    _Float16* wtab = reinterpret_cast<_Float16*>(sp);     // tile (m, hh, cc) at ((m*nw + hh)*NC + cc)*256
+    wt.tab = wtab;
+    wt.nw = nw;
+    wt.NC = NC;
     const float* Wm[3] = {Wq, Wk, Wr};
     const int ntile = 3 * nw * NC;
     for (int idx = threadIdx.x; idx < ntile * 64; idx += blockDim.x) {
@@ -492,9 +555,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
         for (int s = 0; s < 4; ++s)
           if (4 * a4 + s < d.A) v[s] = Wm[m][((long)kin * d.H + hh) * d.A + 4 * a4 + s];
       }
-      row_write<F16>(wtab + tl * TS, kin_l, a4, to_op<F16>(v));
+      row_write<true>(wtab + tl * 256, kin_l, a4, to_op<true>(v));
     }
+  } else {
+    wt.init(Wq, Wk, Wr, d);
   }
+  row_write<F16>(kimg, d.FP + c, g, to_op<F16>(f32x4{0.f, 0.f, 0.f, 0.f}));   // the zero tile (never written again)
   f32x4 gam = {0.f, 0.f, 0.f, 0.f};
   bool aval[4];
 #pragma unroll
@@ -507,29 +573,25 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
   for (int cc = 0; cc < NC; ++cc) dWq[cc] = dWk[cc] = dWr[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
   const float qs = -scale * 1.4426950408889634f;
-  const Elem* wq_t = wtab + ((0 * nw + h) * NC) * TS;
-  const Elem* wk_t = wtab + ((1 * nw + h) * NC) * TS;
+  // "reduce over kin" weight fragments of this head: the f32 mode keeps them in registers (they would come from global
+  // memory on every use), the f16 mode re-reads its LDS table (registers are what limits its occupancy)
+  Op wq_r[NC], wk_r[NC];
+  if constexpr (!F16) {
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      wq_r[cc] = wt.kin(0, h, cc, lane);
+      wk_r[cc] = wt.kin(1, h, cc, lane);
+    }
+  }
 
   for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
-    __syncthreads();   // weight table built / the previous sample's k (dk) images and x image are no longer read
+    lds_barrier();   // weight table built / the previous sample's k (dk) images and x image are no longer read
     if constexpr (XL) {
       stage_x_f16(x, xs16, d, b, blockDim.x);
-      __syncthreads();
+      lds_barrier();
     } else {
       xsrc.set_sample(d, b);
     }
-    {
-      Op wk[NC];
-#pragma unroll
-      for (int cc = 0; cc < NC; ++cc) wk[cc] = tr_read<F16>(wk_t + cc * TS, 0, lane);
-      project_k<NC, F16>(xsrc, kimg, wk, d.nblk, lane);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    f32x4 dk[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this (head, sample)'s [F][A] rows as raw buffers; a tensor that is not used gets a zero-size descriptor (reads 0)
     const long slab = ((long)h * d.B + b) * d.F * d.A;
     const long slab_bytes = (long)d.F * d.A * 4;
@@ -542,6 +604,18 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
     // block inputs are fetched one query block ahead (they come from HBM)
     f32x4 n_dy = sl.load(r_dy, c), n_y = sl.load(r_ys, c), n_av = sl.load(r_avs, c), n_dr = sl.load(r_dr, c);
 
+    {
+      Op wk[NC];
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) wk[cc] = F16 ? wt.kin(1, h, cc, lane) : wk_r[cc];
+      project_k<NC, F16>(xsrc, kimg, wk, d.nblk, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4 dk[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < d.nblk; ++i) {
       const int par = i & 1;
       f32x4 dz = n_dy, dr = n_dr;
@@ -573,7 +647,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
           xh[s] = aval[s] ? avv[s] - mu : 0.f;
           sq = fmaf(xh[s], xh[s], sq);
         }
-        const float rstd = 1.0f / sqrtf(groups_sum(sq) * inv_a + eps);
+        const float rstd = __builtin_amdgcn_rsqf(groups_sum(sq) * inv_a + eps);   // v_rsq_f32, 1 ulp
         float s1 = 0.f, s2 = 0.f;
         f32x4 dxh;
 #pragma unroll
@@ -599,51 +673,63 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) {
         const Op xr = xsrc.row(i, cc, lane);
-        const Op wq = tr_read<F16>(wq_t + cc * TS, 0, lane);
+        const Op wq = F16 ? wt.kin(0, h, cc, lane) : wq_r[cc];
         qT = mma<F16>(wq, xr, qT);   // [a 4g+r][query c] -> row fragment of q_i
         qD = mma<F16>(xr, wq, qD);   // [query 4g+r][a c] -> column fragment of q_i
       }
       const Op qn = to_op<F16>(qT * qs);     // scores come out as -log2(e) * scale * q.k
       const Op qc = to_op<F16>(qD * scale);  // dk += dP^T (scale q)
       f32x4 dqT = {0.f, 0.f, 0.f, 0.f};
-      // ---- the score tiles, software-pipelined: [reads + S, dS of tile j+1] [sigmoid, dk of tile j] [dq of tile j-1]
-      Op kT_cur, kT_prev = kT_cur = to_op<F16>(f32x4{0.f, 0.f, 0.f, 0.f});
-      f32x4 sc_n = {0.f, 0.f, 0.f, 0.f}, ds_n = {0.f, 0.f, 0.f, 0.f};
-      {
-        const Op kB = row_read<F16>(kimg, c, g);
-        kT_cur = tr_read<F16>(kimg, 0, lane);
-        sc_n = mma<F16>(qn, kB, sc_n);
-        ds_n = mma<F16>(dav_r, kB, ds_n);
-      }
+      // ---- the score tiles, software-pipelined over three tiles: [LDS reads of tile j+1] [sigmoid + dk of tile j]
+      // [S, dS of tile j+1] [dq of tile j-1].  The k image carries one zero tile behind the last key block, so the reads
+      // and products of tile j+1 need no guard; leaving the unrolled loop with `break` keeps the exit test scalar.
+      Op kB_n = row_read<F16>(kimg, c, g);                    // k[key c][a 4g+s]
+      Op kT_n = tr_read<F16>(kimg, 0, lane);                  // k[key 4g+s][a c]
+      f32x4 sc_n = mma<F16>(qn, kB_n, f32x4{0.f, 0.f, 0.f, 0.f});        // [query 4g+r][key c]
+      f32x4 ds_n = mma<F16>(dav_r, kB_n, f32x4{0.f, 0.f, 0.f, 0.f});     // dS = dav k^T
+      Op kT_prev = kT_n;
+      // one tile; J is a compile-time index (the dk accumulators must stay in registers)
+      auto tile_step = [&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+        const f32x4 sc = sc_n, ds = ds_n;
+        const Op kT_j = kT_n;
+        Op dpT = kT_n;
+        if constexpr (j > 0) dpT = tr_read<F16>(tiles + ((j - 1) & 1) * TS, 0, lane);   // dP[query c][key 4g+s] of tile j-1
+        kB_n = row_read<F16>(kimg, 16 * (j + 1) + c, g);
+        kT_n = tr_read<F16>(kimg, 16 * (j + 1), lane);
+        f32x4 sg, dp;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        if (j < d.nblk) {
-          const f32x4 sc = sc_n, ds = ds_n;
-          const Op kT_j = kT_cur;
-          if (j + 1 < NB && j + 1 < d.nblk) {
-            const Op kB = row_read<F16>(kimg, 16 * (j + 1) + c, g);   // k[key c][a 4g+s]
-            kT_cur = tr_read<F16>(kimg, 16 * (j + 1), lane);          // k[key 4g+s][a c]
-            sc_n = mma<F16>(qn, kB, f32x4{0.f, 0.f, 0.f, 0.f});       // [query 4g+r][key c]
-            ds_n = mma<F16>(dav_r, kB, f32x4{0.f, 0.f, 0.f, 0.f});    // dS = dav k^T
-          }
-          f32x4 sg, dp;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            sg[r] = sigmoid_from_neg_log2(sc[r]);
-            dp[r] = ds[r] * fmaf(-sg[r], sg[r], sg[r]);       // dS S (1-S); the 1/sqrt(A) factor rides on qc and dq
-          }
-          const Op dp_o = to_op<F16>(dp), sg_o = to_op<F16>(sg);
-          if (j > 0) {
-            const Op dpT = tr_read<F16>(tiles + ((j - 1) & 1) * TS, 0, lane);   // dP[query c][key 4g+s] of tile j-1
-            dqT = mma<F16>(kT_prev, dpT, dqT);                // dq^T[a 4g+r][query c] += k^T dP^T
-          }
-          row_write<F16>(tiles + (j & 1) * TS, c, g, dp_o);   // [key c][query 4g..4g+3]
-          dk[j] = mma<F16>(qc, dp_o, dk[j]);                  // dk^T[a 4g+r][key c] += (scale q)^T dP
-          dk[j] = mma<F16>(dav_c, sg_o, dk[j]);               //                     += dav^T S      (V == K)
-          kT_prev = kT_j;
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sc[r]);        // exp(-score)
+          sg[r] = __builtin_amdgcn_rcpf(1.0f + e);
+          dp[r] = ds[r] * (e * sg[r] * sg[r]);                  // dS S (1-S), 1-S = e S; the 1/sqrt(A) factor rides on qc and dq
         }
+        const Op dp_o = to_op<F16>(dp), sg_o = to_op<F16>(sg);
+        sc_n = mma<F16>(qn, kB_n, f32x4{0.f, 0.f, 0.f, 0.f});
+        ds_n = mma<F16>(dav_r, kB_n, f32x4{0.f, 0.f, 0.f, 0.f});
+        if constexpr (j > 0) dqT = mma<F16>(kT_prev, dpT, dqT);   // dq^T[a 4g+r][query c] += k^T dP^T
+        row_write<F16>(tiles + (j & 1) * TS, c, g, dp_o);     // [key c][query 4g..4g+3]
+        dk[j] = mma<F16>(qc, dp_o, dk[j]);                    // dk^T[a 4g+r][key c] += (scale q)^T dP
+        dk[j] = mma<F16>(dav_c, sg_o, dk[j]);                 //                     += dav^T S      (V == K)
+        kT_prev = kT_j;
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      // straight-line tiles with a scalar exit test each (a `break` in an unrolled loop re-rolls it and sends dk to scratch;
+      // the count is laundered through an empty asm so that the NB exit conditions are not hoisted out of the block loop
+      // as NB lane masks, which then live in spilled SGPRs)
+      int nb_s = d.nblk;
+      asm volatile("" : "+s"(nb_s));
+#define FIL_TILE(J)                                             \
+  if constexpr (J < NB) {                                       \
+    if (J >= nb_s) goto tiles_done;                             \
+    tile_step(std::integral_constant<int, J>{});                \
+  }
+      FIL_TILE(0) FIL_TILE(1) FIL_TILE(2) FIL_TILE(3) FIL_TILE(4) FIL_TILE(5) FIL_TILE(6) FIL_TILE(7)
+      FIL_TILE(8) FIL_TILE(9) FIL_TILE(10) FIL_TILE(11) FIL_TILE(12) FIL_TILE(13) FIL_TILE(14) FIL_TILE(15)
+      FIL_TILE(16) FIL_TILE(17) FIL_TILE(18) FIL_TILE(19) FIL_TILE(20) FIL_TILE(21) FIL_TILE(22) FIL_TILE(23)
+      FIL_TILE(24) FIL_TILE(25) FIL_TILE(26) FIL_TILE(27) FIL_TILE(28) FIL_TILE(29) FIL_TILE(30) FIL_TILE(31)
+#undef FIL_TILE
+    tiles_done:
       {
         const Op dpT = tr_read<F16>(tiles + ((d.nblk - 1) & 1) * TS, 0, lane);
         dqT = mma<F16>(kT_prev, dpT, dqT);
@@ -667,8 +753,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
         f32x4 px = {0.f, 0.f, 0.f, 0.f};
         for (int hh = 0; hh < nw; ++hh) {
           const Elem* th = tiles0 + (hh * 6 + 2 + 2 * par) * TS;
-          px = mma<F16>(row_read<F16>(th, c, g), row_read<F16>(wtab + ((0 * nw + hh) * NC + cc) * TS, c, g), px);
-          if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), row_read<F16>(wtab + ((2 * nw + hh) * NC + cc) * TS, c, g), px);
+          px = mma<F16>(row_read<F16>(th, c, g), wt.arole(0, hh, cc, lane), px);
+          if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), wt.arole(2, hh, cc, lane), px);
         }
         const int kin = 16 * cc + c;
 #pragma unroll
@@ -687,17 +773,31 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(
       const Op dk_c = tr_read<F16>(kimg, 16 * j, lane);       // dk[key 4g+s][a c]
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) dWk[cc] = mma<F16>(xsrc.col(j, cc, lane), dk_c, dWk[cc]);
-      for (int cc = h; cc < NC; cc += nw) {
-        f32x4 px = {0.f, 0.f, 0.f, 0.f};
-        for (int hh = 0; hh < nw; ++hh)
-          px = mma<F16>(row_read<F16>(kimg0 + hh * d.FP * RS, 16 * j + c, g),
-                        row_read<F16>(wtab + ((1 * nw + hh) * NC + cc) * TS, c, g), px);
-        const int kin = 16 * cc + c;
+    }
+    // dx += dk Wk^T (summed over the heads), by the lanes that wrote the dq part of the same elements.  All of a chunk's
+    // read-backs are issued before the first is used (they come from L2 / the Infinity Cache; the dk accumulators'
+    // registers are free by now).
+    for (int cc = h; cc < NC; cc += nw) {
+      const int kin = 16 * cc + c;
+      f32x4 old[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * j + 4 * g + r;
-          const int o = (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB;
-          buf_store1(r_dx, o, buf_load1(r_dx, o) + px[r]);     // the lanes that wrote the dq part add the dk part
+          old[j][r] = buf_load1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
+        }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j < d.nblk) {
+          f32x4 px = old[j];
+          for (int hh = 0; hh < nw; ++hh)
+            px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * j + 4 * g + r;
+            buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);
+          }
         }
       }
     }
@@ -797,10 +897,10 @@ static size_t fwd_lds(const AttnDims& d, bool f16) {
 static size_t bwd_lds(const AttnDims& d, bool f16) {
   const size_t tiles = (size_t)d.H * 6 + 3 * (size_t)d.H * d.NC;   // per-wave tiles + the weight table
   if (f16) {
-    const size_t ximg = d.NC <= 2 ? (size_t)d.NC * d.FP * 16 : 0;
-    return (ximg + (size_t)d.H * d.FP * 16 + tiles * 256) * sizeof(_Float16);
+    const size_t ximg = d.NC <= FIL_ATTN_XL_MAXNC ? (size_t)d.NC * d.FP * 16 : 0;
+    return (ximg + (size_t)d.H * (d.FP + 16) * 16 + tiles * 256) * sizeof(_Float16);
   }
-  return ((size_t)d.H * d.FP * 20 + tiles * 320) * sizeof(float);
+  return ((size_t)d.H * (d.FP + 16) * 20 + (size_t)d.H * 6 * 320) * sizeof(float);   // no weight table in the f32 mode
 }
 constexpr size_t kLdsCap = 160 * 1024;
 constexpr int kMaxBwdGrid = 1024;   // persistent workgroups (the workspace holds this many partial sums)

@@ -49,15 +49,30 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v != nullptr && *v != 0 ? atoi(v) : dflt;
 }
-// FIL_CIN_MB=1|2 overrides the choice (tuning knob; results are identical up to summation order)
-static int mb_rows(long M) {
-  const int forced = env_int("FIL_CIN_MB", 0);
-  if (forced == 1 || forced == 2) return forced;
-  return cdiv((int)std::min<long>(M, 1L << 30), 64) >= 768 ? 2 : 1;
+// Process-level tuning knobs, read from the environment ONCE (first call into the library), never on the launch path:
+//   FIL_CIN_MB=1|2        rows per wave (x32) of the row-parallel kernels (default: by M)
+//   FIL_CIN_SYM=0         symmetric first-layer kernels off
+//   FIL_CIN_DW_MB, FIL_CIN_DW_SPLITS, FIL_CIN_DZ_MB   launch shape of the dW / dZ kernels
+// Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
+// (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
+struct Knobs {
+  int mb, sym, dw_mb, dw_splits, dz_mb;
+};
+static const Knobs& knobs() {
+  static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
+                          env_int("FIL_CIN_DZ_MB", 1)};
+  return k;
 }
-
-// FIL_CIN_SYM=0 turns the symmetric first-layer kernels off (tuning / A-B knob; results agree to fp32 rounding)
-static bool sym_first_layer() { return env_int("FIL_CIN_SYM", 1) != 0; }
+// per-call view of the knobs: the process defaults with the call's mode bits applied
+struct CinTune {
+  int mb_forced;
+  bool sym;
+  explicit CinTune(int mode) : mb_forced((mode & FIL_CIN_MB2) ? 2 : knobs().mb), sym(knobs().sym != 0 && !(mode & FIL_CIN_NOSYM)) {}
+  int mb_rows(long M) const {
+    if (mb_forced == 1 || mb_forced == 2) return mb_forced;
+    return cdiv((int)std::min<long>(M, 1L << 30), 64) >= 768 ? 2 : 1;
+  }
+};
 
 static const char* kFwdNames[kCinMaxL] = {"cin_fwd_l1", "cin_fwd_l2", "cin_fwd_l3", "cin_fwd_l4", "cin_fwd_l5", "cin_fwd_l6", "cin_fwd_l7", "cin_fwd_l8"};
 static const char* kDwNames[kCinMaxL] = {"cin_bwd_dw_l1", "cin_bwd_dw_l2", "cin_bwd_dw_l3", "cin_bwd_dw_l4", "cin_bwd_dw_l5", "cin_bwd_dw_l6", "cin_bwd_dw_l7", "cin_bwd_dw_l8"};
@@ -86,14 +101,14 @@ static int cu_count() {
 static DwPlan dw_plan(long M, int C, int H) {
   DwPlan p;
   p.chunks = chunks_of(H);
-  p.MB = env_int("FIL_CIN_DW_MB", 1) == 2 ? 2 : 1;   // 64 rows per wave measured slower (67 vs 122 TFLOP/s)
+  p.MB = knobs().dw_mb == 2 ? 2 : 1;   // 64 rows per wave measured slower (67 vs 122 TFLOP/s)
   const int waves_c = cdiv(C, 32 * p.MB);
   p.blocks_x = cdiv(waves_c, 4);
   const long tiles = (long)p.blocks_x * p.chunks;
   const long ncu = cu_count();
   const long unit = 2 * kDwDepth;
   auto rows_of = [&](int splits) { return std::max<long>(unit, ((M + splits - 1) / splits + unit - 1) / unit * unit); };
-  int best = env_int("FIL_CIN_DW_SPLITS", 0);
+  int best = knobs().dw_splits;
   if (best <= 0) {
     static const double t_of[4] = {0.0, 1.05e-4, 1.39e-4, 1.96e-4};
     double best_ms = -1.0;
@@ -234,8 +249,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 3) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bit 0: general kernels for every layer; bit 1: split-bf16 GEMMs)", mode);
+  if (mode < 0 || mode > 15) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
+  const CinTune tune(mode);
   mode &= 1;
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && W && bias && pooled && saved);
@@ -244,7 +260,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     return fail(FIL_ERR_WORKSPACE, "fil_cin_fwd: workspace %zu < %zu bytes", workspace_bytes, fwd_ws_bytes(s));
   hipStream_t st = (hipStream_t)stream;
   const long M = s.M();
-  const int JT = s.JT(), MB = mb_rows(M);
+  const int JT = s.JT(), MB = tune.mb_rows(M);
   Carver ws(workspace);
   PoolArgs pa;
   for (int l = 0; l < L; ++l) {
@@ -269,7 +285,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     float* part = const_cast<float*>(pa.part[l]);
     // mode 0, last layer: only its sum-pool is observable -> contract with wsum[c] = sum_n W[c,n].  When the layer
     // below it runs the general (non pair-symmetric) forward kernel, that kernel's epilogue does it (fused_last).
-    const bool fuse_next = mode == 0 && l == L - 2 && !(l == 0 && sym_first_layer());
+    const bool fuse_next = mode == 0 && l == L - 2 && !(l == 0 && tune.sym);
     if (l == L - 1 && mode == 0) {
       if (!fused_last) {
         const size_t sh = (size_t)Hp * ((F + 3) & ~3) * sizeof(float);
@@ -281,7 +297,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       }
     } else {
       const int chunks = chunks_of(Hl);
-      if (l == 0 && sym_first_layer()) {
+      if (l == 0 && tune.sym) {
         // first layer: x^{l-1} = x, reduce over unordered field pairs (half the steps)
         const int JTs = cin_jt_sym(F);
         const long npack = (long)chunks * F * 2 * JTs * 128;
@@ -329,17 +345,25 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
 extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias, const float* dense_w,
                            const float* pooled, const float* saved, const float* g, float* dx, float* const* dW,
                            float* const* dbias, float* ddense_w, float* ddense_b, int B, int F, int K, int L, const int* H,
-                           int output_dim, int mode, void* workspace, size_t workspace_bytes, void* stream) {
+                           int output_dim, int mode, void* const* grad_ready_events, void* workspace, size_t workspace_bytes,
+                           void* stream) {
   (void)bias; (void)x;
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 3) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bit 0: general kernels for every layer; bit 1: split-bf16 GEMMs)", mode);
+  if (mode < 0 || mode > 15) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (general layers l >= 1; the pair-symmetric first layer and the last-layer shortcut stay exact fp32)
+  const CinTune tune(mode);
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
   hipStream_t st = (hipStream_t)stream;
   const size_t LK = (size_t)L * K;
+  // grad_ready_events[l] (l < L): recorded once dW[l] and dbias[l] are final; [L]: the dense head's gradients.  The
+  // data-parallel caller makes a side stream wait on them and starts each layer's all-reduce while the rest of the
+  // backward is still running (gradients become final from the top layer down).
+  auto ready = [&](int slot) {
+    if (grad_ready_events != nullptr && grad_ready_events[slot] != nullptr) (void)hipEventRecord((hipEvent_t)grad_ready_events[slot], st);
+  };
   if (B == 0) {  // empty batch: parameter gradients are zero
     for (int l = 0; l < L; ++l) {
       (void)hipMemsetAsync(dW[l], 0, (size_t)s.Hp(l) * F * H[l] * sizeof(float), st);
@@ -349,6 +373,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       (void)hipMemsetAsync(ddense_w, 0, LK * sizeof(float), st);
       (void)hipMemsetAsync(ddense_b, 0, sizeof(float), st);
     }
+    for (int l = 0; l <= L; ++l) ready(l);
     return FIL_OK;
   }
   FIL_CHECK_ARG(g && dx && saved);
@@ -393,6 +418,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     (void)hipMemcpyAsync(ddense_b, tmp + LK, sizeof(float), hipMemcpyDeviceToDevice, st);
     dPsrc = dP;
   }
+  ready(L);
 
   int cur = 0;
   int ltop = L - 1;          // first layer handled by the general kernels
@@ -423,6 +449,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)cl, 64)), dim3(256), 0, st, part, vlast, (long)cl, nb);
       hipLaunchKernelGGL(cin_fill_rows_kernel, dim3((int)std::min<long>(((long)cl * Hl + 255) / 256, 2048)), dim3(256), 0, st, vlast, dW[l], (long)cl, Hl);
     }
+    ready(l);
     // G^{L-1} and dX
     if (l > 0) {
       // (the dZ kernels' packed-W buffer is idle here: scratch for wsum in the MFMA operand layout)
@@ -460,7 +487,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     // dW
     int parts;
-    const int symD = (l == 0 && sym_first_layer()) ? F / 2 + 1 : 0;   // unordered field pairs: half the channels
+    const int symD = (l == 0 && tune.sym) ? F / 2 + 1 : 0;   // unordered field pairs: half the channels
     const int Cl = symD > 0 ? F * symD : Hp * F;
     {
       ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl));
@@ -489,15 +516,16 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       }
     }
     FIL_CHECK_LAUNCH();
+    ready(l);   // dW[l], dbias[l] final: the dZ kernel of this layer and everything below can overlap their all-reduce
     // dZ -> G^{l-1}, dX
     {
       const int NHMAX = HSl / 2;                  // 64 (H <= 128) or 128
-      const int MB = NHMAX == 128 ? 1 : mb_rows(M);      // pair-symmetric first layer: 64 rows per wave measured best
+      const int MB = NHMAX == 128 ? 1 : tune.mb_rows(M);      // pair-symmetric first layer: 64 rows per wave measured best
       // general dZ kernel: 32 rows per wave, two waves per SIMD -- the second wave covers the issue time of the first
       // one's register contraction (c4: 0.715 -> 0.687 ms exact fp32, 0.436 -> 0.420 split-bf16); FIL_CIN_DZ_MB overrides
-      const int MBg = NHMAX == 128 ? 1 : (env_int("FIL_CIN_DZ_MB", 1) == 2 ? 2 : 1);
+      const int MBg = NHMAX == 128 ? 1 : (knobs().dz_mb == 2 ? 2 : 1);
       const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
-      if (l == 0 && sym_first_layer() && F >= 2) {
+      if (l == 0 && tune.sym && F >= 2) {
         // first layer over unordered field pairs (half the tiles); F = 1 would make both lane halves hit one word
         const int JTs = cin_jt_sym(F);
         const int periods = cdiv(F, cin_dz_h_per_period(JTs));

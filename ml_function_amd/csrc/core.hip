@@ -51,13 +51,12 @@ static hipEvent_t pool_event() {
   return g_pool[g_pool_next++];
 }
 
-// FIL_PROFILE_FILTER=<substr>[,<substr>...] (read at fil_profile_begin): only scopes whose name contains one of the
+// fil_profile_begin(filter): filter = "<substr>[,<substr>...]" or NULL; only scopes whose name contains one of the
 // substrings record events -- an event pair costs about 5 us of stream time per scope, so bench.py's timed region
 // profiles the GEMM kernels only and takes the full per-kernel table from a separate pass.
 static std::vector<std::string> g_prof_filter;
-static void load_filter() {
+static void load_filter(const char* f) {
   g_prof_filter.clear();
-  const char* f = getenv("FIL_PROFILE_FILTER");
   if (f == nullptr) return;
   std::string cur;
   for (const char* p = f;; ++p) {
@@ -93,11 +92,11 @@ void prof_end_scope(hipStream_t st) {
 
 }  // namespace fil
 
-extern "C" int fil_profile_begin(void) {
+extern "C" int fil_profile_begin(const char* filter) {
   std::lock_guard<std::mutex> lk(fil::g_prof_mu);
   fil::g_prof.clear();
   fil::g_pool_next = 0;
-  fil::load_filter();
+  fil::load_filter(filter);
   fil::g_prof_on = true;
   return FIL_OK;
 }

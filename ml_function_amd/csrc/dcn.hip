@@ -294,8 +294,11 @@ __global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict
 // dw/db that the reduction has to read back (256: bwd + reduce 49 us at c3, 512: 67 us, 1024: 105 us).
 // FIL_DCN_GRID overrides both (tuning knob).
 static int dcn_grid_cap(int B, int cap) {
-  const char* e = getenv("FIL_DCN_GRID");
-  if (e != nullptr && atoi(e) > 0) cap = atoi(e);
+  static const int forced = [] {   // read once, never on the launch path
+    const char* e = getenv("FIL_DCN_GRID");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  if (forced > 0) cap = forced;
   return std::max(1, std::min(cdiv(B, kDcnWaves), cap));
 }
 static int dcn_grid(int B) { return dcn_grid_cap(B, 256); }        // backward (and its workspace sizing)

@@ -61,6 +61,77 @@ class GradBucket:
             p.grad = v
 
 
+class LayerwiseAllReduce:
+    """All-reduce of a flat gradient bucket in SEGMENTS, each started as soon as its gradients are final.
+
+    The CIN backward produces parameter gradients from the top layer down, each before the (long) data-gradient kernel
+    of its layer (fil.h: grad_ready_events).  `segments` are element ranges [lo, hi) of `flat` in that order;
+    `events[i]` is the torch.cuda.Event the library records when segment i is final.  launch() -- called right after the
+    backward has been ENQUEUED -- makes a side stream wait on each event and issues that segment's all-reduce there, so
+    the collectives (RCCL kernels, a handful of workgroups) run underneath the remaining backward kernels; wait() joins
+    them into the current stream.  On CPU tensors (gloo tests) there are no streams: launch() reduces synchronously.
+    Sums are over ranks in the backend's fixed order, segment boundaries never split a reduction, so the result is the
+    same as one all-reduce of the whole bucket."""
+
+    def __init__(self, flat, segments, group=None):
+        self.flat, self.segments, self.group = flat, [(int(a), int(b)) for a, b in segments], group
+        assert all(0 <= a <= b <= flat.numel() for a, b in self.segments)
+        self.cuda = flat.is_cuda
+        self.events = [torch.cuda.Event() for _ in self.segments] if self.cuda else [None] * len(self.segments)
+        self.side = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self._works = []
+
+    def active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def launch(self):
+        if not self.active():
+            return
+        if not self.cuda:
+            for lo, hi in self.segments:
+                if hi > lo:
+                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        for ev, (lo, hi) in zip(self.events, self.segments):
+            if hi <= lo:
+                continue
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Make the current stream wait for every segment's collective (call before anything reads the gradients)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.cuda and self.active():
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+def cin_bucket_layout(W_shapes, b_shapes, head_shapes):
+    """Flat gradient bucket of a CIN in the order the backward finishes them: [head | layer L-1 | ... | layer 0], each
+    layer as (dW_l, dbias_l).  Returns (sizes, segments, index) where segments[i] is the element range that becomes
+    final with event i (segment 0 = head + top layer, then one per layer downwards) and index maps
+    ("W", l) / ("b", l) / ("head", j) to its position in `sizes`."""
+    L = len(W_shapes)
+    sizes, index = [], {}
+    for j, sh in enumerate(head_shapes):
+        index[("head", j)] = len(sizes)
+        sizes.append(int(torch.Size(sh).numel()))
+    bounds = []
+    for l in range(L - 1, -1, -1):
+        index[("W", l)] = len(sizes)
+        sizes.append(int(torch.Size(W_shapes[l]).numel()))
+        index[("b", l)] = len(sizes)
+        sizes.append(int(torch.Size(b_shapes[l]).numel()))
+        bounds.append(sum(sizes))
+    segments, lo = [], 0
+    for hi in bounds:
+        segments.append((lo, hi))
+        lo = hi
+    return sizes, segments, index
+
+
 def allreduce_module_grads(module, group=None):
     """Bucketed all-reduce of the gradients of every parameter of `module` (after backward)."""
     params = [p for p in module.parameters() if p.requires_grad]

@@ -167,9 +167,11 @@ def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0):
     return out, pooled, saved
 
 
-def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0, grads=None):
+def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0, grads=None, ready_events=None):
     """Raw backward.  grads (optional): dict with preallocated 'dx','dW'(list),'db'(list),'ddw','ddb' tensors
-    (e.g. views into one flat all-reduce bucket).  Returns the dict."""
+    (e.g. views into one flat all-reduce bucket).  ready_events (optional): L+1 torch.cuda.Event objects (or None
+    entries), recorded as each layer's / the head's parameter gradients become final (fil.h: grad_ready_events).
+    Returns the dict."""
     lib = _lib.load()
     B, F, K = x.shape
     L = len(Ws)
@@ -181,9 +183,17 @@ def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0,
                      ddb=torch.empty((1,), dtype=torch.float32, device=x.device) if output_dim == 1 else None)
     nws = lib.fil_cin_bwd_workspace_bytes(B, F, K, L, Harr)
     ws = _workspace(nws, x.device)
+    evs = None
+    if ready_events is not None:
+        if len(ready_events) != L + 1:
+            raise FilError("cin: ready_events must have L+1 = %d entries" % (L + 1))
+        for e in ready_events:      # a torch event only owns a hipEvent_t once it has been recorded
+            if e is not None and not e.cuda_event:
+                e.record()
+        evs = (ctypes.c_void_p * (L + 1))(*[None if e is None else e.cuda_event for e in ready_events])
     check(lib.fil_cin_bwd(ptr(x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(pooled), ptr(saved), ptr(g),
                           ptr(grads["dx"]), ptr_array(grads["dW"]), ptr_array(grads["db"]), ptr(grads["ddw"]),
-                          ptr(grads["ddb"]), B, F, K, L, Harr, output_dim, mode, ptr(ws), nws, stream_ptr()), "fil_cin_bwd")
+                          ptr(grads["ddb"]), B, F, K, L, Harr, output_dim, mode, evs, ptr(ws), nws, stream_ptr()), "fil_cin_bwd")
     return grads
 
 

@@ -79,6 +79,96 @@ def test_gradient_allreduce_equals_full_batch(tmp_path):
     assert np.abs(flat - want).max() / np.abs(want).max() < 1e-6
 
 
+def _layerwise_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, F, K, conv = 10, 5, 4, [6, 7, 3]
+        c = synth.cin_case(B, F, K, conv, dist="normal")
+        lo, hi = dp.shard_bounds(B, rank, world)
+        _, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"][lo:hi], c["Ws"], c["bs"], c["dense_w"], c["g"][lo:hi])
+        sizes, segments, index = dp.cin_bucket_layout([w.shape for w in dWs], [b.shape for b in dbs], [ddw.shape, (1,)])
+        flat = torch.zeros(sum(sizes))
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        put = lambda key, a: flat[offs[index[key]]:offs[index[key] + 1]].copy_(torch.tensor(np.asarray(a, np.float32).reshape(-1)))
+        for l in range(len(conv)):
+            put(("W", l), dWs[l])
+            put(("b", l), dbs[l])
+        put(("head", 0), ddw)
+        put(("head", 1), ddb)
+        red = dp.LayerwiseAllReduce(flat, segments)
+        assert red.active() and red.events == [None] * len(conv)
+        red.launch()
+        red.wait()
+        if rank == 0:
+            np.save(os.path.join(out_dir, "flat.npy"), flat.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cin_bucket_layout_is_in_readiness_order():
+    sizes, segments, index = dp.cin_bucket_layout([(15, 6), (30, 7), (35, 3)], [(6,), (7,), (3,)], [(12, 1), (1,)])
+    # [head | layer 2 | layer 1 | layer 0]; segment 0 (head + top layer) is final first, then one layer at a time downwards
+    assert sizes == [12, 1, 105, 3, 210, 7, 90, 6]
+    assert segments == [(0, 121), (121, 338), (338, 434)] and segments[-1][1] == sum(sizes)
+    assert index[("W", 2)] == 2 and index[("b", 0)] == 7 and index[("head", 1)] == 1
+
+
+def test_layerwise_allreduce_equals_full_batch(tmp_path):
+    """The bucket reduced segment by segment (the order bench.py overlaps them in) == gradient of the full batch."""
+    world = 2
+    mp.spawn(_layerwise_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    flat = np.load(tmp_path / "flat.npy")
+    B, F, K, conv = 10, 5, 4, [6, 7, 3]
+    c = synth.cin_case(B, F, K, conv, dist="normal")
+    _, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"])
+    want = np.concatenate([ddw.reshape(-1), ddb.reshape(-1)] + [np.concatenate([dWs[l].reshape(-1), dbs[l].reshape(-1)]) for l in (2, 1, 0)])
+    assert flat.shape == want.shape and np.abs(flat - want).max() / np.abs(want).max() < 1e-6
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks itself (torch.distributed.run
+    children), relays rank 0's JSON line and the exit code.  The kernels are replaced by CPU stand-ins (tests/bench_stub.py:
+    gloo, oracle gradients), everything else -- launcher, bucket layout, layer-wise all-reduce, timing protocol,
+    max-over-ranks, JSON -- is bench.py's own code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FIL_STUB_OUT"] = str(tmp_path)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--stub", "tests.bench_stub"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0 and res["steps"] == 2
+    assert res["config"]["global_batch"] == 24 and res["config"]["parallelism"] == "dp2"
+    assert res["rccl"]["world_size_seen"] == 2 and res["rccl"]["backend"] == "gloo" and res["rccl"]["allreduce_bytes"] > 0
+    assert "cpu_baseline" not in res          # reported at N = 1 only
+    # the reduced bucket: identical on both ranks, equal to the sum of the two shards' gradients
+    from tests import bench_stub
+    f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
+    assert np.array_equal(f0, f1)
+    sh = bench_stub.SHAPE
+    par = synth.cin_case(sh["batch"], sh["fields"], sh["embed"], sh["conv"], seed=synth.SEED)
+    want = None
+    for rank in range(2):
+        d = synth.cin_case(sh["batch"], sh["fields"], sh["embed"], sh["conv"], seed=synth.SEED + 1 + rank)
+        _, dWs, dbs, ddw, ddb = closed.cin_bwd(d["x"], par["Ws"], par["bs"], par["dense_w"], d["g"][:, :1])
+        v = np.concatenate([ddw.reshape(-1), ddb.reshape(-1)] + [np.concatenate([dWs[l].reshape(-1), dbs[l].reshape(-1)]) for l in (1, 0)])
+        want = v if want is None else want + v
+    assert np.abs(f0 - want).max() / np.abs(want).max() < 1e-5
+    # a rank count that does not match an existing launcher environment is an error, not a silent single-GPU run
+    env_bad = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub", "tests.bench_stub"], env=env_bad,
+                       cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+
+
 def _sparse_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
