@@ -230,8 +230,9 @@ def test_pmc_traffic_summary_and_bench_lookup(tmp_path, monkeypatch):
     assert per["cin_fwd3_kernel<2,20,false,false> grid=64"]["hbm_bytes"] == (2 * 20.0 + 2.0) * 1024
     import bench
     monkeypatch.setattr(bench.os.path, "dirname", lambda p: str(tmp_path))  # bench looks under <its dir>/profiles
-    assert bench.pmc_traffic("cin_fwd_l2") == (2 * 20.0 + 2.0) * 1024      # not the split instantiation (99 / 9)
-    assert bench.pmc_traffic("cin_fwd_l1") == (2 * 10.0 + 1.0) * 1024
-    assert bench.pmc_traffic("cin_bwd_dz_l2") == (2 * 30.0 + 3.0) * 1024   # backward visits layer 2 first
-    assert bench.pmc_traffic("cin_bwd_dz_l1") == (2 * 40.0 + 4.0) * 1024
-    assert bench.pmc_traffic("cin_head_fwd") is None
+    # (a lookup of a committed file, labelled as such in the JSON line) -- not the split instantiation (99 / 9)
+    assert bench.pmc_traffic("cin_fwd_l2") == ((2 * 20.0 + 2.0) * 1024, "committed profile r99_pmc_traffic.json")
+    assert bench.pmc_traffic("cin_fwd_l1")[0] == (2 * 10.0 + 1.0) * 1024
+    assert bench.pmc_traffic("cin_bwd_dz_l2")[0] == (2 * 30.0 + 3.0) * 1024   # backward visits layer 2 first
+    assert bench.pmc_traffic("cin_bwd_dz_l1")[0] == (2 * 40.0 + 4.0) * 1024
+    assert bench.pmc_traffic("cin_head_fwd") == (None, None)
