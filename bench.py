@@ -320,8 +320,7 @@ def mfma_util(scope):
     e = per.get("by_scope", {}).get(scope)
     if not e:
         return None
-    return {"mfma_busy_frac": e.get("mfma_busy_frac"), "hbm_frac": e.get("hbm_frac"),
-            "util_source": "committed profile " + os.path.basename(files[-1])}
+    return {"mfma_busy_frac": e.get("mfma_busy_frac"), "util_source": "committed profile " + os.path.basename(files[-1])}
 
 
 def launch_ranks(args, argv):
@@ -560,6 +559,8 @@ def main():
             util = mfma_util(dom)
             if util is not None:
                 res["roofline"].update(util)
+            if traffic:   # BASELINE's "%HBM roofline" of the same kernel: counter bytes over the live launch time
+                res["roofline"]["hbm_frac"] = traffic / (d["avg_ms"] * 1e-3) / (PEAK_HBM_GBPS * 1e9)
             res["kernels"] = kernels
             res["gpu_kernel_ms_per_step"] = sum(v["total_ms"] for v in prof_all.values()) / n_all
         if rccl is not None:

@@ -255,6 +255,80 @@ def test_cin(B, F, K, conv, output_dim, mode):
         check("cin ddense_b", db.grad, ddb)
 
 
+_BENCH_ORACLE = {}
+
+
+def _bench_shape_oracle():
+    """fp64 oracle of the benchmark's own workload (B=4096, F=39, K=16, 3x128; bench.py's seeded inputs): the op-for-op
+    graph under autograd, 16 shards of 256 samples (rows are independent; parameter gradients add) -- ~25 s of CPU."""
+    if not _BENCH_ORACLE:
+        from oracle import graph
+        B, F, K, conv = 4096, 39, 16, [128, 128, 128]
+        c = synth.cin_case(B, F, K, conv)
+        T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+        Ws, bs, dw, db = [T(w) for w in c["Ws"]], [T(b) for b in c["bs"]], T(c["dense_w"]), T(c["dense_b"])
+        params = Ws + bs + [dw, db]
+        for p in params:
+            p.requires_grad_()
+        outs, dxs = [], []
+        for lo in range(0, B, 256):
+            x = T(c["x"][lo:lo + 256]).requires_grad_()
+            out = graph.cin(x, Ws, bs, dw, db)
+            out.backward(T(c["g"][lo:lo + 256]))        # parameter .grad accumulates over the shards
+            outs.append(out.detach().numpy())
+            dxs.append(x.grad.numpy())
+        _BENCH_ORACLE.update(c=c, out=np.concatenate(outs), dx=np.concatenate(dxs), dW=[w.grad.numpy() for w in Ws],
+                             db=[b.grad.numpy() for b in bs], ddw=dw.grad.numpy(), ddb=db.grad.numpy())
+    return _BENCH_ORACLE
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_cin_at_the_benchmark_shape(mode):
+    """The launch configuration bench.py times (M = B*K = 65,536 rows: 64-row waves, the fused pooling epilogue, the dW
+    split plan and XCD mapping of that size) against the fp64 oracle -- every output and every gradient, all 4096 samples.
+    mode 0 = headline, 1 = general kernels for every layer, 2 = the split-bf16 experiment."""
+    from ml_function_amd import functional as Fn
+    o = _bench_shape_oracle()
+    c = o["c"]
+    x = dev(c["x"]).requires_grad_()
+    Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+    bs = [dev(b).requires_grad_() for b in c["bs"]]
+    dw, db = dev(c["dense_w"]).requires_grad_(), dev(c["dense_b"]).requires_grad_()
+    out = Fn.cin(x, Ws, bs, dw, db, mode=mode)
+    check("bench-shape out", out, o["out"])
+    out.backward(dev(c["g"]))
+    check("bench-shape dx", x.grad, o["dx"], tol=2e-5)
+    for l in range(3):
+        check("bench-shape dW%d" % l, Ws[l].grad, o["dW"][l], tol=2e-5)
+        check("bench-shape db%d" % l, bs[l].grad, o["db"][l], tol=2e-5)
+    check("bench-shape ddense_w", dw.grad, o["ddw"], tol=2e-5)
+    check("bench-shape ddense_b", db.grad, o["ddb"], tol=2e-5)
+
+
+@pytest.mark.parametrize("B,F,K,conv", [(64, 39, 16, [128, 128, 128]), (33, 38, 16, [64, 48, 8]), (9, 5, 8, [6, 7]), (16, 26, 16, [200, 200])])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_cin_wide_wave_instantiations_at_small_sizes(B, F, K, conv, mode):
+    """FIL_CIN_MB2 forces the 64-row-per-wave instantiations (what M >= 49,152 rows selects by itself, i.e. the kernels the
+    benchmark runs) at sizes the oracle checks in full; FIL_CIN_NOSYM the general first-layer kernels.  Both against the
+    fp64 oracle at the usual bars."""
+    from ml_function_amd import functional as Fn
+    c = synth.cin_case(B, F, K, conv, dist="uniform")
+    c["x"] = (c["x"] * 10).astype(np.float32)
+    want = closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"])
+    dx, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"])
+    for extra in (4, 8, 12):    # MB2, NOSYM, both
+        x = dev(c["x"]).requires_grad_()
+        Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+        bs = [dev(b).requires_grad_() for b in c["bs"]]
+        out = Fn.cin(x, Ws, bs, dev(c["dense_w"]), dev(c["dense_b"]), mode=mode | extra)
+        check("out (mode %d)" % (mode | extra), out, want)
+        out.backward(dev(c["g"]))
+        check("dx (mode %d)" % (mode | extra), x.grad, dx, tol=2e-5)
+        for l in range(len(conv)):
+            check("dW%d (mode %d)" % (l, mode | extra), Ws[l].grad, dWs[l], tol=2e-5)
+            check("db%d (mode %d)" % (l, mode | extra), bs[l].grad, dbs[l], tol=2e-5)
+
+
 def test_cin_unscaled_inputs_match_fp32_reference_accuracy():
     """x ~ U(-0.05,0.05): the outputs are dominated by the biases, which is where a bias-seeded accumulator loses
     accuracy.  The HIP path must stay within a small factor of the fp32 reference graph's own error."""

@@ -52,6 +52,81 @@ def test_xdeepfm_matches_oracle_composition():
     assert rel(out, want) < 1e-5
 
 
+D64 = lambda t: t.detach().cpu().double()
+
+
+def _oracle_features(fi, vocab, dense, idx, round_bf16=False):
+    """The reference's InputFeature pieces in float64 from the model's own tables (oracle/graph.py:sparse_embed)."""
+    emb, offs = D64(fi.sparse_embed.embeddings), fi.sparse_embed.offsets.cpu()
+    if round_bf16:
+        emb = emb.float().bfloat16().double()
+    sparse = graph.sparse_embed([emb[offs[f]:offs[f] + vocab[f]] for f in range(len(vocab))],
+                                [idx[:, f:f + 1].cpu() for f in range(len(vocab))])          # F x [B,1,K]
+    linear = None
+    if fi.linear_embed is not None:
+        lin, loff = D64(fi.linear_embed.embeddings), fi.linear_embed.offsets.cpu()
+        linear = [lin[loff[f]:loff[f] + vocab[f]][idx[:, f].cpu()].unsqueeze(1) for f in range(len(vocab))]   # F x [B,1,1]
+    dense_l = [] if dense is None else [D64(dense)[:, i:i + 1] for i in range(dense.shape[1])]
+    return sparse, linear, dense_l
+
+
+def _oracle_dnn(dnn, x):
+    """DnnLayer(res_unit=1) with plain Dense hidden layers (core_layer.py:201-226): y = Dense(x); x = ReLU(Add([x, y])) when
+    the shapes agree, ReLU(y) otherwise (the Add raises and is skipped, :211-214)."""
+    for h in dnn.hidden_list:
+        y = x @ D64(h.dense.kernel) + D64(h.dense.bias)
+        x = torch.relu(x + y) if x.shape == y.shape else torch.relu(y)
+    return x
+
+
+def _oracle_merge_score(score, inputs, use_merge=True):
+    x = graph.stack_layer(inputs) if use_merge else inputs
+    return torch.softmax(x @ D64(score.dense.kernel) + D64(score.dense.bias), dim=-1)
+
+
+@pytest.mark.parametrize("name", ["FM", "DeepFM", "DCN", "AutoInt"])
+def test_zoo_matches_oracle_composition(name):
+    """Whole zoo models (embedding gather + interaction layer on the HIP path + heads) against the reference graph composed
+    the same way in float64 (models.py:36-41, 80-106, 150-165), outputs at 1e-5 and the embedding-table gradient at 2e-5."""
+    torch.manual_seed(1)
+    vocab = [7, 11, 5, 13, 3, 17]
+    B, K = 33, 8
+    fi = models.FeatureInput(sparseInfo=models.make_sparse_info(vocab, embed_dim=K), useLinear=name in ("FM", "DeepFM"))
+    body = {"FM": lambda: models.FM(), "DeepFM": lambda: models.DeepFM(hidden_units=[32, 16]),
+            "DCN": lambda: models.DCN(hidden_units=[32, 16], cross_hidden=3),
+            "AutoInt": lambda: models.AutoInt(attention_dim=8, attention_head_dim=3)}[name]()
+    model = models.CTRModel(fi, body).cuda()
+    dense, idx = _inputs(B, 3, vocab, seed=4)
+    if name in ("FM", "AutoInt"):
+        dense = None
+    out = model(dense, idx)
+    sparse, linear, dense_l = _oracle_features(fi, vocab, dense, idx)
+    emb64 = D64(fi.sparse_embed.embeddings).requires_grad_()
+    offs = fi.sparse_embed.offsets.cpu()
+    sparse = graph.sparse_embed([emb64[offs[f]:offs[f] + vocab[f]] for f in range(len(vocab))], [idx[:, f:f + 1].cpu() for f in range(len(vocab))])
+    b = model.body
+    if name == "FM":
+        want = _oracle_merge_score(b.score, graph.fm_layer(sparse, linear).squeeze(1), use_merge=False)
+    elif name == "DeepFM":
+        dnn_ = _oracle_dnn(b.dnn, graph.stack_layer(dense_l + sparse))
+        want = _oracle_merge_score(b.score, [graph.fm_layer(sparse, linear), dnn_])
+    elif name == "DCN":
+        comb = graph.stack_layer(dense_l + sparse)
+        L = b.cross.cross_hidden
+        cross = graph.cross_layer(comb, [D64(getattr(b.cross, "outer_weight_%d" % l)) for l in range(L)],
+                                  [D64(getattr(b.cross, "outer_bias_%d" % l)) for l in range(L)])
+        want = _oracle_merge_score(b.score, [cross, _oracle_dnn(b.deep, comb)])
+    else:
+        a = b.atten_layer
+        y = graph.autoint_interacting(torch.cat(sparse, 1), D64(a.query_w), D64(a.key_w), D64(a.res_w), D64(a.ln_gamma), D64(a.ln_beta))
+        want = _oracle_merge_score(b.score, graph.autoint_flatten(y), use_merge=False)
+    assert out.shape == want.shape == (B, 2) and rel(out, want) < 1e-5, rel(out, want)
+    g = torch.tensor(np.random.default_rng(8).standard_normal((B, 2)), dtype=torch.float64)
+    want.backward(g)
+    out.backward(g.float().cuda())
+    assert rel(fi.sparse_embed.embeddings.grad, emb64.grad) < 2e-5
+
+
 @pytest.mark.parametrize("name", ["FM", "DeepFM", "DCN", "XDeepFM", "AutoInt"])
 def test_zoo_models_train(name):
     torch.manual_seed(0)
@@ -177,6 +252,13 @@ def test_deepfm_config2_bf16():
     assert out16.shape == (B, 2) and torch.isfinite(out16).all()
     assert float((out16 - out32).detach().abs().max()) < 2e-2
     assert float((out16 - out32).detach().abs().max()) > 0.0  # really a different arithmetic
+    # against the ORACLE (not the model itself): the reference graph in float64 on the bf16-rounded embeddings -- fp32 run at
+    # 1e-5 of the unrounded oracle, bf16 run within the labelled mode's 2e-2 on the click probabilities
+    b = model.body
+    for rounded, got, tol in ((False, out32, 1e-5), (True, out16, 2e-2)):
+        sparse, linear, dense_l = _oracle_features(fi, vocab, dense, idx, round_bf16=rounded)
+        want = _oracle_merge_score(b.score, [graph.fm_layer(sparse, linear), _oracle_dnn(b.dnn, graph.stack_layer(dense_l + sparse))])
+        assert float((got.detach().cpu().double() - want).abs().max()) < tol, rounded
     y = torch.tensor(rng.integers(0, 2, B), dtype=torch.float32, device="cuda")
     torch.nn.functional.binary_cross_entropy(out16[:, 1].clamp(1e-6, 1 - 1e-6), y).backward()
     g = fi.sparse_embed.embeddings.grad

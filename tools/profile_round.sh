@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX through gpurun:  gpurun -- 'bash tools/profile_round.sh r01_v5'
-# Produces under gpurun_out/<tag>/: bench.json (unprofiled run), kernel stats of the same command, and the two PMC
-# passes (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only) that tools/pmc_traffic.py summarises.
+# Produces under gpurun_out/<tag>/: bench.json (unprofiled run), kernel stats of the same command, and three PMC passes
+# (FETCH_SIZE / WRITE_SIZE / SQ counters: separate runs, counters + kernel-trace only) that tools/pmc_traffic.py and
+# tools/mfma_util.py summarise.  Copy kernel_stats.csv, pmc_traffic.{json,txt}, mfma_util.{json,txt}, bench.json to profiles/<tag>_*.
 set -u
 tag=${1:-prof}
 out=gpurun_out/$tag
@@ -11,8 +12,11 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline > $out/bench_profiled.json 2> $out/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write.log
-# bench.py --steps 3 --warmup 1 runs 1 + 3 timed + 2 (full-table pass) = 6 step iterations
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq.log
+# bench.py --steps 3 --warmup 1 runs 1 warm-up + 3 timed + 2 split warm-up + 3 split timed + 2 (full-table pass) step iterations;
+# the exact-fp32 instantiations are launched in 1 + 3 + 2 = 6 of them
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json 6 > $out/pmc_traffic.txt
+python3 tools/mfma_util.py $out/pmc_sq $out/mfma_util.json 6 > $out/mfma_util.txt
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 # raw traces are large; keep the summaries
 find $out -name "*kernel_trace.csv" -delete
