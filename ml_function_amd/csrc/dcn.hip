@@ -13,9 +13,14 @@
 
 namespace fil {
 
-constexpr int kDcnThreads = 256;  // 4 waves per workgroup (1 per SIMD), one sample per wave at a time;
-                                  // kernels that stay under 256 VGPRs co-reside 2 workgroups per CU
+constexpr int kDcnThreads = 256;  // forward: 4 waves per workgroup (1 per SIMD), one sample per wave at a time
 constexpr int kDcnWaves = kDcnThreads / kWave;
+// backward: 8 waves per workgroup = two per SIMD (its ~230 registers per lane allow exactly that), so a second wave covers
+// the first one's load latency; the dw/db accumulators of the 8 waves fold through LDS into ONE partial per workgroup, so
+// doubling the resident waves does not double the partial traffic (round 1 ran 4 waves per CU: 0.56 of peak at B = 131 k)
+constexpr int kDcnBwdWaves = 8;
+constexpr int kDcnBwdThreads = kDcnBwdWaves * kWave;
+constexpr int kDcnMaxLc = 6;   // L limit of the closed-form backward (== kDcnMaxL below)
 
 // Lane-owned element layout: chunk c = lane + 64*u (u < NPL/VEC) covers elements [c*VEC, c*VEC+VEC).
 template <int NPL, int VEC>
@@ -43,6 +48,48 @@ __device__ __forceinline__ void row_store(float* __restrict__ p, int D, int lane
       else p[d] = v[u];
     }
   }
+}
+
+// Rows of the [B,D] tensors through raw buffers (one descriptor per row: lanes past D read 0 / store nothing, no branches,
+// so a row's loads issue back to back behind one wait).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dcn_rsrc(const float* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+typedef float dcn_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int dcn_u4 __attribute__((ext_vector_type(4)));
+template <int NPL, int VEC>
+__device__ __forceinline__ void row_load_buf(__amdgpu_buffer_rsrc_t r, int lane, float (&v)[NPL]) {
+#pragma unroll
+  for (int u = 0; u < NPL / VEC; ++u) {
+    const int off = (lane + kWave * u) * VEC * 4;
+    if constexpr (VEC == 4) {
+      const dcn_f4 t = __builtin_bit_cast(dcn_f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+      v[u * 4 + 0] = t[0]; v[u * 4 + 1] = t[1]; v[u * 4 + 2] = t[2]; v[u * 4 + 3] = t[3];
+    } else {
+      v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
+  }
+}
+template <int NPL, int VEC>
+__device__ __forceinline__ void row_store_buf(__amdgpu_buffer_rsrc_t r, int lane, const float (&v)[NPL]) {
+#pragma unroll
+  for (int u = 0; u < NPL / VEC; ++u) {
+    const int off = (lane + kWave * u) * VEC * 4;
+    if constexpr (VEC == 4) {
+      const dcn_f4 t = {v[u * 4], v[u * 4 + 1], v[u * 4 + 2], v[u * 4 + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dcn_u4, t), r, off, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v[u]), r, off, 0, 0);
+    }
+  }
+}
+
+// wave total as a SCALAR: DPP adds inside each 32-lane half (VALU only, no LDS crossbar round trips like the ds_bpermute
+// behind __shfl_xor), then the two half totals are read into scalar registers
+__device__ __forceinline__ float wave_total(float v) {
+  v = half_wave_sum_hi(v);
+  const int bits = __builtin_bit_cast(int, v);   // (the builtin is typed int: a float argument would be VALUE-converted)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 31)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 63));
 }
 
 // Parameter row l (w or b) from the LDS copy staged at kernel start.
@@ -85,86 +132,192 @@ __global__ __launch_bounds__(kDcnThreads) void dcn_fwd_kernel(const float* __res
   }
 }
 
+// Backward in closed form.  With c_l = 1 + sum_{t<l} s_t (s_t = the forward's saved dots) the recurrence unrolls to
+//   x_l  = c_l x0 + sum_{t<l} b_t                      gx_l = g + sum_{t>l} ds_t w_t
+//   ds_l = gx_l . x0 = g.x0 + sum_{t>l} ds_t (w_t.x0)  (scalars: L+1 dot products per sample, then a scalar recurrence)
+//   dx   = c_L g + sum_l (ds_l c_l) w_l                (elementwise)
+//   dw_l = sum_n (ds_l c_l)[n] x0[n]  +  (sum_{t<l} b_t) (sum_n ds_l[n])
+//   db_l = sum_n g[n]  +  sum_{t>l} w_t (sum_n ds_t[n])
+// so a wave keeps L+1 row accumulators (A_l = sum alpha_l x0 and G = sum g) instead of 2L, never rebuilds x_l, and the
+// parameter-only terms are added once, in the reduction.  ~150 registers per lane instead of ~300: two waves per SIMD.
 template <int NPL, int VEC, int LL>
-__global__ __launch_bounds__(kDcnThreads) void dcn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ b, const float* __restrict__ s,
-                                                              const float* __restrict__ g, float* __restrict__ dx,
-                                                              float* __restrict__ partial, int B, int D) {
+__global__ __launch_bounds__(kDcnBwdThreads) void dcn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ s, const float* __restrict__ g,
+                                                                 float* __restrict__ dx, float* __restrict__ partial, int B, int D) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  for (int i = threadIdx.x; i < LL * D; i += kDcnThreads) {
-    smem[i] = w[i];
-    smem[LL * D + i] = b[i];
-  }
+  for (int i = threadIdx.x; i < LL * D; i += kDcnBwdThreads) smem[i] = w[i];
   __syncthreads();
   const float* ws = smem;
-  const float* bs = smem + LL * D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dwacc[LL][NPL], dbacc[LL][NPL];
+  float acc[LL][NPL], gsum[NPL], dssum[LL];
 #pragma unroll
-  for (int l = 0; l < LL; ++l)
+  for (int l = 0; l < LL; ++l) {
+    dssum[l] = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) dwacc[l][i] = dbacc[l][i] = 0.f;
+    for (int i = 0; i < NPL; ++i) acc[l][i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) gsum[i] = 0.f;
 
-  for (int n = blockIdx.x * kDcnWaves + wave; n < B; n += gridDim.x * kDcnWaves) {
-    float x0[NPL], gx[NPL], dx0[NPL], sv[LL];
-    row_load<NPL, VEC>(x + (long)n * D, D, lane, x0);
-    row_load<NPL, VEC>(g + (long)n * D, D, lane, gx);
+  const int nstep = gridDim.x * kDcnBwdWaves;
+  int n = blockIdx.x * kDcnBwdWaves + wave;
+  float x0[NPL], gv[NPL];
+  const int rowb = D * 4;
+  if (n < B) {
+    row_load_buf<NPL, VEC>(dcn_rsrc(x + (long)n * D, rowb), lane, x0);
+    row_load_buf<NPL, VEC>(dcn_rsrc(g + (long)n * D, rowb), lane, gv);
+  }
+  for (; n < B; n += nstep) {
+    // the next sample's rows are fetched while this one is processed
+    float xn[NPL], gn[NPL];
+    const bool more = n + nstep < B;
+    {   // (past the last sample the descriptors are empty: the loads return zeros and nothing is fetched)
+      const long nn = more ? n + nstep : n;
+      row_load_buf<NPL, VEC>(dcn_rsrc(x + nn * D, more ? rowb : 0), lane, xn);
+      row_load_buf<NPL, VEC>(dcn_rsrc(g + nn * D, more ? rowb : 0), lane, gn);
+    }
+    float sv[LL], dots[LL + 1];
 #pragma unroll
     for (int l = 0; l < LL; ++l) sv[l] = s[(long)n * LL + l];
+    dots[LL] = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) dx0[i] = 0.f;
-#pragma unroll
-    for (int l = LL - 1; l >= 0; --l) {
-      // x_l recomputed from x0 with the saved dots (same operations as forward -> same bits)
-      float xl[NPL];
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) xl[i] = x0[i];
-#pragma unroll
-      for (int t = 0; t < l; ++t) {
-        float bl[NPL];
-        param_load<NPL, VEC>(bs + t * D, D, lane, bl);
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) xl[i] = fmaf(x0[i], sv[t], xl[i]) + bl[i];
-      }
-      float ds = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        dbacc[l][i] += gx[i];
-        ds = fmaf(gx[i], x0[i], ds);
-      }
-      ds = wave_sum(ds);
-      float wl[NPL];
-      param_load<NPL, VEC>(ws + l * D, D, lane, wl);
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        dx0[i] = fmaf(gx[i], sv[l], dx0[i]);
-        dwacc[l][i] = fmaf(xl[i], ds, dwacc[l][i]);
-        gx[i] = fmaf(wl[i], ds, gx[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) dx0[i] += gx[i];
-    row_store<NPL, VEC>(dx + (long)n * D, D, lane, dx0);
-  }
-
-  // block reduction of the per-wave accumulators, fixed wave order, through LDS (one [waves][D] slab at a time)
-  __syncthreads();  // everyone is done with the staged params
-  float* red = smem;  // needs kDcnWaves*D floats (host sizes the dynamic LDS for max(params, this))
-  float* pout = partial + (long)blockIdx.x * 2 * LL * D;
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
+    for (int i = 0; i < NPL; ++i) dots[LL] = fmaf(gv[i], x0[i], dots[LL]);
 #pragma unroll
     for (int l = 0; l < LL; ++l) {
-      if (which == 0) row_store<NPL, VEC>(red + wave * D, D, lane, dwacc[l]);
-      else row_store<NPL, VEC>(red + wave * D, D, lane, dbacc[l]);
-      __syncthreads();
-      for (int d = threadIdx.x; d < D; d += kDcnThreads) {
-        float t = 0.f;
+      float wl[NPL];
+      param_load<NPL, VEC>(ws + l * D, D, lane, wl);
+      float t = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < kDcnWaves; ++wv) t += red[wv * D + d];
-        pout[(which * LL + l) * D + d] = t;
+      for (int i = 0; i < NPL; ++i) t = fmaf(wl[i], x0[i], t);
+      dots[l] = t;
+    }
+#pragma unroll
+    for (int l = 0; l <= LL; ++l) dots[l] = wave_total(dots[l]);
+    float ds[LL], alpha[LL], c = 1.f;
+#pragma unroll
+    for (int l = LL - 1; l >= 0; --l) {
+      float t = dots[LL];
+#pragma unroll
+      for (int u = l + 1; u < LL; ++u) t = fmaf(ds[u], dots[u], t);
+      ds[l] = t;
+      dssum[l] += t;
+    }
+#pragma unroll
+    for (int l = 0; l < LL; ++l) {
+      alpha[l] = ds[l] * c;
+      c += sv[l];
+    }
+    float dxv[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      dxv[i] = gv[i] * c;
+      gsum[i] += gv[i];
+    }
+    // (the parameter rows are read from LDS a second time on purpose: keeping the L rows of the dot phase alive would
+    // cost L*NPL registers and a wave per SIMD; the laundered pointer stops the compiler from merging the two reads)
+    int off2 = 0;                      // (an offset, not the pointer: the reads stay LDS reads, not flat ones)
+    asm volatile("" : "+v"(off2));
+    const float* ws2 = ws + off2;
+#pragma unroll
+    for (int l = 0; l < LL; ++l) {
+      float wl[NPL];
+      param_load<NPL, VEC>(ws2 + l * D, D, lane, wl);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        dxv[i] = fmaf(wl[i], alpha[l], dxv[i]);
+        acc[l][i] = fmaf(x0[i], alpha[l], acc[l][i]);
       }
-      __syncthreads();
+    }
+    row_store_buf<NPL, VEC>(dcn_rsrc(dx + (long)n * D, rowb), lane, dxv);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      x0[i] = xn[i];
+      gv[i] = gn[i];
+    }
+  }
+
+  // block reduction of the per-wave accumulators, fixed wave order, through LDS (one [waves][D] slab at a time):
+  // partial[block] = [A_0 .. A_{L-1} | G | sum ds_0 .. sum ds_{L-1} (padded to 8)]
+  __syncthreads();  // everyone is done with the staged params
+  float* red = smem;  // needs kDcnBwdWaves*(D+8) floats (host sizes the dynamic LDS for max(params, this))
+  float* pout = partial + (long)blockIdx.x * ((LL + 1) * D + 8);
+#pragma unroll
+  for (int l = 0; l <= LL; ++l) {
+    if (l < LL) row_store<NPL, VEC>(red + wave * D, D, lane, acc[l < LL ? l : 0]);
+    else row_store<NPL, VEC>(red + wave * D, D, lane, gsum);
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += kDcnBwdThreads) {
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < kDcnBwdWaves; ++wv) t += red[wv * D + d];
+      pout[l * D + d] = t;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < LL; ++l) red[wave * 8 + l] = dssum[l];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float t = 0.f;
+    if (threadIdx.x < LL)
+      for (int wv = 0; wv < kDcnBwdWaves; ++wv) t += red[wv * 8 + threadIdx.x];
+    pout[(LL + 1) * D + threadIdx.x] = t;
+  }
+}
+
+// dw, db from the workgroup partials of dcn_bwd_kernel (fixed order).  grid = (ceil(D/64), L+1): block (., l < L) sums A_l
+// and the ds totals and writes dw_l = A_l + (sum_{t<l} b_t) DS_l; block (., L) sums G and writes every
+// db_l = G + sum_{t>l} w_t DS_t.  The 4 waves take every 4th partial, wave sums are added in wave order.
+__global__ __launch_bounds__(256) void dcn_reduce_closed_kernel(const float* __restrict__ partial, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* __restrict__ dw,
+                                                                float* __restrict__ db, int parts, int D, int L) {
+  __shared__ float red[4][64];
+  __shared__ float dsr[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + lane, l = blockIdx.y;
+  const long pstride = (long)(L + 1) * D + 8;
+  // eight partials in flight per thread (they come from L2 / the Infinity Cache: the loop is latency-, not bandwidth-bound)
+  float tq[8], dq[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) tq[u] = dq[u] = 0.f;
+  // (branch-free: a partial index past the end is clamped and its value multiplied by 0, a column past D reads column D-1,
+  // so the eight loads of a trip issue back to back)
+  const int dc = min(d, D - 1), lc = min(lane, 7);
+  for (int p0 = wave; p0 < parts; p0 += 32) {
+    float a[8], e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* pp = partial + (long)min(p0 + 4 * u, parts - 1) * pstride;
+      a[u] = pp[(long)l * D + dc];
+      e[u] = pp[(long)(L + 1) * D + lc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float keep = p0 + 4 * u < parts ? 1.f : 0.f;
+      tq[u] = fmaf(keep, a[u], tq[u]);
+      dq[u] = fmaf(keep, e[u], dq[u]);
+    }
+  }
+  const float t0 = ((tq[0] + tq[1]) + (tq[2] + tq[3])), t1 = ((tq[4] + tq[5]) + (tq[6] + tq[7]));
+  const float dsl = ((dq[0] + dq[1]) + (dq[2] + dq[3])) + ((dq[4] + dq[5]) + (dq[6] + dq[7]));
+  red[wave][lane] = t0 + t1;
+  if (lane < 8) dsr[wave][lane] = dsl;
+  __syncthreads();
+  if (wave == 0 && d < D) {
+    const float tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    auto DS = [&](int u) { return ((dsr[0][u] + dsr[1][u]) + dsr[2][u]) + dsr[3][u]; };
+    if (l < L) {
+      float bsum = 0.f;
+      for (int u = 0; u < l; ++u) bsum += b[(long)u * D + d];
+      dw[(long)l * D + d] = fmaf(bsum, DS(l), tot);
+    } else {
+      for (int ll = 0; ll < L; ++ll) {
+        float v = tot;
+        for (int u = ll + 1; u < L; ++u) v = fmaf(w[(long)u * D + d], DS(u), v);
+        db[(long)ll * D + d] = v;
+      }
     }
   }
 }
@@ -299,10 +452,10 @@ static int dcn_grid_cap(int B, int cap) {
     return e != nullptr ? atoi(e) : 0;
   }();
   if (forced > 0) cap = forced;
-  return std::max(1, std::min(cdiv(B, kDcnWaves), cap));
+  return cap;
 }
-static int dcn_grid(int B) { return dcn_grid_cap(B, 256); }        // backward (and its workspace sizing)
-static int dcn_grid_fwd(int B) { return dcn_grid_cap(B, 1024); }
+static int dcn_grid(int B) { return std::max(1, std::min(cdiv(B, kDcnBwdWaves), dcn_grid_cap(B, 256))); }   // backward (and its workspace sizing)
+static int dcn_grid_fwd(int B) { return std::max(1, std::min(cdiv(B, kDcnWaves), dcn_grid_cap(B, 1024))); }
 
 static int pick_npl(int D, bool vec) {
   const int menu[] = {8, 20, 32, 64};
@@ -326,8 +479,9 @@ static void launch_fwd(int grid, size_t sh, hipStream_t st, const float* x, cons
 template <int NPL, int VEC, int LL>
 static void launch_bwd_l(int grid, size_t sh, hipStream_t st, const float* x, const float* w, const float* b,
                          const float* s, const float* g, float* dx, float* partial, int B, int D) {
+  (void)b;
   allow_lds(dcn_bwd_kernel<NPL, VEC, LL>, sh);
-  hipLaunchKernelGGL((dcn_bwd_kernel<NPL, VEC, LL>), dim3(grid), dim3(kDcnThreads), sh, st, x, w, b, s, g, dx, partial, B, D);
+  hipLaunchKernelGGL((dcn_bwd_kernel<NPL, VEC, LL>), dim3(grid), dim3(kDcnBwdThreads), sh, st, x, w, s, g, dx, partial, B, D);
 }
 
 template <int NPL, int VEC>
@@ -381,13 +535,15 @@ extern "C" int fil_dcn_fwd(const float* x, const float* w, const float* b, float
 static bool dcn_register_path(int D, int L) {
   const int npl = pick_npl(D, D % 4 == 0);
   // per-lane accumulators are 2*L*NPL registers (+5*NPL of sample state): stay inside the 512-register file
-  return npl > 0 && 2 * L * npl + 5 * npl <= 440 && std::max((size_t)2 * L * D, (size_t)kDcnWaves * D) * sizeof(float) <= kDcnLdsLimit;
+  // closed-form backward: (L + 1) row accumulators + x0, g and their prefetched successors + a parameter row in flight,
+  // two waves per SIMD (256 registers per lane)
+  return npl > 0 && (L + 7) * npl <= 230 && std::max((size_t)L * D, (size_t)kDcnBwdWaves * (D + 8)) * sizeof(float) <= kDcnLdsLimit;
 }
 static int dcn_generic_chunks(int B) { return std::max(1, std::min(cdiv(B, 32), 64)); }
 
 extern "C" size_t fil_dcn_bwd_workspace_bytes(int B, int D, int L) {
   if (B <= 0 || D <= 0 || L <= 0) return 0;
-  if (dcn_register_path(D, L)) return align_up((size_t)dcn_grid(B) * 2 * L * D * sizeof(float), 256);
+  if (dcn_register_path(D, L)) return align_up((size_t)dcn_grid(B) * ((size_t)(L + 1) * D + 8) * sizeof(float), 256);
   return align_up((size_t)B * L * sizeof(float), 256) + align_up((size_t)dcn_generic_chunks(B) * 2 * L * D * sizeof(float), 256);
 }
 
@@ -427,8 +583,8 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
   }
   const bool vec = (D % 4 == 0);
   const int npl = pick_npl(D, vec);
-  const size_t psz = (size_t)2 * L * D * sizeof(float);
-  const size_t red = (size_t)kDcnWaves * D * sizeof(float);
+  const size_t psz = (size_t)L * D * sizeof(float);
+  const size_t red = (size_t)kDcnBwdWaves * (D + 8) * sizeof(float);
   const size_t sh = std::max(psz, red);
   if (sh > kDcnLdsLimit) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: %zu bytes of LDS needed (> 160 KiB)", sh);
   const int grid = dcn_grid(B);
@@ -442,7 +598,7 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
 #undef BWD_SCALAR
   if (rc != 0) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: no kernel for L=%d", L);
   FIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 64)), dim3(256), 0, st, partial, dw, db, grid, L * D);
+  hipLaunchKernelGGL(dcn_reduce_closed_kernel, dim3(cdiv(D, 64), L + 1), dim3(256), 0, st, partial, w, b, dw, db, grid, D, L);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
