@@ -271,17 +271,43 @@ def side_benchmark(args):
     else:
         rate = d["work"] / (d["avg_ms"] * 1e-3)
     peak, unit, ach = PEAK_HBM_GBPS, "GB/s", rate / 1e9
+    traffic, traffic_src = side_traffic(name, dom)
     print(json.dumps({
         "metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16 products, f32 accumulate" if f16 else "f32", "data": "synthetic",
         "config": {"workload": name},
         "roofline": {"bound": bound, "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                     "traffic": None, "avg_launch_ms": d["avg_ms"]},
+                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": d["avg_ms"],
+                     "algorithmic_bytes_per_launch": rate * d["avg_ms"] * 1e-3},
         **extra,
         "kernels": {k: dict(avg_ms=round(v["avg_ms"], 4), work=v["work"]) for k, v in sorted(ks.items())},
         "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps,
         "hipgraph_replay_ms_per_step": graph_ms}))
+
+
+def side_traffic(workload_name, kernel_scope):
+    """(HBM bytes per launch, source file) of a side benchmark's kernel from the newest committed profile of the SAME workload
+    (profiles/r*_pmc_summary.json written by tools/profile_side.sh / profile_attn.sh next to the bench.json it profiled); a
+    lookup, like pmc_traffic().  (None, None) when no committed profile ran this exact workload."""
+    import glob
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    prefix = {"fm_fwd": "fm_fwd", "fm_bwd": "fm_bwd", "dcn_fwd": "dcn_fwd", "dcn_bwd": "dcn_bwd_kernel", "attn_fwd": "attn_fwd",
+              "attn_bwd": "attn_bwd"}.get(kernel_scope)
+    for f in sorted(glob.glob(os.path.join(root, "r*_pmc_summary.json")), reverse=True):
+        bj = f.replace("_pmc_summary.json", "_bench.json")
+        try:
+            with open(bj) as fh:
+                if json.load(fh)["config"]["workload"] != workload_name:
+                    continue
+            with open(f) as fh:
+                per = json.load(fh)
+        except (OSError, ValueError, KeyError):
+            continue
+        hits = [v["hbm_bytes"] for k, v in per.items() if prefix and k.startswith(prefix) and "hbm_bytes" in v]
+        if hits:
+            return sum(hits) / len(hits), "committed profile " + os.path.basename(f)
+    return None, None
 
 
 def pmc_traffic(scope):

@@ -4,7 +4,11 @@ example/ctr_example/un_seq.py (Adam + binary cross-entropy + AUC, :55-66), on th
   python examples/train_ctr.py --model XDeepFM --steps 200
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ctr.py --model XDeepFM
 
-Data parallel: every rank draws its own shard of each batch, dense gradients go through one bucketed all-reduce
+The input side is the reference's too (kon/utils/data_prepare.py:335-337): the synthetic table is sliced, shuffled with a
+2048-element buffer, repeated, batched and prefetched by ml_function_amd.data.data_pipeline (host -> device copies on a
+side stream); the loss is Keras' compiled loss: binary cross-entropy + the layers' regularisation terms (the l2(emb_reg)
+of every embedding table, interactive_layer.py:217); the optimiser is Keras' 'adam' (lr 1e-3, epsilon 1e-7).
+Data parallel: every rank trains on its own shard of the table, dense gradients go through one bucketed all-reduce
 (ml_function_amd.dp.allreduce_module_grads), the embedding tables exchange only the rows their shards touched
 (dp.exchange_sparse_rows).  Labels come from a fixed random "teacher" so that the AUC has something to learn.
 """
@@ -17,15 +21,17 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ml_function_amd import dp, metrics, models  # noqa: E402
+from ml_function_amd import data, dp, metrics, models  # noqa: E402
+from ml_function_amd.layers.base import collect_regularization_loss  # noqa: E402
 
 
-def make_batch(rng, vocab, n_dense, B, teacher, device):
-    idx = np.stack([np.minimum(rng.zipf(1.3, B) - 1, v - 1) for v in vocab], 1)
-    dense = rng.random((B, n_dense), dtype=np.float32)
+def make_table(rng, vocab, n_dense, rows, teacher):
+    """A synthetic click log as host arrays: (dense [rows, n_dense], sparse ids [rows, F], label [rows])."""
+    idx = np.stack([np.minimum(rng.zipf(1.3, rows) - 1, v - 1) for v in vocab], 1)
+    dense = rng.random((rows, n_dense), dtype=np.float32)
     logit = sum(teacher[f][idx[:, f]] for f in range(len(vocab))) + dense @ teacher["dense"]
-    y = (rng.random(B) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
-    return (torch.tensor(dense, device=device), torch.tensor(idx, device=device), torch.tensor(y, device=device))
+    y = (rng.random(rows) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+    return dense, idx, y
 
 
 def main():
@@ -58,18 +64,20 @@ def main():
     torch.manual_seed(0)  # identical replicas
     model = models.CTRModel(fi, body).to(device)
     rng = np.random.default_rng(1000 + rank)
-    dense, idx, y = make_batch(rng, vocab, args.dense, args.batch, teacher, device)
+    table = make_table(rng, vocab, args.dense, args.steps * args.batch // 2, teacher)      # repeat(2) makes `steps` batches
     use_dense = args.model not in ("FM", "AutoInt", "AFM")
-    model(dense if use_dense else None, idx)  # builds the lazily created weights
+    model(torch.tensor(table[0][:args.batch], device=device) if use_dense else None,
+          torch.tensor(table[1][:args.batch], device=device))  # builds the lazily created weights
     tables = [p for n, p in model.named_parameters() if n.endswith("embeddings")]
     others = [p for n, p in model.named_parameters() if not n.endswith("embeddings")]
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
-    for step in range(args.steps):
-        dense, idx, y = make_batch(rng, vocab, args.dense, args.batch, teacher, device)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, eps=1e-7)      # Keras 'adam' (un_seq.py:61)
+    pipe = data.data_pipeline(table, batch_size=args.batch, shuffle_buffer=2048, repeat=2, prefetch=2, seed=rank, device=device)
+    for step, (dense, idx, y) in enumerate(pipe):
         opt.zero_grad(set_to_none=True)
         out = model(dense if use_dense else None, idx)
         p = (out[:, 1] if out.shape[1] == 2 else out[:, 0]).clamp(1e-6, 1 - 1e-6)
-        loss = torch.nn.functional.binary_cross_entropy(p, y) / world
+        bce = torch.nn.functional.binary_cross_entropy(p, y)
+        loss = (bce + collect_regularization_loss(model)) / world
         loss.backward()
         if world > 1:
             bucket = dp.GradBucket.for_params(others)
@@ -82,8 +90,8 @@ def main():
                 if t.grad is not None:
                     dp.exchange_sparse_rows(t.grad, rows)
         opt.step()
-        if rank == 0 and (step % 20 == 0 or step == args.steps - 1):
-            print("step %4d  loss %.4f  auc %.4f" % (step, float(loss.detach()) * world, metrics.auc(y, p.detach())), flush=True)
+        if rank == 0 and (step % 20 == 0 or step == len(pipe) - 1):
+            print("step %4d  loss %.4f  auc %.4f" % (step, float(bce.detach()), metrics.auc(y, p.detach())), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 201
+#define FIL_ABI_VERSION 202
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -160,13 +160,30 @@ int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* 
  * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,
  *     interactive_layer.py:225-242, emitting the packed [B,F,K] layout directly (bit-exact row copies).
  *   table: all F tables concatenated [sum_f V_f, K]; offsets [F] = first row of field f (int64);
- *   idx [B,F] (int64, per-field local ids, 0 <= idx < V_f).  out [B,F,K].
- *   scatter_add: dtable[offsets[f]+idx[b,f], :] += g[b,f,:]  (fp32 atomics; dtable must be pre-zeroed).
+ *   sizes [F] = V_f (int64; NULL = ids are trusted); idx [B,F] (int64, per-field local ids).  out [B,F,K].
+ *   An id outside [0, V_f) gives a ZERO output row (Keras' Embedding on a GPU) and is counted in *oob_count (device int,
+ *   may be NULL; the caller zeroes it) -- never a read of the neighbouring field's table; its gradient is dropped.
+ *   Gradient, deterministic (default in the Python layer):
+ *     fil_embed_row_ids      row_ids[b*F+f] = offsets[f] + idx[b,f], or -1 for out-of-range ids and frozen fields
+ *                            (frozen [F] bytes, may be NULL: sparseFea.is_trainable = False);
+ *     (the caller sorts row_ids stably -> perm, and takes the run starts of the sorted ids -> rows_out [U], starts [U+1])
+ *     fil_embed_segment_sum  values[u,:] = sum_{j in [starts[u], starts[u+1])} g[perm[j], :] in sorted order with a fixed
+ *                            lane tree; rows_out[u] < 0 is skipped; dtable != NULL additionally stores the row sums into
+ *                            dtable[rows_out[u], :] (unique rows: plain stores).  values / dtable: either may be NULL.
+ *   fil_embed_scatter_add: the fp32-atomic alternative, dtable[offsets[f]+idx[b,f], :] += g[b,f,:] (dtable pre-zeroed;
+ *                            the order of additions into a row hit several times is NOT fixed).
  */
-int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* idx, float* out, int B, int F, int K,
-                     void* stream);
-int fil_embed_scatter_add(const int64_t* offsets, const int64_t* idx, const float* g, float* dtable, int B, int F,
-                          int K, void* stream);
+int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
+                     int* oob_count, int B, int F, int K, void* stream);
+int fil_embed_scatter_add(const int64_t* offsets, const int64_t* sizes, const int64_t* idx, const float* g, float* dtable,
+                          int B, int F, int K, void* stream);
+int fil_embed_row_ids(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,
+                      int64_t* row_ids, int B, int F, void* stream);
+int fil_embed_segment_sum(const float* g, const int64_t* perm, const int64_t* starts, const int64_t* rows_out, float* values,
+                          float* dtable, long U, int K, void* stream);
+/* the same sums without any data-dependent size (HIP-graph capturable): sorted_ids [R] = the stably sorted row ids, perm [R]
+ * the sorting permutation; the run of every distinct id >= 0 is summed in sorted order into the (pre-zeroed) dense dtable. */
+int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, void* stream);
 
 #ifdef __cplusplus
 }

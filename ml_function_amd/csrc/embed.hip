@@ -1,44 +1,160 @@
-// N1  SparseEmbed field-index work for gfx950: packed [B,F,K] gather and its scatter-add gradient.
+// N1  SparseEmbed field-index work for gfx950: packed [B,F,K] gather and its gradient.
 //
 // Replaces the F separate Embedding lookups + Concatenate of the reference
 // (interactive_layer.py:225-242, models.py:131): one launch emits the packed layout the interaction
 // kernels consume.  Rows are copied bit-exactly.  A (b,f) row of K floats is moved by K/4 lanes with
 // 16-byte accesses; consecutive lanes walk consecutive rows of the output, so stores are fully coalesced
 // and each gathered table row is read as one contiguous 4*K-byte segment.
+//
+// Ids are range-checked against the per-field vocabulary when `sizes` is given: an id outside [0, V_f) yields a zero row
+// (what Keras' Embedding does on a GPU; on the CPU it raises -- the Python layer can ask for that, see oob_count) instead
+// of silently reading the next field's table, and its gradient is dropped instead of corrupting that table.
+//
+// Gradient, default = deterministic: the caller sorts the global row ids (stable), the kernel sums each row's
+// contributions in sorted order with a fixed lane tree (fil_embed_segment_sum) and either scatters the unique rows into
+// the dense table or hands them out as (rows, values) -- no atomics, no dense zero table needed.  The fp32-atomic
+// scatter-add (order of additions not fixed) stays available as fil_embed_scatter_add.
 #include "common.h"
 
 namespace fil {
 
 template <int VEC>
 __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ offsets,
-                                                           const int64_t* __restrict__ idx, float* __restrict__ out, long rows,
-                                                           int F, int K) {
+                                                           const int64_t* __restrict__ sizes, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ out, int* __restrict__ oob_count, long rows, int F,
+                                                           int K) {
   const int KV = K / VEC;
   const long total = rows * KV;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const long row = t / KV;
     const int kv = (int)(t - row * KV);
     const int f = (int)(row % F);
-    const long src = (offsets[f] + idx[row]) * K + (long)kv * VEC;
+    const int64_t id = idx[row];
+    const bool ok = sizes == nullptr || (id >= 0 && id < sizes[f]);
+    if (!ok && kv == 0 && oob_count != nullptr) atomicAdd(oob_count, 1);
+    const long src = (offsets[f] + (ok ? id : 0)) * K + (long)kv * VEC;
     if constexpr (VEC == 4) {
-      *reinterpret_cast<float4*>(out + row * K + kv * 4) = *reinterpret_cast<const float4*>(table + src);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(table + src);
+      *reinterpret_cast<float4*>(out + row * K + kv * 4) = v;
     } else {
-      out[row * K + kv] = table[src];
+      out[row * K + kv] = ok ? table[src] : 0.f;
     }
   }
 }
 
 // dtable[offsets[f] + idx[b,f], k] += g[b,f,k]  -- fp32 global atomics (one dword per lane, contiguous per row).
 // The order of additions into a row that is hit several times in a batch is not fixed.
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ idx,
-                                                            const float* __restrict__ g, float* __restrict__ dtable, long rows,
-                                                            int F, int K) {
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
+                                                            const int64_t* __restrict__ idx, const float* __restrict__ g,
+                                                            float* __restrict__ dtable, long rows, int F, int K) {
   const long total = rows * K;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const long row = t / K;
     const int k = (int)(t - row * K);
     const int f = (int)(row % F);
-    atomicAdd(dtable + (offsets[f] + idx[row]) * K + k, g[t]);
+    const int64_t id = idx[row];
+    if (sizes != nullptr && (id < 0 || id >= sizes[f])) continue;
+    atomicAdd(dtable + (offsets[f] + id) * K + k, g[t]);
+  }
+}
+
+// global row id of every (b,f): offsets[f] + idx[b,f], or -1 for an out-of-range / frozen-field id (sorts first, skipped)
+__global__ __launch_bounds__(256) void embed_row_ids_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
+                                                            const unsigned char* __restrict__ frozen, const int64_t* __restrict__ idx,
+                                                            int64_t* __restrict__ row_ids, long rows, int F) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(r % F);
+    const int64_t id = idx[r];
+    const bool ok = (sizes == nullptr || (id >= 0 && id < sizes[f])) && (frozen == nullptr || !frozen[f]);
+    row_ids[r] = ok ? offsets[f] + id : -1;
+  }
+}
+
+// One wave per unique row u: values[u,:] = sum_{j in [starts[u], starts[u+1])} g[perm[j], :], contributions taken in sorted
+// order, C = 64 / KQ of them in parallel (lane = c * KQ + kq, kq = 4 consecutive k), folded with a fixed xor tree.
+// rows_out[u] < 0 (the out-of-range bucket) is skipped.  dtable != NULL: the sum is also stored to dtable[rows_out[u], :]
+// (each row written by exactly one wave: no atomics).
+__global__ __launch_bounds__(256) void embed_segment_sum_kernel(const float* __restrict__ g, const int64_t* __restrict__ perm,
+                                                                const int64_t* __restrict__ starts, const int64_t* __restrict__ rows_out,
+                                                                float* __restrict__ values, float* __restrict__ dtable, long U, int K) {
+  __shared__ float red[4][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int KQ = (K + 3) / 4;                 // 4-wide pieces of a row (the last may be partial)
+  const int C = 64 / KQ;                      // contributions in flight per wave (host guarantees KQ <= 64)
+  const int c = lane / KQ, kq = lane - c * KQ;
+  const bool live = c < C;
+  for (long u = (long)blockIdx.x * 4 + wave; u < U; u += (long)gridDim.x * 4) {
+    const int64_t row = rows_out[u];
+    const long lo = starts[u], hi = starts[u + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live && row >= 0) {
+      for (long j = lo + c; j < hi; j += C) {
+        const float* src = g + perm[j] * K + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kq * 4 + i < K) acc[i] += src[i];
+      }
+    }
+    // fold the C partial sums of every kq in a fixed order: through LDS, lane (0, kq) adds c = 1 .. C-1 in turn
+    float* my = red[wave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) my[lane * 4 + i] = acc[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c == 0 && row >= 0) {
+      for (int cc = 1; cc < C; ++cc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += my[(cc * KQ + kq) * 4 + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kq * 4 + i;
+        if (k < K) {
+          if (values != nullptr) values[u * K + k] = acc[i];
+          if (dtable != nullptr) dtable[row * K + k] = acc[i];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Capture-safe form of the same sum (no data-dependent sizes anywhere): one wave per SORTED POSITION j; the wave whose
+// position starts a run of equal row ids (and only it) sums the run -- lanes (c, kq) take positions j + c, j + c + C, ...
+// while the id stays the same -- folds the C partial sums in lane order and stores the row into the zeroed dense table.
+__global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restrict__ g, const int64_t* __restrict__ perm,
+                                                            const int64_t* __restrict__ sorted_ids, float* __restrict__ dtable, long R,
+                                                            int K) {
+  __shared__ float red[4][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int KQ = (K + 3) / 4, C = 64 / KQ;
+  const int c = lane / KQ, kq = lane - c * KQ;
+  for (long j = (long)blockIdx.x * 4 + wave; j < R; j += (long)gridDim.x * 4) {
+    const int64_t row = sorted_ids[j];
+    if (row < 0 || (j > 0 && sorted_ids[j - 1] == row)) continue;    // wave-uniform: not the start of a run
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+      for (long jj = j + c; jj < R && sorted_ids[jj] == row; jj += C) {
+        const float* src = g + perm[jj] * K + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kq * 4 + i < K) acc[i] += src[i];
+      }
+    }
+    float* my = red[wave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) my[lane * 4 + i] = acc[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c == 0) {
+      for (int cc = 1; cc < C; ++cc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += my[(cc * KQ + kq) * 4 + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (kq * 4 + i < K) dtable[row * K + kq * 4 + i] = acc[i];
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -46,8 +162,20 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
 
 using namespace fil;
 
-extern "C" int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* idx, float* out, int B, int F, int K,
-                                void* stream) {
+extern "C" int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K,
+                                 void* stream) {
+  FIL_CHECK_ARG(R >= 0 && K >= 1);
+  if (K > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_run_sum: K=%d > 256", K);
+  if (R == 0) return FIL_OK;
+  FIL_CHECK_ARG(g && perm && sorted_ids && dtable);
+  hipLaunchKernelGGL(embed_run_sum_kernel, dim3((int)std::min<long>((R + 3) / 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, perm, sorted_ids,
+                     dtable, R, K);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
+                                int* oob_count, int B, int F, int K, void* stream) {
   FIL_CHECK_ARG(B >= 0 && F >= 1 && K >= 1);
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(table && offsets && idx && out);
@@ -55,21 +183,45 @@ extern "C" int fil_embed_gather(const float* table, const int64_t* offsets, cons
   const bool vec = (K % 4 == 0);
   const long total = rows * (vec ? K / 4 : K);
   const int grid = (int)std::min<long>((total + 255) / 256, 256 * 8);
-  if (vec) hipLaunchKernelGGL((embed_gather_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, idx, out, rows, F, K);
-  else hipLaunchKernelGGL((embed_gather_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, idx, out, rows, F, K);
+  if (vec) hipLaunchKernelGGL((embed_gather_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, sizes, idx, out, oob_count, rows, F, K);
+  else hipLaunchKernelGGL((embed_gather_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, sizes, idx, out, oob_count, rows, F, K);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
 
-extern "C" int fil_embed_scatter_add(const int64_t* offsets, const int64_t* idx, const float* g, float* dtable, int B, int F,
-                                     int K, void* stream) {
+extern "C" int fil_embed_scatter_add(const int64_t* offsets, const int64_t* sizes, const int64_t* idx, const float* g, float* dtable,
+                                     int B, int F, int K, void* stream) {
   FIL_CHECK_ARG(B >= 0 && F >= 1 && K >= 1);
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(offsets && idx && g && dtable);
   const long rows = (long)B * F;
   const long total = rows * K;
   const int grid = (int)std::min<long>((total + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, offsets, idx, g, dtable, rows, F, K);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, offsets, sizes, idx, g, dtable, rows, F, K);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" int fil_embed_row_ids(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,
+                                 int64_t* row_ids, int B, int F, void* stream) {
+  FIL_CHECK_ARG(B >= 0 && F >= 1);
+  if (B == 0) return FIL_OK;
+  FIL_CHECK_ARG(offsets && idx && row_ids);
+  const long rows = (long)B * F;
+  hipLaunchKernelGGL(embed_row_ids_kernel, dim3((int)std::min<long>((rows + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, offsets, sizes,
+                     frozen, idx, row_ids, rows, F);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" int fil_embed_segment_sum(const float* g, const int64_t* perm, const int64_t* starts, const int64_t* rows_out, float* values,
+                                     float* dtable, long U, int K, void* stream) {
+  FIL_CHECK_ARG(U >= 0 && K >= 1);
+  if (K > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_segment_sum: K=%d > 256", K);
+  if (U == 0) return FIL_OK;
+  FIL_CHECK_ARG(g && perm && starts && rows_out && (values || dtable));
+  hipLaunchKernelGGL(embed_segment_sum_kernel, dim3((int)std::min<long>((U + 3) / 4, 256 * 16)), dim3(256), 0, (hipStream_t)stream, g, perm, starts,
+                     rows_out, values, dtable, U, K);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

@@ -344,9 +344,32 @@ def mult_head_attention(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=Tru
 
 
 # --------------------------------------------------------------------------------------------- N1  embeddings
+def embed_grad_rows(offsets, sizes, idx, g, frozen=None):
+    """Deterministic embedding-table gradient as (rows [U] int64, values [U,K]): the unique global table rows the batch
+    touched (sorted) and the sum of their gradient rows, contributions added in a fixed order (no atomics).  Out-of-range
+    ids and frozen fields (frozen [F] uint8) contribute nothing.  The sort is torch's (plumbing); the sums are the HIP
+    segment kernel (fil.h: fil_embed_row_ids / fil_embed_segment_sum)."""
+    lib = _lib.load()
+    B, F = idx.shape
+    K = g.shape[-1]
+    g = _f32c(g)
+    row_ids = torch.empty(B * F, dtype=torch.int64, device=g.device)
+    check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
+    sorted_ids, perm = torch.sort(row_ids, stable=True)
+    rows, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
+    starts = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=g.device)
+    torch.cumsum(counts, 0, out=starts[1:])
+    values = torch.zeros((rows.numel(), K), dtype=torch.float32, device=g.device)
+    check(lib.fil_embed_segment_sum(ptr(g), ptr(perm), ptr(starts), ptr(rows), ptr(values), None, rows.numel(), K, stream_ptr()),
+          "fil_embed_segment_sum")
+    # the skipped bucket (id -1: out-of-range ids / frozen fields) sorts first; dropping it without reading it back:
+    # its value row is never written (zeros), its row index is clamped to 0
+    return rows.clamp(min=0), values
+
+
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, offsets, idx):
+    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count):
         _require_cuda(table, offsets, idx)
         table = _f32c(table)
         idx = idx.to(torch.int64).contiguous()
@@ -354,23 +377,45 @@ class _EmbedFn(torch.autograd.Function):
         B, F = idx.shape
         K = table.shape[1]
         out = torch.empty((B, F, K), dtype=torch.float32, device=table.device)
-        check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(idx), ptr(out), B, F, K, stream_ptr()),
-              "fil_embed_gather")
-        ctx.save_for_backward(offsets, idx)
-        ctx.table_shape = tuple(table.shape)
+        check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(oob_count), B, F, K,
+                                           stream_ptr()), "fil_embed_gather")
+        ctx.save_for_backward(offsets, idx, *[t for t in (sizes, frozen) if t is not None])
+        ctx.cfg = (tuple(table.shape), sizes is not None, frozen is not None, bool(sparse_grad), bool(atomic))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        offsets, idx = ctx.saved_tensors
+        table_shape, has_sizes, has_frozen, sparse_grad, atomic = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        offsets, idx = sv[:2]
+        rest = sv[2:]
+        sizes = rest.pop(0) if has_sizes else None
+        frozen = rest.pop(0) if has_frozen else None
         B, F = idx.shape
-        K = ctx.table_shape[1]
-        dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=g.device)
-        check(_lib.load().fil_embed_scatter_add(ptr(offsets), ptr(idx), ptr(_f32c(g)), ptr(dtable), B, F, K, stream_ptr()),
-              "fil_embed_scatter_add")
-        return dtable, None, None
+        K = table_shape[1]
+        g = _f32c(g)
+        if atomic:      # opt-in: fp32 atomics into a zeroed dense table (order of additions not fixed)
+            dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
+            check(_lib.load().fil_embed_scatter_add(ptr(offsets), ptr(sizes), ptr(idx), ptr(g), ptr(dtable), B, F, K, stream_ptr()),
+                  "fil_embed_scatter_add")
+            if frozen is not None:
+                raise FilError("embed_gather: frozen fields are not supported by the atomic scatter-add")
+        elif sparse_grad:   # what Keras hands its optimizers (IndexedSlices): only the touched rows exist
+            rows, values = embed_grad_rows(offsets, sizes, idx, g, frozen)
+            dtable = torch.sparse_coo_tensor(rows.unsqueeze(0), values, table_shape)
+        else:               # dense table, deterministic, no data-dependent shapes (HIP-graph capturable)
+            lib = _lib.load()
+            row_ids = torch.empty(B * F, dtype=torch.int64, device=g.device)
+            check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
+            sorted_ids, perm = torch.sort(row_ids, stable=True)
+            dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
+            check(lib.fil_embed_run_sum(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, stream_ptr()), "fil_embed_run_sum")
+        return dtable, None, None, None, None, None, None, None
 
 
-def embed_gather(table, offsets, idx):
-    """table [sum V_f, K] (all fields concatenated), offsets [F], idx [B,F] -> packed [B,F,K]."""
-    return _EmbedFn.apply(table, offsets, idx)
+def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False, atomic=False, oob_count=None):
+    """table [sum V_f, K] (all fields concatenated), offsets [F], idx [B,F] -> packed [B,F,K].
+    sizes [F] int64: ids outside [0, V_f) give zero rows (counted in oob_count, an int32 device scalar) and no gradient.
+    The gradient is deterministic (sorted segment sums); sparse_grad=True returns it as a sparse COO tensor over the touched
+    rows instead of a dense table; atomic=True selects the fp32-atomic scatter-add instead."""
+    return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count)

@@ -132,3 +132,21 @@ class Layer(torch.nn.Module):
 
     def compute_mask(self, inputs, mask=None):
         return mask
+
+    # -- regularisation losses (Keras: kernel_regularizer / embeddings_regularizer contribute to model.losses) ----------
+    def regularization_losses(self):
+        """Scalar tensors this layer adds to the training loss (overridden where the reference attaches a regularizer)."""
+        return []
+
+
+def collect_regularization_loss(module):
+    """Sum of the regularisation terms of every Layer below `module` (what Keras adds to the compiled loss as
+    sum(model.losses)); a zero scalar when nothing is regularised."""
+    terms = []
+    for m in module.modules():
+        if isinstance(m, Layer):
+            terms += list(m.regularization_losses())
+    if not terms:
+        p = next(module.parameters(), None)
+        return torch.zeros((), device=p.device if p is not None else None)
+    return torch.stack([t.reshape(()) for t in terms]).sum()

@@ -2,6 +2,8 @@
 (StackLayer :32, ScoreLayer :58, MergeScoreLayer :86, HiddenLayer :102, ResActivateLayer :131, DnnLayer :159).
 Dense layers are plain GEMMs and go through torch (hipBLASLt); the AutoInt wrapper path of DnnLayer dispatches to
 the fused attention kernel."""
+import warnings
+
 import torch
 
 from .base import Layer, merge_packed_views, glorot_uniform_
@@ -113,26 +115,44 @@ class MergeScoreLayer(Layer):
 
 
 class HiddenLayer(Layer):
-    """Dense(hidden_units) with glorot_uniform(seed) kernel AND bias (core_layer.py:111-116), optional BatchNorm;
-    call returns (x, inputs).  other_dense replaces the Dense (e.g. by a MultHeadAttentionLayer)."""
+    """Dense(hidden_units) with glorot_uniform(seed) kernel AND bias and kernel_regularizer=l2(l2_reg) (core_layer.py:111-116),
+    optional BatchNorm; call returns (x, inputs).  other_dense replaces the Dense (e.g. by a MultHeadAttentionLayer).
+    The BatchNorm module is created in build() (never inside call): an optimizer or .to(device) made after the first
+    build sees every parameter."""
 
     def __init__(self, hidden_units: int, use_bn: bool = True, seed=2020, l2_reg=0, other_dense=None):
         super().__init__()
         self.dense = other_dense if other_dense else Dense(hidden_units, seed=seed, bias_initializer="glorot_uniform")
+        self.hidden_units = hidden_units
         self.use_bn = use_bn
         self.l2_reg = l2_reg
         self.bn = None
 
+    def build(self, input_shape):
+        if self.use_bn:
+            width = self.hidden_units if isinstance(self.dense, Dense) else getattr(self.dense, "attention_dim", None)
+            if width is None:
+                raise ValueError("HiddenLayer(use_bn=True) around %s: cannot tell the output width at build time" % type(self.dense).__name__)
+            self.bn = torch.nn.BatchNorm1d(int(width), eps=1e-3, momentum=0.01).to(self._build_device)
+        super().build(input_shape)
+
+    def regularization_losses(self):
+        """tf.keras.regularizers.l2(l2_reg) on the Dense kernel (core_layer.py:113)."""
+        if not self.l2_reg or not isinstance(self.dense, Dense) or not self.dense.built:
+            return []
+        return [float(self.l2_reg) * self.dense.kernel.square().sum()]
+
     def call(self, inputs, **kwargs):
         x = self.dense(inputs)
         if self.use_bn:
-            if self.bn is None:
-                self.bn = torch.nn.BatchNorm1d(x.shape[-1], eps=1e-3, momentum=0.01).to(x.device)
             x = self.bn(x)
         return x, inputs
 
 
 class ResActivateLayer(Layer):
+    """BatchNorm / LayerNorm (modules created in build, from the input width) followed by the activation
+    (core_layer.py:131-156)."""
+
     def __init__(self, use_bn, use_ln, hidden_activate):
         super().__init__()
         self.use_bn = use_bn
@@ -141,14 +161,18 @@ class ResActivateLayer(Layer):
         self.bn = None
         self.ln = None
 
+    def build(self, input_shape):
+        width = int(input_shape[-1])
+        if self.use_bn:
+            self.bn = torch.nn.BatchNorm1d(width, eps=1e-3, momentum=0.01).to(self._build_device)
+        if self.use_ln:
+            self.ln = torch.nn.LayerNorm(width, eps=1e-3).to(self._build_device)
+        super().build(input_shape)
+
     def call(self, inputs, **kwargs):
         if self.use_bn:
-            if self.bn is None:
-                self.bn = torch.nn.BatchNorm1d(inputs.shape[-1], eps=1e-3, momentum=0.01).to(inputs.device)
             inputs = self.bn(inputs)
         if self.use_ln:
-            if self.ln is None:
-                self.ln = torch.nn.LayerNorm(inputs.shape[-1], eps=1e-3).to(inputs.device)
             inputs = self.ln(inputs)
         return self.active(inputs)
 
@@ -167,6 +191,11 @@ class DnnLayer(Layer):
             hidden_activate = torch.nn.ReLU()
         self.hidden_list = other_dense
         if not other_dense:
+            # The reference builds HiddenLayer(hidden_units=dim, use_bn=False, other_dense=other_dense) (core_layer.py:182):
+            # its own l2_reg argument never reaches the hidden layers, so nothing is regularised.  Same here, said aloud.
+            if l2_reg:
+                warnings.warn("DnnLayer(l2_reg=%r): the reference drops this argument (core_layer.py:182 builds its HiddenLayers "
+                              "without it); no regulariser is applied. Use HiddenLayer(l2_reg=...) to get one." % (l2_reg,))
             self.hidden_list = [HiddenLayer(hidden_units=dim, use_bn=False, other_dense=other_dense) for dim in hidden_units]
         self.hidden_modules = torch.nn.ModuleList(self.hidden_list)
         self.hidden_activate = hidden_activate

@@ -5,6 +5,8 @@ per-batch arithmetic runs in the HIP kernels behind include/fil.h (no CPU fallba
 
 Packed [B,F,K] is the native layout; the reference's Python lists of F tensors [B,1,K] are accepted and stacked.
 """
+import os
+
 import torch
 
 from .. import functional as Fn
@@ -26,6 +28,9 @@ def pack_linear(inputs, batch):
             return None
         return torch.cat([t.reshape(batch, -1) for t in inputs], dim=1)
     return inputs.reshape(batch, -1)
+
+
+_CHECK_IDS = os.environ.get("FIL_CHECK_IDS", "0") == "1"   # read once at import
 
 
 class InnerLayer(Layer):
@@ -224,10 +229,18 @@ class SparseEmbed(Layer):
     call(list of F integer tensors [B,1] or a packed [B,F]) -> the reference's list of F tensors [B,1,K]
     (views of the packed block; ``packed=True`` returns the block itself), flattened / summed like the reference
     when use_flatten / use_add.
-    """
+
+    Descriptor fields honoured like the reference's Embedding arguments (:209-218), cross tables only:
+      pre_weight    initial table values ([V_f, K] array, or Keras' one-element list of it)
+      is_trainable  False freezes the field: its rows get no gradient
+      emb_reg       l2(emb_reg) on the field's whole table -> regularization_losses() (added to the loss by the trainer)
+    Ids are range-checked in the kernel: an id outside [0, word_size) produces a zero row and no gradient (Keras on a GPU);
+    ``check_ids=True`` (or FIL_CHECK_IDS=1) additionally raises, like Keras on the CPU does (costs a device sync per call).
+    ``sparse_grad=True`` hands the table gradient out as a sparse COO tensor over the touched rows (Keras' IndexedSlices)
+    instead of a dense table; either way it is deterministic (sorted segment sums, no atomics)."""
 
     def __init__(self, sparse_info: list, is_linear=False, use_flatten=True, use_add=False, seed=2020, support_masking=True,
-                 mask_zero=False, packed=False):
+                 mask_zero=False, packed=False, check_ids=None, sparse_grad=False):
         super().__init__()
         self.sparse_info = sparse_info
         self.is_linear = is_linear
@@ -237,6 +250,8 @@ class SparseEmbed(Layer):
         self.supports_masking = support_masking
         self.mask_zero = mask_zero
         self.packed = packed
+        self.check_ids = _CHECK_IDS if check_ids is None else bool(check_ids)
+        self.sparse_grad = sparse_grad
 
     def build(self, input_shape):
         dims = {int(i.linear_unit if self.is_linear else i.cross_unit) for i in self.sparse_info}
@@ -246,23 +261,53 @@ class SparseEmbed(Layer):
         sizes = [int(i.word_size) for i in self.sparse_info]
         self.embeddings = self.add_weight("embeddings", [sum(sizes), k], "zeros")
         off = 0
-        offsets = []
-        for n, v in enumerate(sizes):
+        offsets, frozen, self._reg = [], [], []
+        for n, (v, info) in enumerate(zip(sizes, self.sparse_info)):
             # each table is initialised like its own Keras Embedding (glorot_uniform(seed) over [V_f, K];
             # linear tables use Keras' default 'uniform' = U(-0.05, 0.05))
-            if self.is_linear:
+            pre = None if self.is_linear else getattr(info, "pre_weight", None)
+            if pre is not None:
+                w = pre[0] if isinstance(pre, (list, tuple)) else pre       # Keras: weights=[table]
+                w = torch.as_tensor(w, dtype=torch.float32)
+                if tuple(w.shape) != (v, k):
+                    raise ValueError("pre_weight of %s must be [%d,%d], got %s" % (info.fea_name, v, k, tuple(w.shape)))
+                with torch.no_grad():
+                    self.embeddings[off:off + v].copy_(w)
+            elif self.is_linear:
                 with torch.no_grad():
                     self.embeddings[off:off + v].uniform_(-0.05, 0.05)
             else:
                 glorot_uniform_(self.embeddings.data[off:off + v], seed=self.seed)
+            trainable = True if self.is_linear else getattr(info, "is_trainable", True)
+            frozen.append(0 if (trainable is None or trainable) else 1)
+            reg = 0.0 if self.is_linear else (getattr(info, "emb_reg", 0.0) or 0.0)
+            if reg:
+                self._reg.append((off, off + v, float(reg)))
             offsets.append(off)
             off += v
-        self.register_buffer("offsets", torch.tensor(offsets, dtype=torch.int64, device=self._build_device))
+        dev = self._build_device
+        self.register_buffer("offsets", torch.tensor(offsets, dtype=torch.int64, device=dev))
+        self.register_buffer("sizes", torch.tensor(sizes, dtype=torch.int64, device=dev))
+        self.register_buffer("frozen", torch.tensor(frozen, dtype=torch.uint8, device=dev) if any(frozen) else None)
         super().build(input_shape)
+
+    def regularization_losses(self):
+        """tf.keras.regularizers.l2(emb_reg) on each field's table (interactive_layer.py:217): emb_reg * sum(table^2)."""
+        if not self.built:
+            return []
+        return [reg * self.embeddings[lo:hi].square().sum() for lo, hi, reg in self._reg]
 
     def call(self, inputs, **kwargs):
         idx = torch.cat([t.reshape(t.shape[0], 1) for t in inputs], dim=1) if isinstance(inputs, (list, tuple)) else inputs
-        block = Fn.embed_gather(self.embeddings, self.offsets, idx.to(torch.int64))  # [B,F,K]
+        idx = idx.to(torch.int64)
+        oob = torch.zeros((), dtype=torch.int32, device=idx.device) if self.check_ids else None
+        block = Fn.embed_gather(self.embeddings, self.offsets, idx, sizes=self.sizes, frozen=self.frozen,
+                                sparse_grad=self.sparse_grad, oob_count=oob)  # [B,F,K]
+        if oob is not None and int(oob) > 0:
+            bad = ((idx < 0) | (idx >= self.sizes)).nonzero()[0].tolist()
+            raise IndexError("SparseEmbed: %d ids outside their vocabulary, first at sample %d, field %s (id %d, word_size %d)"
+                             % (int(oob), bad[0], self.sparse_info[bad[1]].fea_name, int(idx[bad[0], bad[1]]),
+                                int(self.sizes[bad[1]])))
         if self.packed:
             return block
         embed_list = list(block.split(1, dim=1))  # F x [B,1,K]

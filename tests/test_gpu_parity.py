@@ -397,6 +397,84 @@ def test_embed_gather_bit_exact():
     check("embed dtable", table.grad, want, tol=1e-6)
 
 
+def test_embed_out_of_range_ids_and_determinism():
+    """Ids outside a field's vocabulary give ZERO rows and no gradient (never the neighbouring field's table: the tables
+    are concatenated); the table gradient is deterministic (sorted segment sums): repeats are bit-identical even with a
+    few rows hit thousands of times, and equal the fp64 oracle; the sparse (rows, values) form sums to the dense one."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(12)
+    vocab = [5, 300, 37, 2]
+    K, B = 16, 4096
+    tables = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
+    idx = np.stack([np.minimum(rng.zipf(1.2, B) - 1, v - 1) for v in vocab], 1)      # heavy duplicates
+    bad = idx.copy()
+    bad[3, 0] = 5            # == V_0: would read row 0 of field 1
+    bad[7, 3] = -1           # negative
+    bad[9, 1] = 10 ** 9
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(vocab)[:-1]]), device="cuda")
+    sizes = torch.tensor(vocab, device="cuda")
+    g = rng.standard_normal((B, len(vocab), K)).astype(np.float32)
+
+    def run(ids, **kw):
+        table = dev(np.concatenate(tables, 0)).requires_grad_()
+        cnt = torch.zeros((), dtype=torch.int32, device="cuda")
+        out = Fn.embed_gather(table, offsets, torch.tensor(ids, device="cuda"), sizes=sizes, oob_count=cnt, **kw)
+        out.backward(dev(g))
+        return out.detach(), table.grad, int(cnt)
+
+    out, grad, n_bad = run(bad)
+    assert n_bad == 3
+    want = closed.embed_gather(tables, np.clip(bad, 0, np.array(vocab) - 1))
+    for (b, f) in [(3, 0), (7, 3), (9, 1)]:
+        want[b, f] = 0.0
+    assert np.array_equal(out.cpu().numpy(), want)
+    gz = g.copy()
+    for (b, f) in [(3, 0), (7, 3), (9, 1)]:
+        gz[b, f] = 0.0
+    want_g = np.concatenate(closed.embed_scatter_add(np.clip(bad, 0, np.array(vocab) - 1), gz, vocab), 0)
+    check("embed grad with oob ids", grad, want_g, tol=1e-6)
+    out2, grad2, _ = run(bad)
+    assert torch.equal(grad, grad2)                                   # bit-identical repeats
+    _, grad_sp, _ = run(bad, sparse_grad=True)
+    assert grad_sp.is_sparse and grad_sp._nnz() <= len(np.unique(idx)) * len(vocab) + 8
+    check("sparse == dense", grad_sp.to_dense(), grad.cpu().numpy(), tol=1e-7)
+    _, grad_at, _ = run(idx, atomic=True)                              # opt-in atomics: same sums, order not fixed
+    check("atomic grad", grad_at, np.concatenate(closed.embed_scatter_add(idx, g, vocab), 0), tol=1e-5)
+    # frozen field (sparseFea.is_trainable = False): no gradient for its rows
+    frozen = torch.tensor([0, 1, 0, 0], dtype=torch.uint8, device="cuda")
+    _, grad_fr, _ = run(idx, frozen=frozen)
+    lo, hi = vocab[0], vocab[0] + vocab[1]
+    assert float(grad_fr[lo:hi].abs().max()) == 0.0 and float(grad_fr[:lo].abs().max()) > 0.0
+
+
+def test_sparse_embed_layer_options():
+    """pre_weight, is_trainable, emb_reg of the sparseFea descriptor (interactive_layer.py:209-218) and the id check."""
+    from ml_function_amd import models
+    from ml_function_amd.layers import SparseEmbed
+    from ml_function_amd.layers.base import collect_regularization_loss
+    rng = np.random.default_rng(3)
+    info = models.make_sparse_info([6, 9, 4], embed_dim=8)
+    w1 = rng.standard_normal((9, 8)).astype(np.float32)
+    info[1] = info[1]._replace(pre_weight=[w1], is_trainable=False, emb_reg=0.0)
+    info[0] = info[0]._replace(emb_reg=0.5)
+    info[2] = info[2]._replace(emb_reg=0.0)
+    emb = SparseEmbed(info, use_flatten=False, check_ids=True)
+    idx = torch.tensor(np.stack([rng.integers(0, v, 32) for v in (6, 9, 4)], 1), device="cuda")
+    outs = emb(idx)
+    assert np.array_equal(outs[1][:, 0].detach().cpu().numpy(), w1[idx[:, 1].cpu().numpy()])     # pre_weight rows, bit-exact
+    reg = collect_regularization_loss(emb)
+    assert abs(float(reg) - 0.5 * float(emb.embeddings[:6].square().sum())) < 1e-6              # l2(emb_reg) on field 0 only
+    (torch.cat(outs, 1).sum() + reg).backward()
+    gr = emb.embeddings.grad
+    assert float(gr[6:15].abs().max()) == 0.0 and float(gr[:6].abs().max()) > 0.0               # frozen field 1
+    bad = idx.clone()
+    bad[5, 2] = 4
+    with pytest.raises(IndexError, match="C3"):
+        emb(bad)
+    quiet = SparseEmbed(info, use_flatten=False, check_ids=False)
+    assert float(quiet(bad)[2][5].abs().max()) == 0.0                                            # Keras-on-GPU semantics
+
+
 # ------------------------------------------------------------------ AutoInt interacting layer
 ATTN_SHAPES = [(4, 200, 16, 4, 16), (3, 39, 16, 3, 8), (2, 5, 4, 2, 4), (5, 17, 8, 1, 16), (2, 33, 24, 2, 16), (64, 39, 16, 2, 16)]
 

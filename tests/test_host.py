@@ -47,6 +47,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
 
 
+def test_embedding_entry_points_validate(lib):
+    assert lib.fil_embed_gather(None, None, None, None, None, None, 4, 3, 8, None) == -1
+    assert lib.fil_embed_gather(None, None, None, None, None, None, 0, 3, 8, None) == 0
+    assert lib.fil_embed_row_ids(None, None, None, None, None, 4, 0, None) == -1
+    assert lib.fil_embed_segment_sum(None, None, None, None, None, None, 5, 300, None) == -4
+    assert lib.fil_embed_run_sum(None, None, None, None, 0, 8, None) == 0
+
+
 def test_workspace_sizes(lib):
     H = _lib.int_array([128, 128, 128])
     B, F, K = 4096, 39, 16

@@ -127,6 +127,67 @@ def test_zoo_matches_oracle_composition(name):
     assert rel(fi.sparse_embed.embeddings.grad, emb64.grad) < 2e-5
 
 
+def test_xdeepfm_adam_step_matches_oracle():
+    """N4: ONE training step as the reference runs it (un_seq.py:61: loss = binary cross-entropy + sum(model.losses), here
+    the l2(emb_reg) of the embedding tables; optimizer 'adam' = lr 1e-3, beta 0.9/0.999, epsilon 1e-7) on the HIP model,
+    against the same step on the float64 oracle graph with a hand-written Adam update: every parameter AFTER the update
+    within 1e-5 (norm-relative), the update itself (new - old) within 1e-3."""
+    from ml_function_amd.layers.base import collect_regularization_loss
+    torch.manual_seed(2)
+    vocab = [7, 11, 5, 13, 3, 17]
+    B, K = 48, 8
+    info = [i._replace(emb_reg=1e-3) for i in models.make_sparse_info(vocab, embed_dim=K)]
+    fi = models.FeatureInput(sparseInfo=info, useLinear=True, useAddLinear=True, useFlattenLinear=True)
+    model = models.CTRModel(fi, models.XDeepFM(conv_size=[16, 12], hidden_units=[32, 16])).cuda()
+    dense, idx = _inputs(B, 3, vocab, seed=9)
+    y = torch.tensor(np.random.default_rng(10).integers(0, 2, B), dtype=torch.float32, device="cuda")
+    model(dense, idx)                                        # lazy build
+    names = [n for n, _ in model.named_parameters()]
+    before = {n: p.detach().cpu().double().clone() for n, p in model.named_parameters()}
+    # ---- oracle: the reference graph in float64 on copies of the parameters
+    P = {n: v.clone().requires_grad_() for n, v in before.items()}
+    b = model.body
+    key = {id(p): n for n, p in model.named_parameters()}
+    O = lambda p: P[key[id(p)]]
+    offs, loff = fi.sparse_embed.offsets.cpu(), fi.linear_embed.offsets.cpu()
+    emb, lin = O(fi.sparse_embed.embeddings), O(fi.linear_embed.embeddings)
+    sparse = graph.sparse_embed([emb[offs[f]:offs[f] + vocab[f]] for f in range(len(vocab))], [idx[:, f:f + 1].cpu() for f in range(len(vocab))])
+    linear = sum(lin[loff[f]:loff[f] + vocab[f]][idx[:, f].cpu()] for f in range(len(vocab)))
+    cin_out = graph.cin(torch.cat(sparse, 1), [O(w)[0] for w in b.cin.conv_kernels], [O(v) for v in b.cin.conv_biases],
+                        O(b.cin.logit_kernel), O(b.cin.logit_bias))
+    x = graph.stack_layer([D64(dense)[:, i:i + 1] for i in range(3)] + sparse)
+    for h in b.dnn.hidden_list:
+        yy = x @ O(h.dense.kernel) + O(h.dense.bias)
+        x = torch.relu(x + yy) if x.shape == yy.shape else torch.relu(yy)
+    dnn_out = x @ O(b.dnn.logit_layer.kernel) + O(b.dnn.logit_layer.bias)
+    p64 = torch.sigmoid(linear + cin_out + dnn_out)[:, 0]
+    y64 = y.cpu().double()
+    reg64 = sum(1e-3 * emb[offs[f]:offs[f] + vocab[f]].square().sum() for f in range(len(vocab)))
+    loss64 = -(y64 * torch.log(p64) + (1 - y64) * torch.log(1 - p64)).mean() + reg64
+    loss64.backward()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-7
+    after64 = {}
+    for n in names:
+        g = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
+        m, v = (1 - b1) * g, (1 - b2) * g * g
+        after64[n] = before[n] - lr * (m / (1 - b1)) / ((v / (1 - b2)).sqrt() + eps)
+    # ---- HIP path: same step
+    opt = torch.optim.Adam(model.parameters(), lr=lr, betas=(b1, b2), eps=eps)
+    opt.zero_grad()
+    out = model(dense, idx)
+    loss = torch.nn.functional.binary_cross_entropy(out[:, 0], y) + collect_regularization_loss(model)
+    assert abs(float(loss) - float(loss64)) < 1e-5 * abs(float(loss64))
+    loss.backward()
+    opt.step()
+    for n, p in model.named_parameters():
+        got = p.detach().cpu().double()
+        if before[n].abs().max() > 0:
+            assert rel(got, after64[n]) < 1e-5, n
+        upd, upd64 = got - before[n], after64[n] - before[n]
+        if upd64.abs().max() > 0:
+            assert float((upd - upd64).abs().max() / upd64.abs().max()) < 1e-3, n     # new - old, the sensitive quantity
+
+
 @pytest.mark.parametrize("name", ["FM", "DeepFM", "DCN", "XDeepFM", "AutoInt"])
 def test_zoo_models_train(name):
     torch.manual_seed(0)
