@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 202
+#define FIL_ABI_VERSION 203
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -155,6 +155,21 @@ int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* 
                  float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H,
                  int A, float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
                  size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ProductAttentionLayer.call([q, k, v], mask) as a stand-alone layer (behavior_layer.py:292-311): separate q / k / v, any
+ * mask.  (AutoInt's own path is fil_attn_*: projections, attention, LayerNorm and residual fused.)
+ *   q [N,Fq,A], k [N,Fk,A], v [N,Fk,Av] -> out [N,Fq,Av] = sigmoid(scale * q k^T + mask * (-1e5)) v     (fp32 MFMA)
+ *   N = the flattened leading axes (e.g. heads x batch); scale = 1/sqrt(A) for use_scale, else 1.
+ *   mask (may be NULL) [mask_period, Fq, Fk], item n uses mask[n % mask_period]: the additive mask of mask_mod == 2
+ *   (:303-306).  mask_mod == 1 (:300-302, the scores right-multiplied by a mask matrix M) is (q k^T) M = q (M^T k)^T:
+ *   the caller passes k' = M^T k and no mask.
+ *   bwd: dout [N,Fq,Av] -> dq, dk, dv.  Limits: A, Av <= 64; LDS footprint 80*(ceil(A/16)+ceil(Av/16))*max(Fq,Fk) bytes <= 160 KiB.
+ */
+int fil_pattn_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, int N, int Fq, int Fk, int A,
+                  int Av, float scale, int mask_period, void* stream);
+int fil_pattn_bwd(const float* q, const float* k, const float* v, const float* mask, const float* dout, float* dq, float* dk,
+                  float* dv, int N, int Fq, int Fk, int A, int Av, float scale, int mask_period, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  SparseEmbed field-index work -- replaces the F Embedding lookups of SparseEmbed.call,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "fil_attn_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "fil_attn_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
     "fil_attn_bwd": (_I, [_P] * 16 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
+    "fil_pattn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "fil_pattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_embed_gather": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_scatter_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_row_ids": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

@@ -343,6 +343,69 @@ def mult_head_attention(x, Wq, Wk, Wr=None, gamma=None, beta=None, use_scale=Tru
     return _AttnFn.apply(x, Wq, Wk, Wr, gamma, beta, _attn_scale(Wq, use_scale), eps, False, _precision(precision))
 
 
+class _PAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale, mask_period):
+        _require_cuda(q, k, v, mask)
+        q, k, v, mask = _f32c(q), _f32c(k), _f32c(v), _f32c(mask)
+        N, Fq, A = q.shape
+        _, Fk, Av = v.shape
+        out = torch.empty((N, Fq, Av), dtype=torch.float32, device=q.device)
+        check(_lib.load().fil_pattn_fwd(ptr(q), ptr(k), ptr(v), ptr(mask), ptr(out), N, Fq, Fk, A, Av, float(scale), int(mask_period),
+                                        stream_ptr()), "fil_pattn_fwd")
+        ctx.save_for_backward(q, k, v, *([mask] if mask is not None else []))
+        ctx.cfg = (float(scale), int(mask_period), mask is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        scale, mask_period, has_mask = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        q, k, v = sv[:3]
+        mask = sv[3] if has_mask else None
+        N, Fq, A = q.shape
+        _, Fk, Av = v.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(_lib.load().fil_pattn_bwd(ptr(q), ptr(k), ptr(v), ptr(mask), ptr(_f32c(dout)), ptr(dq), ptr(dk), ptr(dv), N, Fq, Fk, A, Av,
+                                        scale, mask_period, stream_ptr()), "fil_pattn_bwd")
+        return dq, dk, dv, None, None, None
+
+
+def product_attention(q, k, v, use_scale=False, mask=None, mask_mod=1):
+    """ProductAttentionLayer.call([q, k, v], mask) (reference behavior_layer.py:292-311): q [..., Fq, A], k [..., Fk, A],
+    v [..., Fk, Av] -> sigmoid(scale q k^T (masked)) v, leading axes flattened into the kernel's item axis.
+    mask_mod 1: scores @ mask (mask [..., Fk, Fk'] broadcast over the leading axes; v must have Fk' rows) -- computed as
+    q (mask^T k)^T, so only k is touched; mask_mod 2: scores + mask * (-100000), mask broadcastable to [..., Fq, Fk]."""
+    lead = tuple(q.shape[:-2])
+    Fq, A = q.shape[-2:]
+    scale = 1.0 / (A ** 0.5) if use_scale else 1.0
+    kmask, period = None, 0
+    if mask is not None:
+        m = mask.to(torch.float32)
+        if mask_mod == 1:
+            k = torch.matmul(m.transpose(-1, -2), k)            # (q k^T) M == q (M^T k)^T; autograd carries dk through
+        elif mask_mod == 2:
+            Fk = k.shape[-2]
+            if m.dim() < 2:
+                m = m.reshape((1,) * (2 - m.dim()) + tuple(m.shape))
+            mlead = tuple(m.shape[:-2])
+            # a mask whose leading axes are a suffix of q's (e.g. [B,Fq,Fk] against [H,B,...]) is indexed n % period in the kernel
+            if len(mlead) <= len(lead) and mlead == lead[len(lead) - len(mlead):]:
+                period = 1
+                for s_ in mlead:
+                    period *= s_
+                kmask = m.expand(*mlead, Fq, Fk).reshape(max(period, 1), Fq, Fk).contiguous()
+                period = max(period, 1)
+            else:
+                kmask = m.expand(*lead, Fq, Fk).reshape(-1, Fq, Fk).contiguous()
+                period = kmask.shape[0]
+    if v.shape[-2] != k.shape[-2]:
+        raise FilError("product_attention: k has %d rows but v has %d" % (k.shape[-2], v.shape[-2]))
+    out = _PAttnFn.apply(q.reshape(-1, Fq, A), k.expand(*lead, *k.shape[-2:]).reshape(-1, k.shape[-2], A),
+                         v.reshape(-1, v.shape[-2], v.shape[-1]), kmask, scale, period)
+    return out.reshape(*lead, Fq, v.shape[-1])
+
+
 # --------------------------------------------------------------------------------------------- N1  embeddings
 def embed_grad_rows(offsets, sizes, idx, g, frozen=None):
     """Deterministic embedding-table gradient as (rows [U] int64, values [U,K]): the unique global table rows the batch

@@ -12,9 +12,10 @@ from .base import Layer
 class ProductAttentionLayer(Layer):
     """Scaled product attention with a sigmoid in place of the softmax (behavior_layer.py:272-311).
 
-    On the HIP path the score tensor never exists, so this layer is a configuration holder consumed by
-    MultHeadAttentionLayer's fused kernel (use_scale, mask_mod); calling it on explicit [q,k,v] tensors is outside
-    the hot path and is rejected loudly."""
+    call([q, k, v], mask=None) -> sigmoid(q k^T [/ sqrt(A)] [masked]) v on the HIP path (fil_pattn_*: the scores never
+    leave registers).  mask_mod 1 right-multiplies the scores by the float mask (:300-302), mask_mod 2 adds
+    mask * (-100000) (:303-306).  Inside MultHeadAttentionLayer the same arithmetic runs fused with the projections,
+    LayerNorm and residual (fil_attn_*) when there is no mask."""
 
     def __init__(self, use_scale=False, supports_masking=True, mask_mod=1):
         super().__init__()
@@ -23,8 +24,8 @@ class ProductAttentionLayer(Layer):
         self.mask_mod = mask_mod
 
     def call(self, inputs, mask=None, **kwargs):
-        raise FilError("ProductAttentionLayer on explicit [q,k,v] is not on the HIP hot path; use "
-                       "MultHeadAttentionLayer, which fuses projection, sigmoid attention and LayerNorm")
+        q, k, v = inputs
+        return Fn.product_attention(q, k, v, use_scale=self.use_scale, mask=mask, mask_mod=self.mask_mod)
 
 
 class MultHeadAttentionLayer(Layer):
@@ -71,11 +72,19 @@ class MultHeadAttentionLayer(Layer):
                                    precision=self.precision)
 
     def call(self, inputs, mask=None, **kwargs):
-        if mask is not None:
-            raise FilError("MultHeadAttentionLayer: masks are not supported on the HIP path (AutoInt passes none)")
         Wq, Wk, Wr, g, b = self._args()
-        atten_v, res = Fn.mult_head_attention(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale,
-                                              eps=self.ln_epsilon, precision=self.precision)
+        if mask is None:
+            atten_v, res = Fn.mult_head_attention(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale,
+                                                  eps=self.ln_epsilon, precision=self.precision)
+        else:
+            # masked: the reference's op order (:358-369) with the attention core on the stand-alone kernel -- projections
+            # as tensordot, ProductAttentionLayer([q, k, v], mask), LayerNormalization (epsilon 1e-3) by torch
+            q = torch.tensordot(inputs, Wq, dims=1).permute(2, 0, 1, 3)
+            k = torch.tensordot(inputs, Wk, dims=1).permute(2, 0, 1, 3)
+            atten_v = self.attention_cal([q, k, k], mask=mask)                  # v is projected with key_w (:360)
+            res = torch.tensordot(inputs, Wr, dims=1).permute(2, 0, 1, 3) if Wr is not None else None
+            if g is not None:
+                atten_v = torch.nn.functional.layer_norm(atten_v, (self.attention_dim,), g, b, self.ln_epsilon)
         if res is None:
             res = []
         if self.head_concat:

@@ -628,6 +628,70 @@ def test_attn_repeatable_and_batch_independent():
     assert torch.equal(part[0], a[0][:, 100:164]) and torch.equal(part[1], a[1][100:164])
 
 
+@pytest.mark.parametrize("lead,Fq,Fk,A,Av", [((3, 2), 39, 39, 8, 8), ((5,), 7, 20, 16, 4), ((2, 4), 200, 200, 16, 16), ((2,), 17, 33, 40, 24)])
+@pytest.mark.parametrize("mask_mod", [0, 1, 2])
+def test_product_attention_layer(lead, Fq, Fk, A, Av, mask_mod):
+    """ProductAttentionLayer.call([q,k,v], mask) on explicit tensors, mask_mod 1 (scores @ mask) and 2 (scores + mask*(-1e5)),
+    against the op-for-op oracle (reference behavior_layer.py:292-311) in float64, outputs and all three gradients."""
+    from ml_function_amd.layers import ProductAttentionLayer
+    from oracle import graph
+    rng = np.random.default_rng(21)
+    qn, kn = rng.standard_normal(lead + (Fq, A)), rng.standard_normal(lead + (Fk, A))
+    vn = rng.standard_normal(lead + (Fk, Av))
+    mask = None
+    if mask_mod == 1:
+        mask = (rng.random(lead[-1:] + (Fk, Fk)) < 0.7).astype(np.float32)        # broadcast over the leading axis
+    elif mask_mod == 2:
+        mask = (rng.random(lead[-1:] + (1, Fk)) < 0.3).astype(np.float32)         # key padding mask, broadcast over queries
+    layer = ProductAttentionLayer(use_scale=True, mask_mod=max(mask_mod, 1))
+    q, k, v = [dev(a).requires_grad_() for a in (qn, kn, vn)]
+    out = layer([q, k, v], mask=None if mask is None else dev(mask))
+    T64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    q64, k64, v64 = T64(qn), T64(kn), T64(vn)
+    want = graph.product_attention(q64, k64, v64, use_scale=True, mask=None if mask is None else torch.tensor(mask, dtype=torch.float64),
+                                   mask_mod=max(mask_mod, 1))
+    check("pattn out", out, want.detach().numpy())
+    g = rng.standard_normal(want.shape)
+    out.backward(dev(g))
+    want.backward(torch.tensor(g))
+    check("pattn dq", q.grad, q64.grad.numpy(), tol=2e-5)
+    check("pattn dk", k.grad, k64.grad.numpy(), tol=2e-5)
+    check("pattn dv", v.grad, v64.grad.numpy(), tol=2e-5)
+    if mask_mod == 2:   # masked keys contribute (numerically) nothing
+        dead = mask[..., 0, :] > 0
+        assert float(v.grad.detach().cpu().numpy()[np.broadcast_to(dead[(None,) * (len(lead) - 1)], lead + (Fk,))].__abs__().max()) < 1e-20
+
+
+def test_mult_head_attention_with_mask_matches_reference_graph():
+    """MultHeadAttentionLayer.call(x, mask) (behavior_layer.py:356-377) with atten_mask_mod 2 against the oracle graph."""
+    from ml_function_amd.layers import MultHeadAttentionLayer
+    from oracle import graph
+    B, F, K, H, A = 3, 39, 16, 3, 8
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    rng = np.random.default_rng(5)
+    mask = (rng.random((B, 1, F)) < 0.25).astype(np.float32)
+    att = MultHeadAttentionLayer(attention_dim=A, attention_head_dim=H, atten_mask_mod=2)
+    x = dev(c["x"]).requires_grad_()
+    att._build_device = x.device
+    att.build(tuple(c["x"].shape))
+    att.built = True
+    with torch.no_grad():
+        att.query_w.copy_(dev(c["Wq"])); att.key_w.copy_(dev(c["Wk"])); att.res_w.copy_(dev(c["Wr"]))
+        att.ln_gamma.copy_(dev(c["gamma"])); att.ln_beta.copy_(dev(c["beta"]))
+    av, res = att(x, mask=dev(mask))
+    T64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=True)
+    o = {n: T64(c[n]) for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
+    av_o, res_o = graph.mult_head_attention(o["x"], o["Wq"], o["Wk"], o["Wr"], o["gamma"], o["beta"], mask=torch.tensor(mask, dtype=torch.float64),
+                                            mask_mod=2)
+    check("masked mha atten_v", av, av_o.detach().numpy())
+    check("masked mha res", res, res_o.detach().numpy())
+    g1 = rng.standard_normal(av.shape)
+    (av * dev(g1)).sum().backward()
+    (av_o * torch.tensor(g1)).sum().backward()
+    check("masked mha dx", x.grad, o["x"].grad.numpy(), tol=2e-5)
+    check("masked mha dWk", att.key_w.grad, o["Wk"].grad.numpy(), tol=2e-5)
+
+
 def test_attn_unfused_matches_reference_layer_outputs():
     """MultHeadAttentionLayer.call returns [atten_v, res] (behavior_layer.py:377); gradients flow through both."""
     from ml_function_amd import functional as Fn

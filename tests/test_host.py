@@ -47,6 +47,13 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
 
 
+def test_product_attention_entry_points_validate(lib):
+    assert lib.fil_pattn_fwd(None, None, None, None, None, 4, 39, 39, 80, 8, 1.0, 0, None) == -4      # A > 64
+    assert lib.fil_pattn_fwd(None, None, None, None, None, 0, 39, 39, 8, 8, 1.0, 0, None) == 0       # empty
+    assert lib.fil_pattn_fwd(None, None, None, None, None, 4, 39, 39, 8, 8, 1.0, 0, None) == -1      # NULL tensors
+    assert lib.fil_pattn_bwd(None, None, None, None, None, None, None, None, 4, 0, 39, 8, 8, 1.0, 0, None) == -1
+
+
 def test_embedding_entry_points_validate(lib):
     assert lib.fil_embed_gather(None, None, None, None, None, None, 4, 3, 8, None) == -1
     assert lib.fil_embed_gather(None, None, None, None, None, None, 0, 3, 8, None) == 0
