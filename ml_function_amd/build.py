@@ -62,5 +62,55 @@ def build(force=False, verbose=True):
     return LIB
 
 
+ASAN_OBJ = os.path.join(OBJ, "asan")
+ASAN_LIB = os.path.join(ASAN_OBJ, "libfil_hip_asan.so")
+ASAN_FLAGS = ["-O1", "-g", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-option-ignored",
+              "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+
+
+def asan_runtime():
+    """Path of the AddressSanitizer runtime that a non-instrumented python has to LD_PRELOAD to load ASAN_LIB."""
+    r = subprocess.run([os.path.join(os.path.dirname(HIPCC), "..", "lib", "llvm", "bin", "clang"), "-print-file-name=libclang_rt.asan-x86_64.so"],
+                       capture_output=True, text=True)
+    return r.stdout.strip()
+
+
+def build_asan(verbose=False):
+    """The same sources with AddressSanitizer + UBSan on the HOST pass (hipcc ignores the option for the gfx950 device pass:
+    GPU sanitizers are not available on this pool) -> build/asan/libfil_hip_asan.so.  tests/test_host.py drives the
+    argument-validation / workspace-sizing / error-reporting paths of every entry point through it (no GPU needed)."""
+    os.makedirs(ASAN_OBJ, exist_ok=True)
+    hdr_m = _deps_mtime()
+    jobs, objs = [], []
+    for src in _sources():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(ASAN_OBJ, src[:-4] + ".o")
+        objs.append(o)
+        if not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [HIPCC] + ASAN_FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (asan) failed for %s:\n%s" % (s, r.stderr))
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    if jobs or not os.path.exists(ASAN_LIB):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-o", ASAN_LIB] + objs,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link (asan) failed:\n%s" % r.stderr)
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv))

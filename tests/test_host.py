@@ -2,9 +2,13 @@
 workspace sizing work without a GPU, the layer classes keep the reference's constructor surface / weight names /
 error behaviour, and the product path refuses to run on the CPU (no fallback)."""
 import ctypes
+import os
 import inspect
 
 import numpy as np
+import subprocess
+import sys
+
 import pytest
 import torch
 
@@ -45,6 +49,27 @@ def test_argument_validation_without_gpu(lib):
     # head-major input: the chunk width must divide K; more than 8 heads is outside the one-wave-per-head design
     assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 64, 4, 16, 0.25, 1e-3, 1, 0, 24, None, 0, None) == -1
     assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
+
+
+def test_every_entry_point_validates_its_arguments(lib):
+    from tests import host_calls
+    assert host_calls.run(lib) >= 30
+
+
+def test_host_shim_under_asan_ubsan():
+    """The same calls against the AddressSanitizer + UBSan build of the host shim (hipcc instruments the host pass only: GPU
+    sanitizers are not available on this pool).  A heap / stack overrun, use-after-free or undefined behaviour in argument
+    checking, workspace sizing, launch planning (dw_plan, bwd_grid ...) or error formatting aborts the child."""
+    from ml_function_amd import build as _build
+    asan_lib = _build.build_asan()
+    rt = _build.asan_runtime()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "host_calls.py"), asan_lib], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "host calls ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-3000:]
 
 
 def test_product_attention_entry_points_validate(lib):

@@ -1,0 +1,76 @@
+"""Property tests (hypothesis) of the HIP layers: invariances the reference's arithmetic has by construction, checked on
+randomly drawn small shapes.  GPU only."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+dev = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+
+
+def close(a, b, tol):
+    a, b = a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()
+    return np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30)
+
+
+@settings(max_examples=20, deadline=None)
+@given(B=st.integers(1, 70), F=st.integers(2, 40), K=st.sampled_from([1, 3, 4, 8, 16, 20]), seed=st.integers(0, 2 ** 31 - 1))
+def test_fm_is_field_permutation_equivariant(B, F, K, seed):
+    """sum_{i<j} e_i e_j does not depend on the order of the fields; the embedding gradient permutes with them."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(seed)
+    emb, lin, g = rng.standard_normal((B, F, K)), rng.standard_normal((B, F)), rng.standard_normal((B, K))
+    perm = rng.permutation(F)
+    e1, l1 = dev(emb).requires_grad_(), dev(lin).requires_grad_()
+    e2, l2 = dev(emb[:, perm]).requires_grad_(), dev(lin[:, perm]).requires_grad_()
+    o1, o2 = Fn.fm(e1, l1), Fn.fm(e2, l2)
+    assert close(o2, o1, 2e-5)
+    o1.backward(dev(g))
+    o2.backward(dev(g))
+    assert close(e2.grad, e1.grad[:, perm], 2e-5) and close(l2.grad, l1.grad[:, perm], 1e-6)
+
+
+@settings(max_examples=12, deadline=None)
+@given(B=st.integers(1, 40), F=st.integers(1, 12), K=st.sampled_from([2, 4, 5, 8, 16]),
+       conv=st.lists(st.integers(1, 40), min_size=1, max_size=3), layer=st.integers(0, 2), mode=st.sampled_from([0, 1, 2]),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_cin_is_linear_in_each_layer_kernel(B, F, K, conv, layer, mode, seed):
+    """With zero biases the CIN output is linear in every W_l separately (x^l is linear in W_l and every later layer is
+    linear in x^l): f(a W + b W') = a f(W) + b f(W'), in every kernel mode."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(seed)
+    l = layer % len(conv)
+    x = dev(rng.uniform(-1, 1, (B, F, K)))
+    hp, Ws = F, []
+    for h in conv:
+        Ws.append(rng.uniform(-1, 1, (hp * F, h)) / np.sqrt(hp * F))
+        hp = h
+    W2 = rng.uniform(-1, 1, Ws[l].shape) / np.sqrt(Ws[l].shape[0])
+    bs = [dev(np.zeros(h)) for h in conv]
+    dw, db = dev(rng.uniform(-1, 1, (len(conv) * K, 1))), dev(np.zeros(1))
+    a, b = 0.75, -1.5
+
+    def f(Wl):
+        return Fn.cin(x, [dev(Wl) if i == l else dev(w) for i, w in enumerate(Ws)], bs, dw, db, mode=mode)
+
+    lhs, rhs = f(a * Ws[l] + b * W2), a * f(Ws[l]) + b * f(W2)
+    scale = max(float(f(Ws[l]).abs().max()), float(f(W2).abs().max()), 1e-30)
+    assert float((lhs - rhs).abs().max()) <= 3e-5 * scale
+
+
+@settings(max_examples=12, deadline=None)
+@given(B=st.integers(1, 6), F=st.integers(2, 50), K=st.sampled_from([4, 8, 16, 24]), H=st.integers(1, 4), A=st.sampled_from([4, 8, 16]),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_interacting_layer_is_field_permutation_equivariant(B, F, K, H, A, seed):
+    """No positional information enters the interacting layer: permuting the fields permutes the output rows."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, F, K))
+    W = [dev(rng.standard_normal((K, H, A)) / np.sqrt(K)) for _ in range(3)]
+    gam, bet = dev(1 + 0.1 * rng.standard_normal(A)), dev(0.1 * rng.standard_normal(A))
+    perm = rng.permutation(F)
+    y1 = Fn.autoint_interact(dev(x), W[0], W[1], W[2], gam, bet)
+    y2 = Fn.autoint_interact(dev(x[:, perm]), W[0], W[1], W[2], gam, bet)
+    assert close(y2, y1[:, :, perm], 3e-5)
