@@ -127,11 +127,16 @@ __device__ __forceinline__ typename Prec<F16>::Op tr_read(const typename Prec<F1
   }
 }
 
-// sum over the four lanes {c, c+16, c+32, c+48} (the four 4-element pieces of one fragment row), result in all of them
-__device__ __forceinline__ float groups_sum(float v) {
-  v += __shfl_xor(v, 16);
-  return lane_halves_sum(v);
+// v[lane] + v[lane ^ 16] in every lane with the gfx950 VALU row swap (v_permlane16_swap exchanges the odd rows of its first
+// operand with the even rows of its second), instead of a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ float lane_rows_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
 }
+
+// sum over the four lanes {c, c+16, c+32, c+48} (the four 4-element pieces of one fragment row), result in all of them
+__device__ __forceinline__ float groups_sum(float v) { return lane_halves_sum(lane_rows_sum(v)); }
 
 // sum over the 16 lanes of a row (lanes 16g .. 16g+15), result in all of them: DPP only, no LDS crossbar
 __device__ __forceinline__ float row16_allsum(float v) {
@@ -299,28 +304,25 @@ __device__ __forceinline__ void project_k(const XS& xsrc, typename Prec<F16>::El
 // Lane (g,c) of a 16-row block owns 4 consecutive a (a0 = 4g) of row f of one (head, sample)'s [F][A] slab.  The slab is
 // a raw buffer of F*A*4 bytes: rows f >= F fall outside it by themselves, columns a >= A are pushed out with kOOB.
 struct SlabLane {
-  int A4;        // A * 4 (row pitch in bytes)
-  int off[4];    // byte offset of element a0 + s inside a row, or kOOB
-  bool vecA;     // A % 4 == 0: the four elements are one aligned 16-byte piece (off[0] covers them)
-  __device__ __forceinline__ void init(int A, int a0) {
-    A4 = 4 * A;
-    vecA = (A & 3) == 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) off[s] = a0 + s < A ? 4 * (a0 + s) : kOOB;
+  int A, a0;     // row width, first of the lane's four columns
+  __device__ __forceinline__ void init(int A_, int a0_) {
+    A = A_;
+    a0 = a0_;
   }
+  __device__ __forceinline__ int off(int f, int s) const { return a0 + s < A ? 4 * (f * A + a0 + s) : kOOB; }
   __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, int f) const {
-    if (vecA) return buf_load4(r, f * A4 + off[0]);
+    if ((A & 3) == 0) return buf_load4(r, off(f, 0));     // the four elements are one aligned 16-byte piece
     f32x4 v;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = buf_load1(r, f * A4 + off[s]);
+    for (int s = 0; s < 4; ++s) v[s] = buf_load1(r, off(f, s));
     return v;
   }
   __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int f, const f32x4& v) const {
-    if (vecA) {
-      buf_store4(r, f * A4 + off[0], v);
+    if ((A & 3) == 0) {
+      buf_store4(r, off(f, 0), v);
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) buf_store1(r, f * A4 + off[s], v[s]);
+      for (int s = 0; s < 4; ++s) buf_store1(r, off(f, s), v[s]);
     }
   }
 };
@@ -493,6 +495,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 //   the wave's own fragments AND are the hand-off to the wave that owns a 16-column chunk of dx (sum over the heads in
 //   MFMA accumulators: fixed order, no dx tile in LDS).  The dk part of dx is added in a second visit by the same lanes.
 // Outputs: dx, per-workgroup partials of dWq/dWk/dWr [G][3][K][H][A] and of dgamma/dbeta [G*H][2][16].
+#ifndef FIL_ATTN_TILE_GROUP
+#define FIL_ATTN_TILE_GROUP 1
+#endif
 #ifndef FIL_ATTN_XL_MAXNC
 #define FIL_ATTN_XL_MAXNC 4
 #endif
@@ -504,11 +509,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
     const float* __restrict__ y_s, const float* __restrict__ av_s, float* __restrict__ dx, float* __restrict__ wpart,
-    float* __restrict__ gb_part, AttnDims d, float scale, float eps, int fuse_relu) {
+    float* __restrict__ gb_part, AttnDims d, float scale, float eps, int fuse_relu, long long* __restrict__ stamps) {
   typedef typename Prec<F16>::Elem Elem;
   typedef typename Prec<F16>::Op Op;
   constexpr int RS = Prec<F16>::RS;
-  constexpr int TS = 16 * RS;               // elements per 16-row tile
+  constexpr int TS = 16 * RS;
+  // diagnostic build only (-DFIL_ATTN_STAMPS): shader-clock time per phase and wave, written to a buffer of its own
+#ifdef FIL_ATTN_STAMPS
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_last = __builtin_amdgcn_s_memtime();
+#define FIL_STAMP(P) { const long long t_now = __builtin_amdgcn_s_memtime(); ph[P] += t_now - t_last; t_last = t_now; }
+#else
+#define FIL_STAMP(P)
+#endif               // elements per 16-row tile
   constexpr bool XL = F16 && NC <= FIL_ATTN_XL_MAXNC;   // x image in LDS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -561,13 +574,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     wt.init(Wq, Wk, Wr, d);
   }
   row_write<F16>(kimg, d.FP + c, g, to_op<F16>(f32x4{0.f, 0.f, 0.f, 0.f}));   // the zero tile (never written again)
-  f32x4 gam = {0.f, 0.f, 0.f, 0.f};
+  __shared__ __attribute__((aligned(16))) float gamma_s[16];      // re-read per block: 4 registers less than keeping it
+  if (threadIdx.x < 16) gamma_s[threadIdx.x] = (use_ln && (int)threadIdx.x < d.A) ? gamma[threadIdx.x] : 0.f;
   bool aval[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    aval[s] = 4 * g + s < d.A;
-    if (use_ln && aval[s]) gam[s] = gamma[4 * g + s];
-  }
+  for (int s = 0; s < 4; ++s) aval[s] = 4 * g + s < d.A;
   f32x4 dWq[NC], dWk[NC], dWr[NC];
 #pragma unroll
   for (int cc = 0; cc < NC; ++cc) dWq[cc] = dWk[cc] = dWr[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -585,6 +596,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   }
 
   for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+    FIL_STAMP(7)
     lds_barrier();   // weight table built / the previous sample's k (dk) images and x image are no longer read
     if constexpr (XL) {
       stage_x_f16(x, xs16, d, b, blockDim.x);
@@ -602,7 +614,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     const __amdgpu_buffer_rsrc_t r_dr = make_rsrc(use_dr ? dres_in + slab : dy, use_dr ? slab_bytes : 0);
 
     // block inputs are fetched one query block ahead (they come from HBM)
-    f32x4 n_dy = sl.load(r_dy, c), n_y = sl.load(r_ys, c), n_av = sl.load(r_avs, c), n_dr = sl.load(r_dr, c);
+    // (dres_in of the unfused mode is read at use: one more prefetched tensor would cost the fused mode a wave per SIMD)
+    f32x4 n_dy = sl.load(r_dy, c), n_y = sl.load(r_ys, c), n_av = sl.load(r_avs, c);
 
     {
       Op wk[NC];
@@ -616,16 +629,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     f32x4 dk[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    FIL_STAMP(0)
     for (int i = 0; i < d.nblk; ++i) {
       const int par = i & 1;
-      f32x4 dz = n_dy, dr = n_dr;
+      f32x4 dz = n_dy, dr = {0.f, 0.f, 0.f, 0.f};
+      if (use_dr) dr = sl.load(r_dr, 16 * i + c);
       const f32x4 yv = n_y, avv = n_av;
       {
         const int fn = 16 * (i + 1) + c;    // past the last block every lane is out of range and reads zeros
         n_dy = sl.load(r_dy, fn);
         n_y = sl.load(r_ys, fn);
         n_av = sl.load(r_avs, fn);
-        n_dr = sl.load(r_dr, fn);
       }
       // ---- LayerNorm / ReLU backward of query block i: lane (g,c) owns row f = 16i+c, a = 4g..4g+3
       if (fuse_relu) {
@@ -650,6 +664,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         const float rstd = __builtin_amdgcn_rsqf(groups_sum(sq) * inv_a + eps);   // v_rsq_f32, 1 ulp
         float s1 = 0.f, s2 = 0.f;
         f32x4 dxh;
+        const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma_s + 4 * g);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           xh[s] *= rstd;
@@ -679,6 +694,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
       }
       const Op qn = to_op<F16>(qT * qs);     // scores come out as -log2(e) * scale * q.k
       const Op qc = to_op<F16>(qD * scale);  // dk += dP^T (scale q)
+      FIL_STAMP(1)
       f32x4 dqT = {0.f, 0.f, 0.f, 0.f};
       // ---- the score tiles, software-pipelined over three tiles: [LDS reads of tile j+1] [sigmoid + dk of tile j]
       // [S, dS of tile j+1] [dq of tile j-1].  The k image carries one zero tile behind the last key block, so the reads
@@ -712,7 +728,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         dk[j] = mma<F16>(qc, dp_o, dk[j]);                    // dk^T[a 4g+r][key c] += (scale q)^T dP
         dk[j] = mma<F16>(dav_c, sg_o, dk[j]);                 //                     += dav^T S      (V == K)
         kT_prev = kT_j;
-        __builtin_amdgcn_sched_barrier(0);
+        // scheduling fence every FIL_ATTN_TILE_GROUP tiles: inside a group the scheduler may interleave the tiles' chains
+        // (instruction-level parallelism for a kernel that runs at two waves per SIMD), across groups it may not (registers)
+        if constexpr (j % FIL_ATTN_TILE_GROUP == FIL_ATTN_TILE_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
       };
       // straight-line tiles with a scalar exit test each (a `break` in an unrolled loop re-rolls it and sends dk to scratch;
       // the count is laundered through an empty asm so that the NB exit conditions are not hoisted out of the block loop
@@ -734,6 +752,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         const Op dpT = tr_read<F16>(tiles + ((d.nblk - 1) & 1) * TS, 0, lane);
         dqT = mma<F16>(kT_prev, dpT, dqT);
       }
+      FIL_STAMP(2)
       const Op dq_r = to_op<F16>(dqT * scale);                // row fragment of dq_i
       Elem* t_dq = tiles + (2 + 2 * par) * TS;
       row_write<F16>(t_dq, c, g, dq_r);
@@ -747,9 +766,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         dWq[cc] = mma<F16>(xc, dq_c, dWq[cc]);                // [kin 4g+r][a c]
         if (has_res) dWr[cc] = mma<F16>(xc, dr_c, dWr[cc]);
       }
+      FIL_STAMP(3)
       lds_barrier();   // every head's dq / dres tile of this step is in LDS
-      // ---- dx_i[:, 16cc..] = sum_heads dq Wq^T + dres Wr^T, by the wave that owns chunk cc
-      for (int cc = h; cc < NC; cc += nw) {
+      FIL_STAMP(4)
+      // ---- dx_i[:, 16cc..] = sum_heads dq Wq^T + dres Wr^T, by the wave that owns chunk cc of THIS block: the owner
+      // rotates with the block index, so the extra work (and the arrival skew it causes at the next barrier) is spread
+      // over the waves instead of landing on wave 0 every step
+      for (int cc = (h + nw - i % nw) % nw; cc < NC; cc += nw) {
         f32x4 px = {0.f, 0.f, 0.f, 0.f};
         for (int hh = 0; hh < nw; ++hh) {
           const Elem* th = tiles0 + (hh * 6 + 2 + 2 * par) * TS;
@@ -763,7 +786,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
           buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);      // [query 4g+r][kin c]
         }
       }
+      FIL_STAMP(5)
     }
+    FIL_STAMP(5)
     // ---- dk of this head: accumulators -> the (now dead) k image as row fragments [key][a]
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -777,19 +802,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     // dx += dk Wk^T (summed over the heads), by the lanes that wrote the dq part of the same elements.  All of a chunk's
     // read-backs are issued before the first is used (they come from L2 / the Infinity Cache; the dk accumulators'
     // registers are free by now).
-    for (int cc = h; cc < NC; cc += nw) {
-      const int kin = 16 * cc + c;
+    // (block j's chunk cc belongs to wave (cc + j) % nw, as in the block loop: the same lanes revisit the same elements;
+    // this wave's chunk of block j in round m is ((h - j) mod nw) + m nw)
+    for (int m = 0; m * nw < NC; ++m) {
       f32x4 old[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
+      for (int j = 0; j < NB; ++j) {
+        const int cc = (h + nw - j % nw) % nw + m * nw, kin = 16 * cc + c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * j + 4 * g + r;
-          old[j][r] = buf_load1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
+          old[j][r] = buf_load1(r_dx, (cc < NC && f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
         }
+      }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        if (j < d.nblk) {
+        const int cc = (h + nw - j % nw) % nw + m * nw, kin = 16 * cc + c;
+        if (j < d.nblk && cc < NC) {
           f32x4 px = old[j];
           for (int hh = 0; hh < nw; ++hh)
             px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
@@ -802,6 +831,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
       }
     }
   }
+  FIL_STAMP(6)
+#ifdef FIL_ATTN_STAMPS
+  if (stamps != nullptr && lane == 0)
+    for (int p8 = 0; p8 < 8; ++p8) stamps[((long)blockIdx.x * nw + h) * 8 + p8] = ph[p8];
+#endif
   // ---- per-workgroup partials of the parameter gradients
   float* wp = wpart + (long)blockIdx.x * 3 * d.K * d.H * d.A;
   const long wstride = (long)d.K * d.H * d.A;
@@ -962,6 +996,9 @@ static int resident_blocks(KernelT kernel, int threads, size_t sh) {
     case 4: { if (f16) { CALL(4, true); } else { CALL(4, false); } } break;  \
   }
 
+// diagnostic builds (-DFIL_ATTN_STAMPS): device buffer the backward writes its per-phase clocks to (fil_attn_debug_stamps)
+static long long* g_attn_stamps = nullptr;
+
 static int launch_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma, const float* beta,
                       float* y, float* res_out, float* av_out, const AttnDims& d, float scale, float eps, int fuse_relu,
                       bool f16, hipStream_t st) {
@@ -984,6 +1021,10 @@ static int launch_fwd(const float* x, const float* Wq, const float* Wk, const fl
 }  // namespace fil
 
 using namespace fil;
+
+#ifdef FIL_ATTN_STAMPS
+extern "C" void fil_attn_debug_stamps(long long* buf) { g_attn_stamps = buf; }
+#endif
 
 extern "C" size_t fil_attn_fwd_workspace_bytes(int, int, int, int, int) { return 0; }
 
@@ -1074,7 +1115,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   if (lrc == FIL_OK) {                                                                                                      \
     G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV>, 64 * H, sh));                                               \
     hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved,    \
-                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu);                                            \
+                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                             \
   }
 #define CALL_BWD(N, P)                                  \
   if (d.nblk <= 4) { CALL_BWD_NB(N, P, 4); }            \

@@ -37,8 +37,9 @@ def test_fm_is_field_permutation_equivariant(B, F, K, seed):
        conv=st.lists(st.integers(1, 40), min_size=1, max_size=3), layer=st.integers(0, 2), mode=st.sampled_from([0, 1, 2]),
        seed=st.integers(0, 2 ** 31 - 1))
 def test_cin_is_linear_in_each_layer_kernel(B, F, K, conv, layer, mode, seed):
-    """With zero biases the CIN output is linear in every W_l separately (x^l is linear in W_l and every later layer is
-    linear in x^l): f(a W + b W') = a f(W) + b f(W'), in every kernel mode."""
+    """With zero biases x^l is linear in W_l and every later layer is linear in x^l, so the output is AFFINE in every W_l
+    separately (the pooled outputs of the layers below l are a constant): f(a W + (1-a) W') = a f(W) + (1-a) f(W'), in every
+    kernel mode (a outside [0,1]: an extrapolation, not an average)."""
     from ml_function_amd import functional as Fn
     rng = np.random.default_rng(seed)
     l = layer % len(conv)
@@ -50,7 +51,7 @@ def test_cin_is_linear_in_each_layer_kernel(B, F, K, conv, layer, mode, seed):
     W2 = rng.uniform(-1, 1, Ws[l].shape) / np.sqrt(Ws[l].shape[0])
     bs = [dev(np.zeros(h)) for h in conv]
     dw, db = dev(rng.uniform(-1, 1, (len(conv) * K, 1))), dev(np.zeros(1))
-    a, b = 0.75, -1.5
+    a, b = 1.75, -0.75
 
     def f(Wl):
         return Fn.cin(x, [dev(Wl) if i == l else dev(w) for i, w in enumerate(Ws)], bs, dw, db, mode=mode)
