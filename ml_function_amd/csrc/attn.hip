@@ -84,6 +84,15 @@ __device__ __forceinline__ typename Prec<F16>::Op to_op(f32x4 v) {
   }
 }
 
+template <bool F16>
+__device__ __forceinline__ f32x4 from_op(typename Prec<F16>::Op v) {
+  if constexpr (F16) {
+    return __builtin_convertvector(v, f32x4);
+  } else {
+    return v;
+  }
+}
+
 // ---- LDS tile images: [rows][16] elements ------------------------------------------------------------------------------
 // f16: 32-byte rows; the four 8-byte chunks of row r are stored at chunk ^ ((r >> 2) & 3).  Conflict-free for all three
 // access shapes: 8-byte row reads (a 32-lane half = 16 rows x 2 chunks over 64 banks: rows r and r+8 share their bank
@@ -292,8 +301,8 @@ __device__ __forceinline__ void load_w_kin(const float* __restrict__ W, int h, c
 // k image of one head (== v): kimg[f][a] = (x Wk)[f][a], written as row fragments from the transposed product
 template <int NC, bool F16, typename XS>
 __device__ __forceinline__ void project_k(const XS& xsrc, typename Prec<F16>::Elem* kimg, const typename Prec<F16>::Op (&wk)[NC],
-                                          int nblk, int lane) {
-  for (int blk = 0; blk < nblk; ++blk) {
+                                          int first, int step, int nblk, int lane) {
+  for (int blk = first; blk < nblk; blk += step) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc = mma<F16>(wk[c], xsrc.row(blk, c, lane), acc);   // D[a 4g+r][f lane&15]
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
       bet[s] = beta[4 * g + s];
     }
   }
-  project_k<NC, F16>(xsrc, kimg, wk, d.nblk, lane);
+  project_k<NC, F16>(xsrc, kimg, wk, 0, 1, d.nblk, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
@@ -504,7 +513,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 #ifndef FIL_ATTN_BWD_WPE
 #define FIL_ATTN_BWD_WPE(NC, F16) 2
 #endif
-template <int NC, bool F16, int NB>
+// WPH = waves per head.  1: a head is one wave.  2: two waves per head take alternate QUERY blocks (block i = 2 step + sub):
+// nothing is computed twice (each wave runs the whole prologue + all key tiles of its own blocks and keeps its own partial dk /
+// dW / dgamma sums, merged after the loop), and a workgroup has twice the waves -- for the shapes whose LDS footprint lets only
+// one workgroup onto a CU (K = 64 layers of a stack, the f32 mode at large F) that is the second wave per SIMD.
+template <int NC, bool F16, int NB, int WPH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BWD_WPE(NC, F16)))) void attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
@@ -524,8 +537,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
 #endif               // elements per 16-row tile
   constexpr bool XL = F16 && NC <= FIL_ATTN_XL_MAXNC;   // x image in LDS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;   // == H
+  static_assert(WPH == 1 || WPH == 2, "one or two waves per head");
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;   // == H * WPH
+  const int NH = d.H;
+  const int h = w / WPH, sub = w % WPH;   // this wave's head; its query blocks are i = WPH * step + sub
   const int c = lane & 15, g = lane >> 4;
   unsigned char* sp = smem_raw;
   XSrc<F16, XL> xsrc;
@@ -540,10 +556,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   }
   const int KIS = (d.FP + 16) * RS;           // k image of one head: FP rows + one zero tile (the pipeline reads one tile ahead)
   Elem* kimg0 = reinterpret_cast<Elem*>(sp);
-  Elem* kimg = kimg0 + h * KIS;
-  sp += (size_t)nw * KIS * sizeof(Elem);
+  Elem* kimg = kimg0 + h * KIS;               // shared by the head's waves
+  sp += (size_t)NH * KIS * sizeof(Elem);
   Elem* tiles0 = reinterpret_cast<Elem*>(sp);
-  Elem* tiles = tiles0 + h * 6 * TS;
+  Elem* tiles = tiles0 + w * 6 * TS;          // per wave
   sp += (size_t)nw * 6 * TS * sizeof(Elem);
   const bool use_ln = gamma != nullptr, has_res = Wr != nullptr;
   SlabLane sl;
@@ -554,13 +570,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   if constexpr (F16) {
     _Float16* wtab = reinterpret_cast<_Float16*>(sp);     // tile (m, hh, cc) at ((m*nw + hh)*NC + cc)*256
     wt.tab = wtab;
-    wt.nw = nw;
+    wt.nw = NH;
     wt.NC = NC;
     const float* Wm[3] = {Wq, Wk, Wr};
-    const int ntile = 3 * nw * NC;
+    const int ntile = 3 * NH * NC;
     for (int idx = threadIdx.x; idx < ntile * 64; idx += blockDim.x) {
       const int tl = idx >> 6, kin_l = (idx >> 2) & 15, a4 = idx & 3;
-      const int m = tl / (nw * NC), rem = tl - m * nw * NC, hh = rem / NC, cc = rem - hh * NC;
+      const int m = tl / (NH * NC), rem = tl - m * NH * NC, hh = rem / NC, cc = rem - hh * NC;
       const int kin = 16 * cc + kin_l;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (Wm[m] != nullptr && kin < d.K) {
@@ -615,28 +631,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
 
     // block inputs are fetched one query block ahead (they come from HBM)
     // (dres_in of the unfused mode is read at use: one more prefetched tensor would cost the fused mode a wave per SIMD)
-    f32x4 n_dy = sl.load(r_dy, c), n_y = sl.load(r_ys, c), n_av = sl.load(r_avs, c);
+    f32x4 n_dy = sl.load(r_dy, 16 * sub + c), n_y = sl.load(r_ys, 16 * sub + c), n_av = sl.load(r_avs, 16 * sub + c);
 
     {
       Op wk[NC];
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) wk[cc] = F16 ? wt.kin(1, h, cc, lane) : wk_r[cc];
-      project_k<NC, F16>(xsrc, kimg, wk, d.nblk, lane);
+      project_k<NC, F16>(xsrc, kimg, wk, sub, WPH, d.nblk, lane);   // the head's waves share the blocks
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (WPH > 1) {
+      lds_barrier();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
 
     f32x4 dk[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     FIL_STAMP(0)
-    for (int i = 0; i < d.nblk; ++i) {
-      const int par = i & 1;
+    for (int step = 0; step * WPH < d.nblk; ++step) {
+      const int i = step * WPH + sub, par = step & 1;
+      if (WPH == 1 || i < d.nblk) {     // (wave-uniform; with two waves per head and an odd block count the last step is one wave's)
       f32x4 dz = n_dy, dr = {0.f, 0.f, 0.f, 0.f};
       if (use_dr) dr = sl.load(r_dr, 16 * i + c);
       const f32x4 yv = n_y, avv = n_av;
       {
-        const int fn = 16 * (i + 1) + c;    // past the last block every lane is out of range and reads zeros
+        const int fn = 16 * (i + WPH) + c;  // past the last block every lane is out of range and reads zeros
         n_dy = sl.load(r_dy, fn);
         n_y = sl.load(r_ys, fn);
         n_av = sl.load(r_avs, fn);
@@ -767,34 +788,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         if (has_res) dWr[cc] = mma<F16>(xc, dr_c, dWr[cc]);
       }
       FIL_STAMP(3)
-      lds_barrier();   // every head's dq / dres tile of this step is in LDS
+      }
+      lds_barrier();   // every wave's dq / dres tile of this step is in LDS
       FIL_STAMP(4)
-      // ---- dx_i[:, 16cc..] = sum_heads dq Wq^T + dres Wr^T, by the wave that owns chunk cc of THIS block: the owner
-      // rotates with the block index, so the extra work (and the arrival skew it causes at the next barrier) is spread
-      // over the waves instead of landing on wave 0 every step
-      for (int cc = (h + nw - i % nw) % nw; cc < NC; cc += nw) {
-        f32x4 px = {0.f, 0.f, 0.f, 0.f};
-        for (int hh = 0; hh < nw; ++hh) {
-          const Elem* th = tiles0 + (hh * 6 + 2 + 2 * par) * TS;
-          px = mma<F16>(row_read<F16>(th, c, g), wt.arole(0, hh, cc, lane), px);
-          if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), wt.arole(2, hh, cc, lane), px);
-        }
-        const int kin = 16 * cc + c;
+      // ---- dx_i[:, 16cc..] = sum_heads dq Wq^T + dres Wr^T for the step's blocks: job q = (sub', cc) belongs to wave
+      // (q + step) mod nw: the owner rotates with the step, so the extra work (and the arrival skew it causes at the next
+      // barrier) is spread over the waves instead of landing on wave 0 every step
+      for (int q = (w + nw - step % nw) % nw; q < WPH * NC; q += nw) {
+        const int qs_ = q / NC, cc = q - qs_ * NC, bi = step * WPH + qs_;
+        if (bi < d.nblk) {
+          f32x4 px = {0.f, 0.f, 0.f, 0.f};
+          for (int hh = 0; hh < NH; ++hh) {
+            const Elem* th = tiles0 + ((hh * WPH + qs_) * 6 + 2 + 2 * par) * TS;
+            px = mma<F16>(row_read<F16>(th, c, g), wt.arole(0, hh, cc, lane), px);
+            if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), wt.arole(2, hh, cc, lane), px);
+          }
+          const int kin = 16 * cc + c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = 16 * i + 4 * g + r;
-          buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);      // [query 4g+r][kin c]
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * bi + 4 * g + r;
+            buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);      // [query 4g+r][kin c]
+          }
         }
       }
       FIL_STAMP(5)
     }
     FIL_STAMP(5)
     // ---- dk of this head: accumulators -> the (now dead) k image as row fragments [key][a]
+    // (two waves per head: each holds the sum over its own query blocks; the second wave's part goes through the image)
+    if constexpr (WPH > 1) {
+      if (sub == 1) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
+        for (int j = 0; j < NB; ++j)
+          if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
+      }
+      lds_barrier();
+      if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (j < d.nblk) dk[j] += from_op<F16>(row_read<F16>(kimg, 16 * j + c, g));
+      }
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
+    }
     lds_barrier();
-    for (int j = 0; j < d.nblk; ++j) {
+    for (int j = sub; j < d.nblk; j += WPH) {
       const Op dk_c = tr_read<F16>(kimg, 16 * j, lane);       // dk[key 4g+s][a c]
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) dWk[cc] = mma<F16>(xsrc.col(j, cc, lane), dk_c, dWk[cc]);
@@ -802,25 +843,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     // dx += dk Wk^T (summed over the heads), by the lanes that wrote the dq part of the same elements.  All of a chunk's
     // read-backs are issued before the first is used (they come from L2 / the Infinity Cache; the dk accumulators'
     // registers are free by now).
-    // (block j's chunk cc belongs to wave (cc + j) % nw, as in the block loop: the same lanes revisit the same elements;
-    // this wave's chunk of block j in round m is ((h - j) mod nw) + m nw)
-    for (int m = 0; m * nw < NC; ++m) {
+    // (job (block j = WPH step + sub', chunk cc) belongs to wave (sub' NC + cc + step) % nw, as in the block loop: the same
+    // lanes revisit the same elements; this wave's job of step `st` in round m is q = ((w - st) mod nw) + m nw)
+    for (int m = 0; m * nw < WPH * NC; ++m) {
       f32x4 old[NB];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int cc = (h + nw - j % nw) % nw + m * nw, kin = 16 * cc + c;
+        const int q = (w + nw - (j / WPH) % nw) % nw + m * nw, cc = q - (j % WPH) * NC, kin = 16 * cc + c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * j + 4 * g + r;
-          old[j][r] = buf_load1(r_dx, (cc < NC && f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
+          old[j][r] = buf_load1(r_dx, (cc >= 0 && cc < NC && f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
         }
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int cc = (h + nw - j % nw) % nw + m * nw, kin = 16 * cc + c;
-        if (j < d.nblk && cc < NC) {
+        const int q = (w + nw - (j / WPH) % nw) % nw + m * nw, cc = q - (j % WPH) * NC, kin = 16 * cc + c;
+        if (j < d.nblk && cc >= 0 && cc < NC) {
           f32x4 px = old[j];
-          for (int hh = 0; hh < nw; ++hh)
+          for (int hh = 0; hh < NH; ++hh)
             px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -834,10 +875,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   FIL_STAMP(6)
 #ifdef FIL_ATTN_STAMPS
   if (stamps != nullptr && lane == 0)
-    for (int p8 = 0; p8 < 8; ++p8) stamps[((long)blockIdx.x * nw + h) * 8 + p8] = ph[p8];
+    for (int p8 = 0; p8 < 8; ++p8) stamps[((long)blockIdx.x * nw + w) * 8 + p8] = ph[p8];
 #endif
   // ---- per-workgroup partials of the parameter gradients
-  float* wp = wpart + (long)blockIdx.x * 3 * d.K * d.H * d.A;
+  float* wp = wpart + ((long)blockIdx.x * WPH + sub) * 3 * d.K * d.H * d.A;   // one partial set per (workgroup, sub)
   const long wstride = (long)d.K * d.H * d.A;
 #pragma unroll
   for (int cc = 0; cc < NC; ++cc)
@@ -853,7 +894,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     }
   if (use_ln) {
     // lane (g,c) holds partial sums for a = 4g+s over its queries: sum the 16 lanes of the row
-    float* gp = gb_part + ((long)blockIdx.x * nw + h) * 32;
+    float* gp = gb_part + ((long)blockIdx.x * nw + w) * 32;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float tg = row16_allsum(dgam[s]), tb = row16_allsum(dbet[s]);
@@ -928,27 +969,27 @@ static int make_dims(const char* fn, int B, int F, int K, int H, int A, int x_ch
 static size_t fwd_lds(const AttnDims& d, bool f16) {
   return f16 ? ((size_t)d.NC * d.FP * 16 + (size_t)d.H * d.FP * 16) * sizeof(_Float16) : (size_t)d.H * d.FP * 20 * sizeof(float);
 }
-static size_t bwd_lds(const AttnDims& d, bool f16) {
-  const size_t tiles = (size_t)d.H * 6 + 3 * (size_t)d.H * d.NC;   // per-wave tiles + the weight table
+static size_t bwd_lds(const AttnDims& d, bool f16, int wph = 1) {
+  const size_t tiles = (size_t)d.H * wph * 6 + 3 * (size_t)d.H * d.NC;   // per-wave tiles + the weight table
   if (f16) {
     const size_t ximg = d.NC <= FIL_ATTN_XL_MAXNC ? (size_t)d.NC * d.FP * 16 : 0;
     return (ximg + (size_t)d.H * (d.FP + 16) * 16 + tiles * 256) * sizeof(_Float16);
   }
-  return ((size_t)d.H * (d.FP + 16) * 20 + (size_t)d.H * 6 * 320) * sizeof(float);   // no weight table in the f32 mode
+  return ((size_t)d.H * (d.FP + 16) * 20 + (size_t)d.H * wph * 6 * 320) * sizeof(float);   // no weight table in the f32 mode
 }
 constexpr size_t kLdsCap = 160 * 1024;
 constexpr int kMaxBwdGrid = 1024;   // persistent workgroups (the workspace holds this many partial sums)
 
 // persistent backward grid: `per_cu` resident workgroups on each of the 256 CUs, sized so that every workgroup takes the
 // same number of samples (+-1)
-static int bwd_grid(const AttnDims& d, int per_cu) {
-  const long cap = std::min<long>(kMaxBwdGrid, 256L * std::max(1, per_cu));
+static int bwd_grid(const AttnDims& d, int per_cu, int wph = 1) {
+  const long cap = std::min<long>(kMaxBwdGrid / wph, 256L * std::max(1, per_cu));   // (grid * wph partial sets fit the workspace)
   const long rounds = ((long)d.B + cap - 1) / cap;
   return (int)std::max<long>(1, ((long)d.B + rounds - 1) / std::max<long>(rounds, 1));
 }
 
 static size_t attn_bwd_ws(const AttnDims& d, bool have_saved) {
-  const long G = std::min<long>(kMaxBwdGrid, std::max(d.B, 1));
+  const long G = std::min<long>(kMaxBwdGrid, 2L * std::max(d.B, 1));   // partial sets: workgroups x waves per head
   size_t t = align_up((size_t)G * 3 * d.K * d.H * d.A * sizeof(float), 256);       // dW partials
   t += align_up((size_t)G * d.H * 32 * sizeof(float), 256);                         // dgamma/dbeta partials
   if (!have_saved) t += 2 * align_up((size_t)d.H * d.B * d.F * d.A * sizeof(float), 256);   // av / y recomputed
@@ -1086,11 +1127,20 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   // unfused mode: the residual branch's gradient arrives separately (dres_in)
   const bool has_res = Wr != nullptr;
   if (!fuse_relu && has_res && dres_in == nullptr) return fail(FIL_ERR_ARG, "fil_attn_bwd: dres is required when fuse_relu == 0 and Wr != NULL");
-  const size_t sh = bwd_lds(d, f16);
+  size_t sh = bwd_lds(d, f16);
   if (sh > kLdsCap)
     return fail(FIL_ERR_UNSUPPORTED, "fil_attn_bwd: F=%d K=%d H=%d needs %zu bytes of LDS (> 160 KiB)%s", F, K, H, sh,
                 f16 ? "" : "; the f16-MFMA precision needs less than half of that");
-  const long Gws = std::min<long>(kMaxBwdGrid, B);
+  // two waves per head when the footprint lets only ONE one-wave-per-head workgroup onto a CU (and the doubled workgroup fits)
+  static const int wph_knob = [] {   // 0 = automatic, 1 / 2 = forced (tests, sweeps); read once
+    const char* e = getenv("FIL_ATTN_WPH");
+    return e != nullptr ? atoi(e) : 0;
+  }();
+  int wph = (2 * sh > kLdsCap && d.nblk > 8) ? 2 : 1;
+  if (wph_knob == 1 || wph_knob == 2) wph = d.nblk > 8 ? wph_knob : 1;
+  if (wph == 2 && (H > 4 || bwd_lds(d, f16, 2) > kLdsCap || d.nblk < 2)) wph = 1;
+  sh = bwd_lds(d, f16, wph);
+  const long Gws = std::min<long>(kMaxBwdGrid, 2L * B);
   Carver ws(workspace);
   float* wpart = ws.take<float>((size_t)Gws * 3 * K * H * A);
   float* gb_part = ws.take<float>((size_t)Gws * H * 32);
@@ -1108,20 +1158,21 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   {
     // algorithmic flops of the score pass: S, dS, dq, 2 x dk = 5 products of 2*F*F*A, plus projections and their gradients
     ProfScope ps("attn_bwd", st, (double)B * H * (10.0 * F * (double)F * A + 2.0 * F * K * A * (has_res ? 9 : 7)));
-    const dim3 block(64 * H);
+    const dim3 block(64 * H * wph);
     int lrc = FIL_OK;
-#define CALL_BWD_NB(N, P, NBV)                                                                                              \
-  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV>, sh);                                                                     \
+#define CALL_BWD_NB(N, P, NBV, WV)                                                                                          \
+  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV, WV>, sh);                                                                 \
   if (lrc == FIL_OK) {                                                                                                      \
-    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV>, 64 * H, sh));                                               \
-    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved,    \
+    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV, WV>, 64 * H * WV, sh), WV);                                  \
+    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV, WV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, \
                        av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                             \
   }
-#define CALL_BWD(N, P)                                  \
-  if (d.nblk <= 4) { CALL_BWD_NB(N, P, 4); }            \
-  else if (d.nblk <= 8) { CALL_BWD_NB(N, P, 8); }       \
-  else if (d.nblk <= 13) { CALL_BWD_NB(N, P, 13); }     \
-  else { CALL_BWD_NB(N, P, 32); }
+  // (the two-waves-per-head form exists for the large-F instantiations only: smaller shapes fit two workgroups per CU)
+#define CALL_BWD(N, P)                                                                     \
+  if (d.nblk <= 4) { CALL_BWD_NB(N, P, 4, 1); }                                            \
+  else if (d.nblk <= 8) { CALL_BWD_NB(N, P, 8, 1); }                                       \
+  else if (d.nblk <= 13) { if (wph == 2) { CALL_BWD_NB(N, P, 13, 2); } else { CALL_BWD_NB(N, P, 13, 1); } } \
+  else { if (wph == 2) { CALL_BWD_NB(N, P, 32, 2); } else { CALL_BWD_NB(N, P, 32, 1); } }
     FIL_ATTN_NC(d.NC, CALL_BWD)
 #undef CALL_BWD
 #undef CALL_BWD_NB
@@ -1129,10 +1180,10 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     FIL_CHECK_LAUNCH();
   }
   const int n = K * H * A;
-  hipLaunchKernelGGL(attn_reduce_dw_kernel, dim3(cdiv(n, 64), 3), dim3(256), 0, st, wpart, dWq, dWk, dWr, n, G);
+  hipLaunchKernelGGL(attn_reduce_dw_kernel, dim3(cdiv(n, 64), 3), dim3(256), 0, st, wpart, dWq, dWk, dWr, n, G * wph);
   FIL_CHECK_LAUNCH();
   if (gamma != nullptr) {
-    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, G * H, A);
+    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, G * H * wph, A);
     FIL_CHECK_LAUNCH();
   }
   return FIL_OK;

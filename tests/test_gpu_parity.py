@@ -91,6 +91,93 @@ def test_cin_wide_dynamic_range(mode):
         check("wide dW%d" % l, Ws[l].grad, dWs[l], tol=2e-5)
 
 
+def _cin_run(c, mode, with_grad=True):
+    from ml_function_amd import functional as Fn
+    x = dev(c["x"]).requires_grad_()
+    Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+    bs = [dev(b) for b in c["bs"]]
+    out = Fn.cin(x, Ws, bs, dev(c["dense_w"]), dev(c["dense_b"]), output_dim=1, mode=mode)
+    if with_grad:
+        out.backward(dev(c["g"]))
+    return out.detach(), x.grad, [w.grad for w in Ws]
+
+
+# ---- tests that decide whether the split-bf16 mode may ever be promoted: dynamic range, subnormals,
+# ---- non-finite inputs.  What they pin down is stated in DESIGN.md section 4.1 ("promotion tests").
+@pytest.mark.parametrize("mode", [0, 2, 10])
+@pytest.mark.parametrize("exp10", [-9, -6, -3, 3, 5])
+def test_cin_split_promotion_magnitudes(mode, exp10):
+    """Inputs scaled by 10^e (per-field spread of three more decades on top): the feature maps then sit at ~10^(2e), 10^(3e)
+    (degree 2, 3, 4 in x) -- 1e-36..1e+30 across the parametrisation, the widest range whose exact result stays inside fp32.  A bf16 piece keeps fp32's exponent range, and the third piece of a value v is
+    ~2^-16 |v|, so the split holds the exact mode's bar while |v| 2^-16 stays a normal number (|v| >~ 1e-33).  Mode 10 runs
+    the split kernels for the first layer as well (no pair symmetry)."""
+    B, F, K, conv = 40, 39, 16, [128, 128, 128]
+    c = synth.cin_case(B, F, K, conv, dist="normal")
+    rng = np.random.default_rng(5)
+    c["x"] = (c["x"] * 10.0 ** exp10 * 10.0 ** rng.uniform(-1.5, 1.5, size=(1, F, 1))).astype(np.float32)
+    out, dx, dWs = _cin_run(c, mode)
+    want = closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"], 1)
+    gx, gWs, _, _, _ = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"], 1)
+    check("magnitude 1e%d out" % exp10, out, want, tol=1e-5)
+    check("magnitude 1e%d dx" % exp10, dx, gx, tol=2e-5)
+    for l in range(3):
+        check("magnitude 1e%d dW%d" % (exp10, l), dWs[l], gWs[l], tol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 10])
+def test_cin_split_promotion_subnormal_inputs(mode):
+    """Every third field holds fp32 subnormals (1e-39..1e-44), the rest ordinary values: the subnormal fields' products are
+    far below the others' rounding error, so both modes must still meet the bar; and a batch of ONLY subnormals gives the
+    bias-only answer (finite, equal to the oracle's at the bar) in both."""
+    B, F, K, conv = 24, 12, 8, [32, 48, 16]
+    c = synth.cin_case(B, F, K, conv, dist="normal")
+    rng = np.random.default_rng(6)
+    tiny = (10.0 ** rng.uniform(-44, -39, size=(B, F, K)) * np.sign(c["x"])).astype(np.float32)
+    assert (np.abs(tiny[tiny != 0]) < np.finfo(np.float32).tiny).all()
+    mixed = c["x"].copy()
+    mixed[:, ::3, :] = tiny[:, ::3, :]
+    for name, xin in (("mixed", mixed), ("all-subnormal", tiny)):
+        cc = dict(c, x=xin)
+        out, dx, dWs = _cin_run(cc, mode)
+        assert torch.isfinite(out).all() and torch.isfinite(dx).all()
+        check("subnormal %s out" % name, out, closed.cin_fwd(xin, c["Ws"], c["bs"], c["dense_w"], c["dense_b"], 1), tol=1e-5)
+        if name == "mixed":
+            gx, gWs, _, _, _ = closed.cin_bwd(xin, c["Ws"], c["bs"], c["dense_w"], c["g"], 1)
+            # gradient entries of the subnormal fields are tiny but not zero; the norm-relative bar covers the tensor
+            check("subnormal dx", dx, gx, tol=2e-5)
+            for l in range(3):
+                check("subnormal dW%d" % l, dWs[l], gWs[l], tol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [2, 10])
+def test_cin_split_promotion_nonfinite(mode):
+    """+-inf / NaN in single samples.  What is identical to the exact mode: WHICH outputs and gradient rows are non-finite
+    (a bad sample poisons its own output and dx rows and the weight gradients, nothing else), and every finite entry still
+    meets the bar.  What is NOT: the exact mode can return +-inf where the split returns NaN (inf = bf16 inf + (inf - inf),
+    and an exact zero second piece of the other operand gives inf * 0) -- one documented reason the mode stays opt-in."""
+    B, F, K, conv = 16, 10, 8, [32, 32, 16]
+    c = synth.cin_case(B, F, K, conv, dist="normal")
+    bad = c["x"].copy()
+    bad[3, 2, 1] = np.inf
+    bad[7, 0, 5] = -np.inf
+    bad[11, 4, 0] = np.nan
+    cc = dict(c, x=bad)
+    out0, dx0, dW0 = _cin_run(cc, mode & 8)        # exact kernels with the same first-layer form
+    out2, dx2, dW2 = _cin_run(cc, mode)
+    assert torch.equal(torch.isfinite(out0), torch.isfinite(out2))
+    assert torch.equal(torch.isfinite(dx0), torch.isfinite(dx2))
+    for a, b in zip(dW0, dW2):
+        assert torch.equal(torch.isfinite(a), torch.isfinite(b))
+    bad_rows = [3, 7, 11]
+    fin = torch.isfinite(out2).reshape(-1).cpu().numpy()
+    assert not fin[bad_rows].any() and fin[[i for i in range(B) if i not in bad_rows]].all()
+    # the good samples are untouched by their neighbours: same values as a run without the bad ones
+    good = [i for i in range(B) if i not in bad_rows]
+    cg = dict(c, x=c["x"][good], g=c["g"][good])
+    outg, dxg, _ = _cin_run(cg, mode)
+    assert torch.equal(out2[good], outg) and torch.equal(dx2[good], dxg)
+
+
 def test_cin_large_batch_rows_beyond_2_pow_21():
     """B*K = 2.4 M rows (the dW kernel's buffer descriptors used to span the whole tensor: 2^21 rows at most).
     Size-independent checks: the first samples equal a small run bit for bit (batch independence), and the weight
@@ -548,6 +635,27 @@ def test_attn_f16_mfma_mode(B, F, K, H, A, fused):
         (av32.sum() + (res32 * res32).sum()).backward()
         for name, a, b in zip(["dx", "dWq", "dWk", "dWr"], g16, [t[n].grad for n in ["x", "Wq", "Wk", "Wr"]]):
             check("attn f16 unfused " + name, a, b.detach().cpu().numpy(), tol=2e-2)
+
+
+@pytest.mark.parametrize("B,F,K,H,A,precision", [(2, 200, 64, 4, 16, "f32"), (3, 170, 16, 4, 16, "f32"), (5, 200, 64, 4, 16, "f16_mfma"),
+                                                  (2, 190, 64, 4, 16, "f16_mfma"), (3, 170, 64, 4, 16, "f16_mfma")])
+def test_attn_two_waves_per_head(B, F, K, H, A, precision):
+    """Shapes whose LDS footprint lets one workgroup per CU only: the backward then runs two waves per head over alternate
+    query blocks (odd and even block counts, more workgroups than samples).  The f32 cases hold the strict bar, so they
+    pin the block/job bookkeeping the f16 instantiations share."""
+    from ml_function_amd import functional as Fn
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    beta = (c["beta"] + (6.0 if precision != "f32" else 0.0)).astype(np.float32)     # f16: keep outputs off the ReLU kink
+    t = {n: dev(c[n]).requires_grad_() for n in ["x", "Wq", "Wk", "Wr", "gamma"]}
+    tb = dev(beta).requires_grad_()
+    y = Fn.autoint_interact(t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], tb, precision=precision)
+    ty, tg = (1e-5, 2e-5) if precision == "f32" else (5e-3, 2e-2)
+    check("attn wph2 y", y, closed.attn_fwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], beta, use_res=True, use_ln=True), tol=ty)
+    y.backward(dev(c["dy"]))
+    grads = closed.attn_bwd(c["x"], c["Wq"], c["Wk"], c["Wr"], c["gamma"], beta, c["dy"], use_res=True, use_ln=True)
+    for n, got, want in zip(["x", "Wq", "Wk", "Wr", "gamma", "beta"],
+                            [t["x"].grad, t["Wq"].grad, t["Wk"].grad, t["Wr"].grad, t["gamma"].grad, tb.grad], grads):
+        check("attn wph2 d" + n, got, want, tol=tg)
 
 
 @pytest.mark.parametrize("B,F,Hp,Ap,H,A", [(3, 39, 3, 8, 2, 8), (2, 200, 4, 16, 4, 16), (2, 21, 2, 5, 3, 4)])
