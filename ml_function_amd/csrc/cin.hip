@@ -166,6 +166,7 @@ static size_t wf_floats(const CinShape& s) {
     w = std::max(w, (size_t)chunks_of(s.H[l]) * s.Hp(l) * 2 * s.JT() * 128);
     w = std::max(w, cin_wb_floats(s.Hp(l), s.JT(), chunks_of(s.H[l])));   // split-bf16 planes (mode bit 1)
   }
+  w = std::max(w, cin_wb_sym_floats(s.F, cin_jt_sym(s.F), chunks_of(s.H[0])));   // ... of the pair-symmetric first layer
   return w + (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
 }
 static int dz_periods(const CinShape& s, int l) { return cdiv(s.Hp(l), cin_dz_h_per_period(s.JT())); }
@@ -300,10 +301,17 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       if (l == 0 && tune.sym) {
         // first layer: x^{l-1} = x, reduce over unordered field pairs (half the steps)
         const int JTs = cin_jt_sym(F);
-        const long npack = (long)chunks * F * 2 * JTs * 128;
-        hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
+        if (split) {
+          const int hps = cin_sym_hps(JTs);
+          const long nvec = (long)cin_wb_sym_floats(F, JTs, chunks) / 4;
+          hipLaunchKernelGGL(cin_pack_wb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
+                             reinterpret_cast<bf16x8*>(Wf), F, F, Hl, JTs, (F + hps - 1) / hps, chunks, 1, hps);
+        } else {
+          const long npack = (long)chunks * F * 2 * JTs * 128;
+          hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
+        }
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
-        cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl);
+        cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl, split);
       } else {
         long npack = (long)chunks * Hp * 2 * JT * 128;
         if (split) {

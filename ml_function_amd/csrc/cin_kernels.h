@@ -163,9 +163,13 @@ __device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[3], const bf16x8 
 // JT/2 groups (even, JT being a multiple of 4: the kernel double-buffers groups).  Group gg of super-period sp, element e: step s = 8*gg + e,
 // h = 4*sp + s / JT, j = s % JT, f = 2j + half.  Layout [chunk][sp][gg][plane][nb][lane 64][8 bf16]: one aligned
 // 16-byte load per (group, plane, nb) and lane; lane r owns columns 4r..4r+3 (nb) of the chunk.
+//
+// sym (pair-symmetric first layer, Hp = F): the super-period holds hps = 4 or 8 values of h (8 when JT is not a multiple of 4,
+// so that the group count stays even), step (h, j) of lane half `half` is the pair (h, f = (h + d) mod F), d = 2j + half, and
+// carries the pair weight of cin_pack_wf_sym_kernel (W[(h,h)]; W[(h,f)] + W[(f,h)], halved at 2d == F; zero for d > F/2).
 static __global__ __launch_bounds__(256) void cin_pack_wb_kernel(const float* __restrict__ W, bf16x8* __restrict__ Wb, int Hp, int F, int H,
-                                                          int JT, int nsp, int chunks) {
-  const int ngs = JT / 2;  // groups per super-period
+                                                          int JT, int nsp, int chunks, int sym = 0, int hps = 4) {
+  const int ngs = hps * JT / 8;  // groups per super-period
   const long total = (long)chunks * nsp * ngs * 12 * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -183,9 +187,22 @@ static __global__ __launch_bounds__(256) void cin_pack_wb_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int s = 8 * gg + e;
-      const int h = 4 * sp + s / JT, j = s % JT;
+      const int h = hps * sp + s / JT, j = s % JT;
       const int f = 2 * j + half;
-      const float w = (h < Hp && f < F && n < H) ? W[((long)h * F + f) * H + n] : 0.f;
+      float w = 0.f;
+      if (sym) {
+        const int d = f;
+        if (h < F && n < H && d <= F / 2) {
+          const int fp = (h + d) % F;
+          if (d == 0) w = W[((long)h * F + h) * H + n];
+          else {
+            w = W[((long)h * F + fp) * H + n] + W[((long)fp * F + h) * H + n];
+            if (2 * d == F) w *= 0.5f;
+          }
+        }
+      } else {
+        w = (h < Hp && f < F && n < H) ? W[((long)h * F + f) * H + n] : 0.f;
+      }
       const __bf16 h1 = (__bf16)w;
       const float r1 = w - (float)h1;
       const __bf16 h2 = (__bf16)r1;
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   if (wrow0 >= M) return;  // whole wave past the end (no barriers in this kernel)
   long mq[MB];
   bool vq[MB];
-  float xr[MB][JT];
+  float xr[MB][JT];   // (unused by the SYM + SPLIT form: it keeps a sliding window instead)
   float xn[SYM ? MB : 1][SYM ? JT : 1];
   int d0[SYM ? JT : 1];  // (2j + half) mod F
   if constexpr (SYM) {
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
       }
     }
   }
-  if constexpr (SYM) {
+  if constexpr (SYM && !SPLIT) {
     load_x(0, xn);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -274,8 +291,105 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
-  if constexpr (SPLIT) {
-    static_assert(!SYM, "the split-bf16 loop is for the general layers");
+  if constexpr (SPLIT && SYM) {
+    // Pair-symmetric first layer on split-bf16 operands.  Step (h, j) of a lane multiplies x[m,h] by x[m,(h + 2j + half) mod F]:
+    // the second factor moves with h, so the lane keeps a sliding window wl[t] = x[m,(h0 + half + t) mod F] over the
+    // super-period's HPS values of h (h0 = HPS*sp); the next super-period's window is this one shifted by HPS, i.e. HPS
+    // new values per super-period, fetched one super-period ahead together with the next x[m,h] values.
+    constexpr int HPS = JT % 4 == 0 ? 4 : 8;   // h per super-period (an even number of 8-step groups)
+    constexpr int NGS = HPS * JT / 8;
+    constexpr int WS = HPS + 2 * JT - 2;       // window length: t = u + 2j, u < HPS, j < JT
+    static_assert(NGS % 2 == 0 && JT % 2 == 0, "groups per super-period must be even");
+    const int nsp = (F + HPS - 1) / HPS;
+    const long chunk_bytes = (long)nsp * NGS * 12 * 1024;
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wf) + (long)chunk * (chunk_bytes >> 2), 0, (int)chunk_bytes, 0x00020000);
+    const int vo = lane * 16;
+    u32x4 bb[2][12];
+    auto fetch_group = [&](int grp, u32x4 (&dst)[12]) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (grp * 12 + i) * 1024, 0));
+    };
+    fetch_group(0, bb[0]);
+    const float* xrow[MB];
+    float wl[MB][WS], wnew[MB][HPS], xph[MB][HPS], xpn[MB][HPS];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      xrow[mb] = xT + mq[mb] * F;
+#pragma unroll
+      for (int t = 0; t < WS; ++t) wl[mb][t] = xrow[mb][(half + t) % F];
+#pragma unroll
+      for (int u = 0; u < HPS; ++u) xph[mb][u] = xrow[mb][u % F];
+    }
+    auto make_a = [&](const float (&xp)[MB][HPS], const float (&win)[MB][WS], int gg, int mb, bf16x8 (&a)[3]) {
+      float p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int st = 8 * gg + e;  // compile-time
+        p[e] = xp[mb][st / JT] * win[mb][st / JT + 2 * (st % JT)];
+      }
+      split3(p, a[0], a[1], a[2]);
+    };
+    bf16x8 acur[3], anext[3];
+    make_a(xph, wl, 0, 0, acur);
+#pragma unroll 1
+    for (int sp = 0; sp < nsp; ++sp) {
+      // next super-period: x[m, h0' + u] and the HPS window entries that slide in (h >= F steps meet zero weights)
+      const int h1 = HPS * (sp + 1);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int u = 0; u < HPS; ++u) {
+          xpn[mb][u] = xrow[mb][(h1 + u) % F];
+          wnew[mb][u] = xrow[mb][(h1 + half + WS - HPS + u) % F];
+        }
+#pragma unroll
+      for (int gg = 0; gg < NGS; ++gg) {
+        fetch_group(sp * NGS + gg + 1, bb[(gg + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 b[4][3];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bb[gg & 1][pl * 4 + nb]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          if (mb + 1 < MB) make_a(xph, wl, gg, mb + 1, anext);
+          else if (gg + 1 < NGS) make_a(xph, wl, gg + 1, 0, anext);
+          else {
+            // first unit of the next super-period: its window is this one shifted by HPS (entries beyond it: wnew)
+            float p[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int t = e / JT + 2 * (e % JT) + HPS;   // compile-time; e < 8 <= steps of the first group
+              p[e] = xpn[0][e / JT] * (t < WS ? wl[0][t < WS ? t : 0] : wnew[0][t >= WS ? t - WS : 0]);
+            }
+            split3(p, anext[0], anext[1], anext[2]);
+          }
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma_split(acur, b[nb], acc[mb][nb]);
+#pragma unroll
+          for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU behind it
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) acur[pl] = anext[pl];
+        }
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int t = 0; t + HPS < WS; ++t) wl[mb][t] = wl[mb][t + HPS];
+#pragma unroll
+        for (int u = 0; u < HPS; ++u) {
+          wl[mb][WS - HPS + u] = wnew[mb][u];
+          xph[mb][u] = xpn[mb][u];
+        }
+      }
+    }
+  } else if constexpr (SPLIT) {
     static_assert(JT % 4 == 0, "groups per super-period must be even");
     constexpr int NGS = JT / 2;  // groups of 8 steps per super-period of 4 h
     const int nsp = (Hp + 3) >> 2;

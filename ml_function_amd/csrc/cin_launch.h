@@ -11,7 +11,14 @@ inline int cin_jt_of(int F) { return ((F + 1) / 2 + 3) / 4 * 4; }
 inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
 
 void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT,
-                         int HS, float* pool_part, int M, int F, int H);
+                         int HS, float* pool_part, int M, int F, int H, bool split = false);
+
+// split-bf16 form of the symmetric first layer: h per super-period, and floats of its packed weight planes
+inline int cin_sym_hps(int JTs) { return JTs % 4 == 0 ? 4 : 8; }
+inline size_t cin_wb_sym_floats(int F, int JTs, int chunks) {
+  const int hps = cin_sym_hps(JTs);
+  return (size_t)chunks * ((F + hps - 1) / hps) * (hps * JTs / 8) * 12 * 256;
+}
 
 // wsn != nullptr: also sum-pool the next (last, mode 0) layer in the epilogue -> pool_next (see cin_fwd3_kernel)
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,

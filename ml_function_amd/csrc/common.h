@@ -34,15 +34,22 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 bool prof_enabled();
 bool prof_begin_scope(const char* name, hipStream_t st, double work);
 void prof_end_scope(hipStream_t st);
+// roctx ranges around the same scopes (host-side push/pop; `rocprofv3 --marker-trace --kernel-trace` shows which launches
+// belong to which step of the layer).  Off unless FIL_ROCTX=1 was set when the library was loaded (read once).
+bool roctx_enabled();
+void roctx_push(const char* name);
+void roctx_pop();
 struct ProfScope {
   hipStream_t st;
-  bool on;
+  bool on, rx;
   // work = algorithmic flops (MFMA kernels) or bytes (streaming kernels) of this launch, reported back verbatim
-  ProfScope(const char* name, hipStream_t s, double work = 0.0) : st(s), on(prof_enabled()) {
+  ProfScope(const char* name, hipStream_t s, double work = 0.0) : st(s), on(prof_enabled()), rx(roctx_enabled()) {
+    if (rx) roctx_push(name);
     if (on) on = prof_begin_scope(name, st, work);
   }
   ~ProfScope() {
     if (on) prof_end_scope(st);
+    if (rx) roctx_pop();
   }
 };
 

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include <string.h>
+#include <dlfcn.h>
 
 #include <mutex>
 #include <string>
@@ -89,6 +90,35 @@ void prof_end_scope(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
 }
+
+// ---- roctx ranges (opt-in, FIL_ROCTX=1): the marker library is looked up at run time so that libfil_hip.so does not link it
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+};
+static const Roctx& roctx() {
+  static const Roctx r = [] {
+    Roctx x;
+    const char* e = getenv("FIL_ROCTX");
+    if (e == nullptr || atoi(e) == 0) return x;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (h == nullptr) continue;
+      x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (x.push != nullptr && x.pop != nullptr) {
+        x.on = true;
+        break;
+      }
+    }
+    return x;
+  }();
+  return r;
+}
+bool roctx_enabled() { return roctx().on; }
+void roctx_push(const char* name) { (void)roctx().push(name); }
+void roctx_pop() { (void)roctx().pop(); }
 
 }  // namespace fil
 

@@ -850,3 +850,25 @@ def test_cin_step_is_hipgraph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(out_g, out_e)
     assert torch.equal(gr_g["dx"], gr_e["dx"]) and all(torch.equal(a, b) for a, b in zip(gr_g["dW"], gr_e["dW"]))
+
+
+def test_roctx_ranges_opt_in():
+    """FIL_ROCTX=1 (read when the library loads) wraps every profiled scope in a roctx range; the marker library is looked
+    up with dlopen.  Without a profiler attached the ranges are no-ops: the layer must run and give the same numbers."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, numpy as np\n"
+            "from ml_function_amd import functional as Fn, synth\n"
+            "c = synth.cin_case(8, 6, 4, [8, 8], dist='uniform')\n"
+            "d = lambda a: torch.tensor(a, device='cuda')\n"
+            "out = Fn.cin(d(c['x']), [d(w) for w in c['Ws']], [d(b) for b in c['bs']], d(c['dense_w']), d(c['dense_b']), output_dim=1)\n"
+            "print('%.9e' % float(out.double().sum()))\n")
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, FIL_ROCTX=flag)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
