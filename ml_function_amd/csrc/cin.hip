@@ -360,7 +360,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
   if (mode < 0 || mode > 15) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM)", mode);
-  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (general layers l >= 1; the pair-symmetric first layer and the last-layer shortcut stay exact fp32)
+  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
@@ -499,14 +499,14 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const int Cl = symD > 0 ? F * symD : Hp * F;
     {
       ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl));
-      if (split && symD == 0) {
+      if (split) {
         // opt-in split-bf16 GEMM: G re-laid as three bf16 planes (inside the scope: it is part of this GEMM's cost)
-        const long nvec = ((M + 15) / 16) * (HSl / 128) * 12 * 64;
-        hipLaunchKernelGGL(cin_split_g_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 8192)), dim3(256), 0, st, G, HSl, Gb, (int)M, Hl);
+        const long nthr = ((M + 15) / 16) * (HSl / 128) * 64;
+        hipLaunchKernelGGL(cin_split_g_kernel, dim3((int)std::min<long>((nthr + 255) / 256, 8192)), dim3(256), 0, st, G, HSl, Gb, (int)M, Hl);
         const DwPlan p = dw_plan(M, Cl, Hl);
         const int items = p.blocks_x * p.splits * p.chunks;
         hipLaunchKernelGGL(cin_dw3b_kernel, dim3((items + 7) / 8 * 8), dim3(kCinThreads), 0, st, Gb, xT, xpT, xps, part, (int)M, F, Hp, Hl,
-                           p.rows_per_split, p.blocks_x, p.chunks, items);
+                           p.rows_per_split, p.blocks_x, p.chunks, items, symD);
         parts = p.splits;
       } else {
         parts = launch_dw3(st, dw_plan(M, Cl, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl, symD);
@@ -539,9 +539,16 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
         const int periods = cdiv(F, cin_dz_h_per_period(JTs));
         const int tiles = periods * cin_dz_tiles_per_period(JTs) + 1;
         const long npack = (long)tiles * 32 * HSl;
-        hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
+        const int MBs = split ? MBg : MB;
+        if (split) {
+          const long nvec = (long)tiles * (HSl / 16) * 3 * 64;
+          hipLaunchKernelGGL(cin_pack_wzb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
+                             reinterpret_cast<bf16x8*>(Wz), F, F, Hl, JTs, HSl, tiles, 1);
+        } else {
+          hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
+        }
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
-        cin_launch_dz3_sym(st, MB, JTs, NHMAX, dim3(cdiv((int)M, 128 * MB)), G, HSl, Wz, xT, gx0T, dxT, dx_started ? 1 : 0, (int)M, F, Hl, periods);
+        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(cdiv((int)M, 128 * MBs)), G, HSl, Wz, xT, gx0T, dxT, dx_started ? 1 : 0, (int)M, F, Hl, periods, split);
       } else {
         const int periods = dz_periods(s, l);
         const int tiles = periods * cin_dz_tiles_per_period(JT) + 1;

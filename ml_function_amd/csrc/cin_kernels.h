@@ -632,8 +632,9 @@ static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float
 
 // Split-bf16 form of Wz: [(tile*NT + t)*3 + plane][lane 64][8 bf16], NT = NCOL/16.  Element e of lane (r, half) is the
 // plane of Wz[tile][row r][col = half*NCOL/2 + 8t + e] (rows and columns as in cin_pack_wz_kernel).
+// sym: the pair weights of cin_pack_wz_sym_kernel (slot (h, j), parity hf <-> pair (h, (h + 2j + hf) mod F)).
 static __global__ __launch_bounds__(256) void cin_pack_wzb_kernel(const float* __restrict__ W, bf16x8* __restrict__ Wzb, int Hp, int F, int H,
-                                                           int JT, int NCOL, int tiles) {
+                                                           int JT, int NCOL, int tiles, int sym = 0) {
   const int NT = NCOL / 16;
   const long total = (long)tiles * NT * 3 * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -652,7 +653,20 @@ static __global__ __launch_bounds__(256) void cin_pack_wzb_kernel(const float* _
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int col = half * (NCOL / 2) + 8 * t + e;
-      const float w = (h < Hp && f < F && col < H) ? W[((long)h * F + f) * H + col] : 0.f;
+      float w = 0.f;
+      if (sym) {
+        const int d = f;
+        if (h < F && d <= F / 2 && col < H) {
+          const int fp = (h + d) % F;
+          if (d == 0) w = W[((long)h * F + h) * H + col];
+          else {
+            w = W[((long)h * F + fp) * H + col] + W[((long)fp * F + h) * H + col];
+            if (2 * d == F) w *= 0.5f;
+          }
+        }
+      } else {
+        w = (h < Hp && f < F && col < H) ? W[((long)h * F + f) * H + col] : 0.f;
+      }
       const __bf16 h1 = (__bf16)w;
       const float r1 = w - (float)h1;
       const __bf16 h2 = (__bf16)r1;
@@ -1069,33 +1083,41 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
 // ---- split-bf16 dW (opt-in, general layers; see the split-bf16 notes above the forward kernel) ---------------------
 // Gb = G as three bf16 planes in the B-operand layout of v_mfma_f32_32x32x16_bf16 with the reduction over rows:
 // [chunk][row block of 16][plane][nb][lane 64][8 bf16]; element e of lane (r, half) = G[16*blk + 8*half + e][chunk*128 + 4r + nb].
+// One thread per (row block, wave half, r): eight 16-byte row reads (a half wave covers whole 512-byte rows), twelve
+// 16-byte plane stores (64 lanes = 1 KiB contiguous each).
 static __global__ __launch_bounds__(256) void cin_split_g_kernel(const float* __restrict__ gT, int HS, bf16x8* __restrict__ Gb, int M, int H) {
   const int chunks = HS >> 7;
   const long nblk = ((long)M + 15) >> 4;
-  const long total = (long)chunks * nblk * 12 * 64;
+  const long total = (long)chunks * nblk * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
-    long t = idx >> 6;
-    const int nb = (int)(t & 3);
-    t >>= 2;
-    const int plane = (int)(t % 3);
-    t /= 3;
+    const long t = idx >> 6;
     const long blk = t % nblk;
     const int chunk = (int)(t / nblk);
     const int r = lane & 31, half = lane >> 5;
-    const int n = chunk * 128 + 4 * r + nb;
-    bf16x8 out;
+    const int n = chunk * 128 + 4 * r;
+    float g[8][4];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const long m = blk * 16 + 8 * half + e;
-      const float g = (m < M && n < H) ? gT[m * HS + n] : 0.f;
-      const __bf16 h1 = (__bf16)g;
-      const float r1 = g - (float)h1;
-      const __bf16 h2 = (__bf16)r1;
-      const __bf16 h3 = (__bf16)(r1 - (float)h2);
-      out[e] = plane == 0 ? h1 : (plane == 1 ? h2 : h3);
+      const float4 v = m < M ? *reinterpret_cast<const float4*>(gT + m * HS + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      g[e][0] = n + 0 < H ? v.x : 0.f;
+      g[e][1] = n + 1 < H ? v.y : 0.f;
+      g[e][2] = n + 2 < H ? v.z : 0.f;
+      g[e][3] = n + 3 < H ? v.w : 0.f;
     }
-    Gb[idx] = out;
+    bf16x8* dst = Gb + ((long)chunk * nblk + blk) * 12 * 64 + lane;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      float p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p[e] = g[e][nb];
+      bf16x8 a1, a2, a3;
+      split3(p, a1, a2, a3);
+      dst[(0 * 4 + nb) * 64] = a1;
+      dst[(1 * 4 + nb) * 64] = a2;
+      dst[(2 * 4 + nb) * 64] = a3;
+    }
   }
 }
 
@@ -1105,10 +1127,11 @@ static __global__ __launch_bounds__(256) void cin_split_g_kernel(const float* __
 // their MFMAs), and reads the 12 plane vectors of Gb (fetched one block ahead): 24 bf16 MFMAs per block.
 static __global__ __launch_bounds__(256, 2) void cin_dw3b_kernel(const bf16x8* __restrict__ Gb, const float* __restrict__ xT,
                                                            const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
-                                                           int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items) {
+                                                           int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items,
+                                                           int symD) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  const int C = Hp * F;
+  const int C = symD > 0 ? F * symD : Hp * F;   // symD > 0: unordered pairs c = h*symD + d <-> (h, (h+d) mod F), as in cin_dw3_kernel
   const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware, as in cin_dw3_kernel
   if (item >= items) return;
   const int bx = item % blocks_x;
@@ -1128,7 +1151,8 @@ static __global__ __launch_bounds__(256, 2) void cin_dw3b_kernel(const bf16x8* _
   const int c = c0 + r;
   const bool cv = c < C;
   const int cc = cv ? c : C - 1;
-  const int hh = cc / F, ff = cc - hh * F;
+  const int hh = symD > 0 ? cc / symD : cc / F;
+  const int ff = symD > 0 ? (hh + (cc - hh * symD)) % F : cc - hh * F;
   const int ho = (8 * half * xps + hh) * 4, fo = (8 * half * F + ff) * 4;  // byte offsets of the lane's first row inside a block
   const int vo = lane * 16;
 

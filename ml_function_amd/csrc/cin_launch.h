@@ -39,7 +39,7 @@ void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* 
 
 // symmetric first layer (x^{l-1} = x); FR = field rows of the LDS scratch (see cin_dz_sym_rows)
 void cin_launch_dz3_sym(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
-                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods);
+                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods, bool split = false);
 
 // tiles per period / h per period of the dZ kernel for a given JT (mirrors the constexprs in cin_dz3_kernel)
 inline int cin_gcd(int a, int b) { return b == 0 ? a : cin_gcd(b, a % b); }
