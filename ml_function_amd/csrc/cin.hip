@@ -257,6 +257,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && W && bias && pooled && saved);
   FIL_CHECK_ARG(output_dim != 1 || (dense_w && dense_b && out));
+  // (the same limit as the backward's head kernel: a forward that succeeds must have a backward that can run)
+  if (output_dim == 1 && (size_t)L * K + 1 > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: L*K=%zu > 255", (size_t)L * K);
   if (workspace == nullptr || workspace_bytes < fwd_ws_bytes(s))
     return fail(FIL_ERR_WORKSPACE, "fil_cin_fwd: workspace %zu < %zu bytes", workspace_bytes, fwd_ws_bytes(s));
   hipStream_t st = (hipStream_t)stream;
@@ -531,7 +533,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const int MB = NHMAX == 128 ? 1 : tune.mb_rows(M);      // pair-symmetric first layer: 64 rows per wave measured best
       // general dZ kernel: 32 rows per wave, two waves per SIMD -- the second wave covers the issue time of the first
       // one's register contraction (c4: 0.715 -> 0.687 ms exact fp32, 0.436 -> 0.420 split-bf16); FIL_CIN_DZ_MB overrides
-      const int MBg = NHMAX == 128 ? 1 : (knobs().dz_mb == 2 ? 2 : 1);
+      const int MBg = NHMAX == 128 ? 1 : ((knobs().dz_mb == 2 && JT <= 28) ? 2 : 1);   // (JT = 32 at 64 rows: scratch + line buffers > 160 KB of LDS)
       const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
       if (l == 0 && tune.sym && F >= 2) {
         // first layer over unordered field pairs (half the tiles); F = 1 would make both lane halves hit one word

@@ -8,8 +8,8 @@ template <int MB, int JT, int NHMAX, bool SPLIT>
 static void dz3(hipStream_t st, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT, const float* xpT, int xps,
                 const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT, int accumulate, int M, int F,
                 int Hp, int H, int periods) {
-  // per-lane LDS scratch: x fragment + dX accumulators, [2][MB][JT][256] floats
-  const size_t sh = (size_t)2 * MB * JT * 256 * sizeof(float);
+  // per-lane LDS scratch: x fragment + dX accumulators, [2][MB][JT][256] floats, + the G^{l-1} line buffers [4 waves][MB][32][kGlStride]
+  const size_t sh = ((size_t)2 * MB * JT * 256 + (size_t)4 * MB * 32 * kGlStride) * sizeof(float);
   if (sh > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_dz3_kernel<MB, JT, NHMAX, false, SPLIT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

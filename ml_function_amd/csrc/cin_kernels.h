@@ -693,13 +693,21 @@ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 // shared by the two lane halves of a row -- within one instruction the halves touch f and f+1, never the same word).
 //   gx      += dZ * x[m,f]  -> Gx[m,h]  (gx0T)        dxs[f] += dZ * x[m,h]  -> dX[m,f]   (summed by transpose_out)
 constexpr int kSymStride = 160;  // 4 waves x 32 rows + 32: consecutive f land in opposite bank halves
+// G^{l-1} leaves through a per-wave LDS line buffer [32 rows][kGlStride]: a lane completes HPP consecutive columns of its
+// row at a time, and storing those directly is a 4-16 byte write at a 512-byte row stride -- every 128-byte line of G^{l-1}
+// is then written in 8-32 pieces spread over the whole kernel, L2 evicts it half-filled and the fabric sees read-modify-write
+// traffic (PMC round 1: 187 MB read / 147 MB written per launch against 98 / 44 algorithmic).  The buffer collects 32 columns
+// per row and the wave flushes whole 128-byte lines (8 lanes x 16 bytes per row).
+constexpr int kGlStride = 36;    // floats per buffered row: 16-byte aligned, rows 36 banks apart
 
 //
 // SPLIT (opt-in, general layers): dZ^T = W G^T on split-bf16 operands -- Wz then points to the three bf16 planes of the
 // slot-ordered weights (cin_pack_wzb_kernel), the lane's G row is split once into planes, and a tile is NHMAX/8 steps
 // of 6 bf16 MFMAs per row block (accumulator layout, slot order and the register contraction are unchanged).
+// (exact general kernel at 32 rows per wave, H <= 128: two waves per SIMD are part of the design -- the register budget is held
+// to 256; the split forms sit just below it on their own and schedule better without the cap)
 template <int MB, int JT, int NHMAX, bool SYM = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
+__global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2 : 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
                                                          const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                          const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
                                                          int HSp, float* __restrict__ gx0T, float* __restrict__ dxT, int accumulate,
@@ -717,6 +725,8 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   if (wrow0 >= M) return;
   float* xs = SYM ? smem + wave * 32 + r : smem + tid;                                    // xs[(mb*JT + j)*256]   | SYM: xs[(mb*FR + f)*kSymStride]
   float* dxs = SYM ? xs + MB * FR * kSymStride : smem + MB * JT * 256 + tid;              // dxs[(mb*JT + j)*256]  | SYM: same shape as xs
+  constexpr bool GLINE = !SYM;                                                             // (the first layer has no G^{l-1})
+  float* gl = smem + 2 * MB * JT * 256 + wave * (MB * 32 * kGlStride);                     // GLINE: [mb][row 32][kGlStride]
   long mq[MB];
   bool vq[MB];
   float greg[MB][NHMAX], dpp[MB];
@@ -838,7 +848,14 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
         // (single-dword stores at a row stride turn into one partial-line write each: 7x write amplification)
         gout[mb][hl] = lane_halves_sum(gx[mb]) + dpp[mb];
         gx[mb] = 0.f;
-        if (hl == HPP - 1 && half == 0 && vq[mb] && hb >= 0) {
+        if (GLINE && gvec) {
+          if (hl == HPP - 1 && half == 0 && hb >= 0) {
+            float* bl = gl + (mb * 32 + r) * kGlStride + (hb & 31);
+            if constexpr (HPP == 4) *reinterpret_cast<float4*>(bl) = make_float4(gout[mb][0], gout[mb][1], gout[mb][2], gout[mb][3]);
+            else if constexpr (HPP == 2) *reinterpret_cast<float2*>(bl) = make_float2(gout[mb][0], gout[mb][1]);
+            else bl[0] = gout[mb][0];
+          }
+        } else if (hl == HPP - 1 && half == 0 && vq[mb] && hb >= 0) {
           float* dst = gdst[mb] + hb;
           if (gvec && hb + HPP <= Hp) {
             if constexpr (HPP == 4) *reinterpret_cast<float4*>(dst) = make_float4(gout[mb][0], gout[mb][1], gout[mb][2], gout[mb][3]);
@@ -852,6 +869,26 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
         }
       }
     }
+  };
+  // whole lines of G^{l-1}: columns [32 line, 32 line + 32) of the wave's rows, 8 lanes x 16 bytes per row
+  auto flush_line = [&](int line) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 3, c4 = idx & 7;
+        const int m = wrow0 + mb * 32 + row, col = 32 * line + 4 * c4;
+        const float4 v = *reinterpret_cast<const float4*>(gl + (mb * 32 + row) * kGlStride + 4 * c4);
+        if (m < M && col < Hp) {
+          float* dst = GprevT + (long)m * HSp + col;
+          if (col + 3 < Hp) *reinterpret_cast<float4*>(dst) = v;
+          else {
+            dst[0] = v.x;
+            if (col + 1 < Hp) dst[1] = v.y;
+            if (col + 2 < Hp) dst[2] = v.z;
+          }
+        }
+      }
   };
   slot_fetch(hprev, P - 1, 0);
 
@@ -923,6 +960,10 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) dprev[mb] = d[mb];
+      // the previous period's values became complete behind this period's first tile: flush when they close a line
+      if constexpr (GLINE) {
+        if (tp == 0 && gvec && hprev >= 0 && ((hprev + HPP) & 31) == 0) flush_line(hprev >> 5);
+      }
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -935,6 +976,9 @@ __global__ __launch_bounds__(256, 1) void cin_dz3_kernel(const float* __restrict
   for (int rr = 0; rr < 16; ++rr) {
     slot_apply(dprev, xprev, hprev, P - 1, rr);
     if (rr < 15) slot_fetch(hprev, P - 1, rr + 1);
+  }
+  if constexpr (GLINE) {
+    if (gvec && hprev >= 0) flush_line(hprev >> 5);   // the last (possibly partial) line
   }
   // dX rows of the wave are contiguous in dxT ([32*MB rows][F]): written cooperatively from the LDS scratch so that
   // every store instruction covers whole lines (one lane per row element = a 156-byte stride = 8-16x write
