@@ -195,6 +195,7 @@ static size_t dw_part_floats(const CinShape& s) {
   const int csym = s.F * (s.F / 2 + 1);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
+  pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
   return pmax;
 }
 // bytes of G as three bf16 planes in row blocks of 16 (cin_split_g_kernel)
@@ -454,10 +455,16 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const int YS = (F + 3) & ~3;
       const long tot = M * YS;
       hipLaunchKernelGGL(cin_scale_rows3_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, xT, dPl, (int)LK, K, yT, (int)M, F, YS);
-      const DwPlan p = dw_plan(M, Hp, F);
-      const int nb = launch_dw3(st, p, yT, YS, nullptr, xpT, xps, part, M, /*F=*/1, Hp, /*H=*/F);
+      // l > 0: the roles are swapped -- the F fields of G' are the channel rows and x^{L-1} ([M][HS], 128-aligned rows) is the
+      // streamed right-hand side, so the kernel computes v^T [F][Hp]: 2 channel blocks x a full 128-column chunk instead of
+      // 4 blocks x a chunk that is 70 % padding (27 -> 14 us at c4); the fill kernel reads it transposed
+      const bool swap = l > 0;
+      int nb;
+      if (swap) nb = launch_dw3(st, dw_plan(M, F, Hp), xpT, xps, nullptr, yT, YS, part, M, /*F=*/1, /*Hp=*/F, /*H=*/Hp);
+      else nb = launch_dw3(st, dw_plan(M, Hp, F), yT, YS, nullptr, xpT, xps, part, M, /*F=*/1, Hp, /*H=*/F);
       hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)cl, 64)), dim3(256), 0, st, part, vlast, (long)cl, nb);
-      hipLaunchKernelGGL(cin_fill_rows_kernel, dim3((int)std::min<long>(((long)cl * Hl + 255) / 256, 2048)), dim3(256), 0, st, vlast, dW[l], (long)cl, Hl);
+      hipLaunchKernelGGL(cin_fill_rows_kernel, dim3((int)std::min<long>(((long)cl * Hl + 255) / 256, 2048)), dim3(256), 0, st, vlast, dW[l], (long)cl, Hl,
+                         swap ? F : 0, Hp);
     }
     ready(l);
     // G^{L-1} and dX

@@ -1536,10 +1536,14 @@ static __global__ __launch_bounds__(256) void cin_last_bwd_kernel(const float* _
   }
 }
 
-// dW[c,n] = v[c] for every n
-static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* __restrict__ v, float* __restrict__ dW, long C, int H) {
+// dW[c,n] = v[c] for every n;  Ft > 0: v arrives transposed, v^T [Ft][Hp], c = h*Ft + f
+static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* __restrict__ v, float* __restrict__ dW, long C, int H, int Ft,
+                                                            int Hp) {
   const long total = C * H;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dW[i] = v[i / H];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long c = i / H;
+    dW[i] = Ft > 0 ? v[(c % Ft) * Hp + c / Ft] : v[c];
+  }
 }
 
 // MFMA form of the last layer's data gradients (mode 0, L >= 2; the VALU kernel above stays for L == 1):
