@@ -31,6 +31,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // Makes the compiler wait HERE for any pending load of v (an empty asm that "uses" the register), so that no
 // s_waitcnt vmcnt(0) is placed later inside an MFMA loop, where it would also drain the prefetch just issued.
 __device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void settle(f32x4s& v) { asm volatile("" : "+v"(v)); }
 
 // #################################################################################################
 // v3 kernels: m-major internal layouts + LDS-free streaming GEMMs.
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     for (int mb = 0; mb < MB; ++mb) {
       xprow[mb] = xpT + mq[mb] * xps;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xph[mb][u] = u < Hp ? xprow[mb][u] : 0.f;
+      for (int u = 0; u < 4; ++u) xph[mb][u] = xprow[mb][min(u, Hp - 1)];   // (h >= Hp meets zero weights: any finite value)
     }
     // A operand of unit (gg, mb): the 8 products x^{l-1}[m,h] * x[m,f] of the group's steps, split into three bf16 planes
     auto make_a = [&](const float (&xp4)[MB][4], int gg, int mb, bf16x8 (&a)[3]) {
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xpn[mb][u] = 4 * (sp + 1) + u < Hp ? xprow[mb][4 * (sp + 1) + u] : 0.f;
+        for (int u = 0; u < 4; ++u) xpn[mb][u] = xprow[mb][min(4 * (sp + 1) + u, Hp - 1)];   // branch-free (see the fp32 loop)
 #pragma unroll
       for (int gg = 0; gg < NGS; ++gg) {
         fetch_group(sp * NGS + gg + 1, bb[(gg + 1) & 1]);
@@ -479,20 +481,29 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
       xpv[mb] = xprow[mb][0];
       xpn[mb] = 0.f;
     }
+    // Every prologue load is waited for HERE, once.  The compiler orders the prologue's loads as it likes; when the operand of
+    // the loop's first step is not the oldest of them, the wait count it derives for the top of the loop (the merge of "from
+    // the prologue" and "from the previous iteration") collapses to a few, i.e. it drains the whole operand queue at the top
+    // of every h: ~1,500 idle cycles per 10,240 cycles of MFMA work.  With nothing pending on entry the count at the loop top
+    // comes from the back edge alone (the 9 younger refills + this iteration's loads stay in flight).  A/B on one box, c4 l2:
+    // 0.659 -> 0.634 ms.
+  #pragma unroll
+    for (int d = 0; d < DEPTH; ++d) settle(q[d].x);
+  #pragma unroll
+    for (int mb = 0; mb < MB; ++mb) settle(xpv[mb]);
   #pragma unroll 1
     for (int h = 0; h < Hp; ++h) {
       const bool more = h + 1 < Hp;
+      // (branch-free: a conditional load makes the compiler's wait-count bookkeeping fall back to vmcnt(0) at the top of
+      // every h, which drains the whole operand queue once per h -- ~1,500 idle cycles against 10,240 of MFMA work)
   #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-        if (more) xpn[mb] = xprow[mb][h + 1];
+      for (int mb = 0; mb < MB; ++mb) xpn[mb] = xprow[mb][more ? h + 1 : h];
       if constexpr (SYM) load_x(more ? h + 1 : h, xn);
       const float4* wh = wbase + (long)h * (2 * JT) * 32;
       const float4* whn = wbase + (long)(more ? h + 1 : h) * (2 * JT) * 32;
   #pragma unroll
       for (int j = 0; j < JT; ++j) {
         const float4 w = q[j % DEPTH];
-        const int jn = j + DEPTH;  // refill this slot with the operand of step j + DEPTH (possibly in the next h)
-        q[j % DEPTH] = jn < JT ? wh[(long)(2 * jn) * 32] : whn[(long)(2 * (jn - JT)) * 32];
   #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const float a = xpv[mb] * xr[mb][j];
@@ -501,6 +512,12 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
           acc[mb][2] = mfma32(a, w.z, acc[mb][2]);
           acc[mb][3] = mfma32(a, w.w, acc[mb][3]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // refill this slot with the operand of step j + DEPTH (possibly in the next h) -- AFTER the step's MFMAs were issued,
+        // so the load may land in the registers it replaces: when JT == DEPTH every slot is refilled once per h and a refill
+        // into fresh registers has to be copied back at the end of the h iteration, which waits for ALL of them (vmcnt(0))
+        const int jn = j + DEPTH;
+        q[j % DEPTH] = jn < JT ? wh[(long)(2 * jn) * 32] : whn[(long)(2 * (jn - JT)) * 32];
         __builtin_amdgcn_sched_barrier(0);  // keep the refill load here (the scheduler would sink it to its use)
       }
   #pragma unroll
@@ -741,10 +758,15 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
         dxs[(mb * FR + f) * kSymStride] = 0.f;
       }
     } else {
+      // all JT loads first (unconditional, clamped, masked with an AND: see the per-period loads below), then the LDS writes:
+      // a conditional load per element is JT exposed load latencies in a row before the wave's first MFMA
+      float xt[JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) xt[j] = xT[mq[mb] * F + min(2 * j + half, F - 1)];
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
-        const int f = 2 * j + half;
-        xs[(mb * JT + j) * 256] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
+        const int keep = (vq[mb] && 2 * j + half < F) ? -1 : 0;
+        xs[(mb * JT + j) * 256] = __builtin_bit_cast(float, __builtin_bit_cast(int, xt[j]) & keep);
         dxs[(mb * JT + j) * 256] = 0.f;
       }
     }
@@ -898,7 +920,14 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int hl = 0; hl < HPP; ++hl) xcur[mb][hl] = (vq[mb] && hbase + hl < Hp) ? xpT[mq[mb] * xps + hbase + hl] : 0.f;
+      for (int hl = 0; hl < HPP; ++hl) {
+        // Unconditional load, masked with an AND.  A conditional load (and equally a select on a load, which the compiler
+        // turns back into a branch around the load) costs a branch + s_waitcnt vmcnt(0) per value at the top of every period:
+        // HPP exposed load latencies in a row, and the A-operand queue drained each time.
+        const float xv = xpT[mq[mb] * xps + min(hbase + hl, Hp - 1)];
+        const int keep = (vq[mb] && hbase + hl < Hp) ? -1 : 0;
+        xcur[mb][hl] = __builtin_bit_cast(float, __builtin_bit_cast(int, xv) & keep);
+      }
 #pragma unroll
     for (int tp = 0; tp < P; ++tp) {
       // the stream is allocated one tile past the last period, so the refill never leaves the buffer
@@ -1091,7 +1120,6 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
       const bool live = mlane + 2 * s < m_hi;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) a[mb] = (live && cv[mb]) ? qx[d][mb] * qp[d][mb] : 0.f;
-      fetch(s + DEPTH, qg[d], qx[d], qp[d]);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         acc[mb][0] = mfma32(a[mb], g4[0], acc[mb][0]);
@@ -1099,6 +1127,13 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
         acc[mb][2] = mfma32(a[mb], g4[2], acc[mb][2]);
         acc[mb][3] = mfma32(a[mb], g4[3], acc[mb][3]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // the refill comes AFTER the step's MFMAs so that it may land in the registers it replaces: loaded into fresh registers,
+      // the eight slots have to be copied back at the end of every group, and those copies wait for every load of the group
+      // (c4 l2, A/B on one box: 0.661 -> 0.617 ms).  Unlike the forward kernel, waiting for the prologue's loads before the
+      // loop -- which lets the full 8-deep queue stay in flight at the top of every group -- made this kernel SLOWER (0.708 ms
+      // with three resident waves per SIMD): the loop-top wait the compiler derives here (8 loads in flight) stays.
+      fetch(s + DEPTH, qg[d], qx[d], qp[d]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1214,6 +1249,9 @@ static __global__ __launch_bounds__(256, 2) void cin_dw3b_kernel(const bf16x8* _
       xq[buf][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, fo, (kb * 16 + e) * F * 4, 0));
       pq[buf][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ho, (kb * 16 + e) * xps * 4, 0));
     }
+    // (order pinned: the next block's A operand needs the 16 gathered dwords only; issued after the plane vectors -- as the
+    // scheduler likes to place them -- its wait would also cover those twelve 16-byte loads, i.e. drain the whole prefetch)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) bq[buf][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, (kb * 12 + i) * 1024, 0));
   };
