@@ -160,6 +160,9 @@ __device__ __forceinline__ float sigmoid_from_neg_log2(float t) {   // t = -log2
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 
+// makes the compiler wait HERE for a pending load of v (an empty asm that "uses" the registers)
+__device__ __forceinline__ void settle4(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 struct AttnDims {
   int B, F, K, H, A;
   int nblk;   // ceil(F/16)
@@ -319,12 +322,19 @@ struct SlabLane {
     a0 = a0_;
   }
   __device__ __forceinline__ int off(int f, int s) const { return a0 + s < A ? 4 * (f * A + a0 + s) : kOOB; }
+  // Branch-free: BOTH forms are issued, the one that does not apply with an out-of-range offset (it reads zeros and moves no
+  // data), and the results are OR-ed.  A branch between the two forms costs far more than four dead load instructions: behind
+  // it the compiler's wait-count bookkeeping falls back to vmcnt(0), i.e. whoever consumes an EARLIER prefetch also waits for
+  // the loads this call just issued (the backward's per-block prefetch was serialised that way).
   __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, int f) const {
-    if ((A & 3) == 0) return buf_load4(r, off(f, 0));     // the four elements are one aligned 16-byte piece
-    f32x4 v;
+    const bool vec = (A & 3) == 0;                         // the four elements are one aligned 16-byte piece
+    // (combined as INTEGER vectors: or-ing per element through float <-> int bit casts makes this compiler narrow the
+    // 16-byte load to its first dword and use that for all four elements)
+    const u32x4 u4 = __builtin_amdgcn_raw_buffer_load_b128(r, vec ? off(f, 0) : kOOB, 0, 0);
+    u32x4 u1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = buf_load1(r, off(f, s));
-    return v;
+    for (int s = 0; s < 4; ++s) u1[s] = __builtin_amdgcn_raw_buffer_load_b32(r, vec ? kOOB : off(f, s), 0, 0);
+    return __builtin_bit_cast(f32x4, u4 | u1);
   }
   __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int f, const f32x4& v) const {
     if ((A & 3) == 0) {
@@ -649,6 +659,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     f32x4 dk[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the first block's inputs, requested before the k projection: waited for once, here, so that the block loop is entered
+    // with nothing pending -- see the end of the block body)
+    settle4(n_dy);
+    settle4(n_y);
+    settle4(n_av);
     FIL_STAMP(0)
     for (int step = 0; step * WPH < d.nblk; ++step) {
       const int i = step * WPH + sub, par = step & 1;
@@ -787,6 +802,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         dWq[cc] = mma<F16>(xc, dq_c, dWq[cc]);                // [kin 4g+r][a c]
         if (has_res) dWr[cc] = mma<F16>(xc, dr_c, dWr[cc]);
       }
+      // The next block's inputs (requested at the top of this block) are waited for HERE, where they have long arrived.
+      // Left to the compiler the wait lands at their first use in the next block's prologue, behind the loads that block
+      // issues for ITS successor (SlabLane::load has two forms, and across that branch the wait count degrades to
+      // vmcnt(0)): every block then waited for a full HBM round trip of loads it had just issued -- the "prologue" phase
+      // of the stamp profile, a quarter of the kernel.
+      settle4(n_dy);
+      settle4(n_y);
+      settle4(n_av);
       FIL_STAMP(3)
       }
       lds_barrier();   // every wave's dq / dres tile of this step is in LDS
