@@ -24,7 +24,9 @@
 //                     The LayerNorm/ReLU backward (from the saved av and y) is the prologue of each query block, and
 //                     the projection gradients are folded in: dW* accumulate in registers across the samples of a
 //                     persistent workgroup, dx of the heads is summed in an LDS tile (fixed order) and written once.
-//                     HBM traffic: x, av, y, dy in; dx out -- no dav/dq/dk/dres round trips.
+//                     HBM traffic: x, av, y, dy in; dx out -- no dav/dq/dk/dres round trips.  Where the LDS footprint
+//                     allows one workgroup per CU only (K = 64, the f32 mode at large F) a head gets TWO waves that take
+//                     alternate query blocks (WPH = 2; nothing is computed twice).
 //
 // precision F32: every product on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains; 1e-5 parity mode), x fragments read from
 // global/L2.  F16_MFMA (BASELINE config 5): operands rounded to fp16 once when they enter LDS / registers, products on
@@ -41,7 +43,7 @@
 namespace fil {
 
 constexpr int kMaxNC = 4;      // K <= 64 (NC = ceil(K/16) chunks of 16 along the projection's reduction)
-constexpr int kMaxHeads = 8;   // one wave per head, one workgroup per sample
+constexpr int kMaxHeads = 8;   // one wave per head (two in the backward's WPH = 2 form, H <= 4)
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
