@@ -422,11 +422,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     if (LK + 1 > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: L*K=%zu > 255", LK);
     ProfScope ps("cin_head_bwd", st);
     hipLaunchKernelGGL(cin_head_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, dense_w, pooled, dP, small, B, (int)LK, kHeadChunk);
-    float* tmp = Gbuf[0];  // not yet in use
-    hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, tmp, (long)(LK + 1), nblk);
+    hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
     FIL_CHECK_LAUNCH();
-    (void)hipMemcpyAsync(ddense_w, tmp, LK * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(ddense_b, tmp + LK, sizeof(float), hipMemcpyDeviceToDevice, st);
     dPsrc = dP;
   }
   ready(L);

@@ -1376,8 +1376,9 @@ static __global__ __launch_bounds__(256) void cin_scale_rows3_kernel(const float
 
 // out[i] = sum_{p < parts} part[p*n + i]   (fixed order).  One workgroup per 64 outputs; the 4 waves take every 4th
 // partial (coalesced over i), then the 4 wave sums are added in wave order -> many loads in flight, fixed order.
+// out2 != nullptr: outputs i >= n1 go to out2[i - n1] (the dense head: ddense_w | ddense_b from one partial buffer, no copies).
 static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
-                                                         int parts) {
+                                                         int parts, float* __restrict__ out2 = nullptr, long n1 = 0) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + lane;
@@ -1394,7 +1395,11 @@ static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __r
   }
   red[wave][lane] = (t0 + t1) + (t2 + t3);
   __syncthreads();
-  if (wave == 0 && i < n) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && i < n) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (out2 != nullptr && i >= n1) out2[i - n1] = v;
+    else out[i] = v;
+  }
 }
 
 // part[blk] = sum over a chunk of samples of dP[b*ldp + k], k < K  (dbias of the last layer: same value for every n)
