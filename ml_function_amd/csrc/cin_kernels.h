@@ -1596,7 +1596,7 @@ static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* 
 // 4r..4r+3 of a chunk and G^{L-1} leaves as 16-byte stores; for u the reduction order is permuted (free in a GEMM)
 // so that wave half `half` takes h = 4q + 2*half + {0,1}: one 8-byte load of its own row per two steps.
 template <int JT>
-__global__ __launch_bounds__(256) void cin_last_bwd2_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+__global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                             const float* __restrict__ wsum, const float* __restrict__ wsn,
                                                             const float* __restrict__ dP, int ldp, const float* __restrict__ dPprev,
                                                             float* __restrict__ GprevT, int HSp, float* __restrict__ dxT, int M, int F,
@@ -1631,13 +1631,23 @@ __global__ __launch_bounds__(256) void cin_last_bwd2_kernel(const float* __restr
 #pragma unroll
       for (int i = 0; i < 16; ++i) t[nb][i] = 0.f;
     const float4* wsb = reinterpret_cast<const float4*>(wsn + (long)chunk * (2 * JT) * 128) + (half * 32 + r);
+    // operand loads in batches of QB ahead of their MFMAs (load -> wait -> 4 MFMAs per step was JT exposed L2 latencies in a
+    // row: the ISA had `s_waitcnt vmcnt(0)` in front of every step; the barrier keeps the scheduler from sinking them back)
+    constexpr int QB = JT % 5 == 0 ? 5 : 4;
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const float4 w = wsb[(long)(2 * j) * 32];
-      t[0] = mfma32(xr[j], w.x, t[0]);
-      t[1] = mfma32(xr[j], w.y, t[1]);
-      t[2] = mfma32(xr[j], w.z, t[2]);
-      t[3] = mfma32(xr[j], w.w, t[3]);
+    for (int j0 = 0; j0 < JT; j0 += QB) {
+      float4 wq[QB];
+#pragma unroll
+      for (int j = 0; j < QB; ++j) wq[j] = wsb[(long)(2 * (j0 + j)) * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        const float4 w = wq[j];
+        t[0] = mfma32(xr[j0 + j], w.x, t[0]);
+        t[1] = mfma32(xr[j0 + j], w.y, t[1]);
+        t[2] = mfma32(xr[j0 + j], w.z, t[2]);
+        t[3] = mfma32(xr[j0 + j], w.w, t[3]);
+      }
     }
     const int n0 = chunk * 128 + 4 * r;
 #pragma unroll
@@ -1670,19 +1680,35 @@ __global__ __launch_bounds__(256) void cin_last_bwd2_kernel(const float* __restr
     float2 av[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) av[i] = q0 + i < quads ? *reinterpret_cast<const float2*>(xprow + 4 * (q0 + i)) : make_float2(0.f, 0.f);
+    // B operands (LDS) four steps at a time ahead of their MFMAs; out-of-range rows / fields read a clamped word and are
+    // masked with an AND (read -> wait -> MFMA per step exposed the LDS latency at every step)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int h = 4 * (q0 + i) + 2 * half;
-      const float* w0 = smem + h * F;
-      const float b00 = (h < Hp && r < F) ? w0[r] : 0.f;
-      const float b01 = (h + 1 < Hp && r < F) ? w0[F + r] : 0.f;
-      u0 = mfma32(av[i].x, b00, u0);
-      u0 = mfma32(av[i].y, b01, u0);
-      if (two) {
-        const float b10 = (h < Hp && r + 32 < F) ? w0[r + 32] : 0.f;
-        const float b11 = (h + 1 < Hp && r + 32 < F) ? w0[F + r + 32] : 0.f;
-        u1 = mfma32(av[i].x, b10, u1);
-        u1 = mfma32(av[i].y, b11, u1);
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+      float b0[4][2], b1[4][2];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int h = 4 * (q0 + i0 + ii) + 2 * half;
+        const float* w0 = smem + min(h, Hp - 1) * F;
+        const float* w1 = smem + min(h + 1, Hp - 1) * F;
+        const int k0 = (h < Hp && r < F) ? -1 : 0, k1 = (h + 1 < Hp && r < F) ? -1 : 0;
+        b0[ii][0] = __builtin_bit_cast(float, __builtin_bit_cast(int, w0[min(r, F - 1)]) & k0);
+        b0[ii][1] = __builtin_bit_cast(float, __builtin_bit_cast(int, w1[min(r, F - 1)]) & k1);
+        b1[ii][0] = b1[ii][1] = 0.f;
+        if (two) {
+          const int k2 = (h < Hp && r + 32 < F) ? -1 : 0, k3 = (h + 1 < Hp && r + 32 < F) ? -1 : 0;
+          b1[ii][0] = __builtin_bit_cast(float, __builtin_bit_cast(int, w0[min(r + 32, F - 1)]) & k2);
+          b1[ii][1] = __builtin_bit_cast(float, __builtin_bit_cast(int, w1[min(r + 32, F - 1)]) & k3);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        u0 = mfma32(av[i0 + ii].x, b0[ii][0], u0);
+        u0 = mfma32(av[i0 + ii].y, b0[ii][1], u0);
+        if (two) {
+          u1 = mfma32(av[i0 + ii].x, b1[ii][0], u1);
+          u1 = mfma32(av[i0 + ii].y, b1[ii][1], u1);
+        }
       }
     }
   }
