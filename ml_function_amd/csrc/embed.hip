@@ -119,9 +119,16 @@ __global__ __launch_bounds__(256) void embed_segment_sum_kernel(const float* __r
   }
 }
 
-// Capture-safe form of the same sum (no data-dependent sizes anywhere): one wave per SORTED POSITION j; the wave whose
-// position starts a run of equal row ids (and only it) sums the run -- lanes (c, kq) take positions j + c, j + c + C, ...
-// while the id stays the same -- folds the C partial sums in lane order and stores the row into the zeroed dense table.
+// Capture-safe form of the same sum (no data-dependent sizes anywhere).  A wave takes C = 64 / KQ consecutive SORTED POSITIONS
+// per iteration, one per lane group (KQ lanes = one row of K floats).  A group whose position starts a run of equal row ids
+//   * of at most kRunShort elements sums it by itself, in sorted order (the ids, the permutation entries and the gradient rows
+//     of the whole run are three rounds of independent loads: Criteo-like batches are mostly runs of 1-3);
+//   * of more elements hands it to the whole wave: lanes (c, kq) take elements c, c + C, ... and the C partial sums are folded
+//     in lane order (hot ids with thousands of hits).
+// Which form a run takes depends on its length only, so repeats are bit-identical.  Rows are stored into the zeroed dense
+// table; id -1 (out-of-range / frozen) is skipped.  (Round 2 first had one wave per position: 60 us for 160 k positions.)
+constexpr int kRunShort = 8;
+
 __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restrict__ g, const int64_t* __restrict__ perm,
                                                             const int64_t* __restrict__ sorted_ids, float* __restrict__ dtable, long R,
                                                             int K) {
@@ -129,32 +136,72 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int KQ = (K + 3) / 4, C = 64 / KQ;
   const int c = lane / KQ, kq = lane - c * KQ;
-  for (long j = (long)blockIdx.x * 4 + wave; j < R; j += (long)gridDim.x * 4) {
-    const int64_t row = sorted_ids[j];
-    if (row < 0 || (j > 0 && sorted_ids[j - 1] == row)) continue;    // wave-uniform: not the start of a run
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < C) {
-      for (long jj = j + c; jj < R && sorted_ids[jj] == row; jj += C) {
-        const float* src = g + perm[jj] * K + kq * 4;
+  float* my = red[wave];
+  for (long j0 = ((long)blockIdx.x * 4 + wave) * C; j0 < R; j0 += (long)gridDim.x * 4 * C) {
+    const long j = j0 + c;
+    const bool have = c < C && j < R;
+    const long jc = have ? j : R - 1;
+    const int64_t row = sorted_ids[jc];
+    const int64_t prev = jc > 0 ? sorted_ids[jc - 1] : -2;
+    const bool start = have && row >= 0 && prev != row;
+    // length of the run, counted up to kRunShort + 1 (all look-ahead ids are independent loads)
+    int64_t nxt[kRunShort];
+#pragma unroll
+    for (int t = 0; t < kRunShort; ++t) nxt[t] = sorted_ids[jc + 1 + t < R ? jc + 1 + t : R - 1];
+    int n = 1;
+    bool same = true;
+#pragma unroll
+    for (int t = 0; t < kRunShort; ++t) {
+      same = same && jc + 1 + t < R && nxt[t] == row;
+      n += same ? 1 : 0;
+    }
+    const bool is_long = start && n > kRunShort;
+    if (start && !is_long) {
+      long pr[kRunShort];
+#pragma unroll
+      for (int t = 0; t < kRunShort; ++t) pr[t] = perm[t < n ? jc + t : jc];
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < kRunShort; ++t) {
+        const float* src = g + pr[t] * K + kq * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (kq * 4 + i < K) acc[i] += src[i];
+          if (t < n && kq * 4 + i < K) acc[i] += src[i];
       }
-    }
-    float* my = red[wave];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) my[lane * 4 + i] = acc[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (c == 0) {
-      for (int cc = 1; cc < C; ++cc)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += my[(cc * KQ + kq) * 4 + i];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (kq * 4 + i < K) dtable[row * K + kq * 4 + i] = acc[i];
     }
-    __builtin_amdgcn_wave_barrier();
+    // long runs: one after the other, by the whole wave
+    unsigned long long pending = __ballot(is_long && kq == 0);
+    while (pending != 0) {
+      const int ll = __builtin_ctzll(pending);          // first lane of the group that found the run
+      pending &= pending - 1;
+      const long js = j0 + ll / KQ;
+      const int64_t rl = sorted_ids[js];
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        for (long jj = js + c; jj < R && sorted_ids[jj] == rl; jj += C) {
+          const float* src = g + perm[jj] * K + kq * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (kq * 4 + i < K) acc[i] += src[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) my[lane * 4 + i] = acc[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (c == 0) {
+        for (int cc = 1; cc < C; ++cc)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += my[(cc * KQ + kq) * 4 + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kq * 4 + i < K) dtable[rl * K + kq * 4 + i] = acc[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -168,8 +215,9 @@ extern "C" int fil_embed_run_sum(const float* g, const int64_t* perm, const int6
   if (K > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_run_sum: K=%d > 256", K);
   if (R == 0) return FIL_OK;
   FIL_CHECK_ARG(g && perm && sorted_ids && dtable);
-  hipLaunchKernelGGL(embed_run_sum_kernel, dim3((int)std::min<long>((R + 3) / 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, perm, sorted_ids,
-                     dtable, R, K);
+  const int C = 64 / ((K + 3) / 4);   // positions per wave and iteration
+  hipLaunchKernelGGL(embed_run_sum_kernel, dim3((int)std::min<long>((R + 4 * C - 1) / (4 * C), 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, perm,
+                     sorted_ids, dtable, R, K);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

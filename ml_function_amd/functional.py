@@ -407,7 +407,33 @@ def product_attention(q, k, v, use_scale=False, mask=None, mask_mod=1):
 
 
 # --------------------------------------------------------------------------------------------- N1  embeddings
-def embed_grad_rows(offsets, sizes, idx, g, frozen=None):
+# (sorted row ids, permutation) of the most recent index tensors.  A model usually looks the SAME ids up in two tables (the
+# embeddings and the linear weights): their gradients need the same sort.  An entry keeps its idx tensor alive, so an equal
+# (data_ptr, _version) really is the same contents; in-place updates bump the version and miss.
+_SORT_CACHE = []
+
+
+def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None):
+    """layout_key: a hashable description of (offsets, sizes, frozen) -- two tables with the same field layout (SparseEmbed
+    passes its word sizes / frozen flags) share the sort even though their offset tensors are different objects."""
+    lib = _lib.load()
+    layout = layout_key if layout_key is not None else (
+        offsets.data_ptr(), offsets._version, sizes.data_ptr() if sizes is not None else 0,
+        frozen.data_ptr() if frozen is not None else 0)
+    key = (idx.data_ptr(), idx._version, tuple(idx.shape), layout, torch.cuda.current_stream().cuda_stream)
+    for k, _, out in _SORT_CACHE:
+        if k == key:
+            return out
+    B, F = idx.shape
+    row_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
+    check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
+    out = torch.sort(row_ids, stable=True)
+    _SORT_CACHE.insert(0, (key, (idx, offsets, sizes, frozen), out))
+    del _SORT_CACHE[2:]
+    return out
+
+
+def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None):
     """Deterministic embedding-table gradient as (rows [U] int64, values [U,K]): the unique global table rows the batch
     touched (sorted) and the sum of their gradient rows, contributions added in a fixed order (no atomics).  Out-of-range
     ids and frozen fields (frozen [F] uint8) contribute nothing.  The sort is torch's (plumbing); the sums are the HIP
@@ -416,9 +442,7 @@ def embed_grad_rows(offsets, sizes, idx, g, frozen=None):
     B, F = idx.shape
     K = g.shape[-1]
     g = _f32c(g)
-    row_ids = torch.empty(B * F, dtype=torch.int64, device=g.device)
-    check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
-    sorted_ids, perm = torch.sort(row_ids, stable=True)
+    sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key)
     rows, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
     starts = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=g.device)
     torch.cumsum(counts, 0, out=starts[1:])
@@ -432,7 +456,7 @@ def embed_grad_rows(offsets, sizes, idx, g, frozen=None):
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count):
+    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key=None):
         _require_cuda(table, offsets, idx)
         table = _f32c(table)
         idx = idx.to(torch.int64).contiguous()
@@ -443,12 +467,12 @@ class _EmbedFn(torch.autograd.Function):
         check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(oob_count), B, F, K,
                                            stream_ptr()), "fil_embed_gather")
         ctx.save_for_backward(offsets, idx, *[t for t in (sizes, frozen) if t is not None])
-        ctx.cfg = (tuple(table.shape), sizes is not None, frozen is not None, bool(sparse_grad), bool(atomic))
+        ctx.cfg = (tuple(table.shape), sizes is not None, frozen is not None, bool(sparse_grad), bool(atomic), layout_key)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        table_shape, has_sizes, has_frozen, sparse_grad, atomic = ctx.cfg
+        table_shape, has_sizes, has_frozen, sparse_grad, atomic, layout_key = ctx.cfg
         sv = list(ctx.saved_tensors)
         offsets, idx = sv[:2]
         rest = sv[2:]
@@ -464,21 +488,19 @@ class _EmbedFn(torch.autograd.Function):
             if frozen is not None:
                 raise FilError("embed_gather: frozen fields are not supported by the atomic scatter-add")
         elif sparse_grad:   # what Keras hands its optimizers (IndexedSlices): only the touched rows exist
-            rows, values = embed_grad_rows(offsets, sizes, idx, g, frozen)
+            rows, values = embed_grad_rows(offsets, sizes, idx, g, frozen, layout_key)
             dtable = torch.sparse_coo_tensor(rows.unsqueeze(0), values, table_shape)
         else:               # dense table, deterministic, no data-dependent shapes (HIP-graph capturable)
             lib = _lib.load()
-            row_ids = torch.empty(B * F, dtype=torch.int64, device=g.device)
-            check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
-            sorted_ids, perm = torch.sort(row_ids, stable=True)
+            sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key)
             dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
             check(lib.fil_embed_run_sum(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, stream_ptr()), "fil_embed_run_sum")
-        return dtable, None, None, None, None, None, None, None
+        return dtable, None, None, None, None, None, None, None, None
 
 
-def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False, atomic=False, oob_count=None):
+def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False, atomic=False, oob_count=None, layout_key=None):
     """table [sum V_f, K] (all fields concatenated), offsets [F], idx [B,F] -> packed [B,F,K].
     sizes [F] int64: ids outside [0, V_f) give zero rows (counted in oob_count, an int32 device scalar) and no gradient.
     The gradient is deterministic (sorted segment sums); sparse_grad=True returns it as a sparse COO tensor over the touched
     rows instead of a dense table; atomic=True selects the fp32-atomic scatter-add instead."""
-    return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count)
+    return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key)

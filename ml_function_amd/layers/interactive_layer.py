@@ -289,6 +289,8 @@ class SparseEmbed(Layer):
         self.register_buffer("offsets", torch.tensor(offsets, dtype=torch.int64, device=dev))
         self.register_buffer("sizes", torch.tensor(sizes, dtype=torch.int64, device=dev))
         self.register_buffer("frozen", torch.tensor(frozen, dtype=torch.uint8, device=dev) if any(frozen) else None)
+        # tables with the same field layout (the embeddings and the linear weights of one model) share the sort of their gradient
+        self._layout_key = (tuple(sizes), tuple(frozen) if any(frozen) else None)
         super().build(input_shape)
 
     def regularization_losses(self):
@@ -302,7 +304,7 @@ class SparseEmbed(Layer):
         idx = idx.to(torch.int64)
         oob = torch.zeros((), dtype=torch.int32, device=idx.device) if self.check_ids else None
         block = Fn.embed_gather(self.embeddings, self.offsets, idx, sizes=self.sizes, frozen=self.frozen,
-                                sparse_grad=self.sparse_grad, oob_count=oob)  # [B,F,K]
+                                sparse_grad=self.sparse_grad, oob_count=oob, layout_key=self._layout_key)  # [B,F,K]
         if oob is not None and int(oob) > 0:
             bad = ((idx < 0) | (idx >= self.sizes)).nonzero()[0].tolist()
             raise IndexError("SparseEmbed: %d ids outside their vocabulary, first at sample %d, field %s (id %d, word_size %d)"
