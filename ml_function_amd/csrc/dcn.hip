@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kDcnThreads) void dcn_fwd_kernel(const float* __res
   __syncthreads();
   const float* ws = smem;
   const float* bs = smem + L * D;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: descriptors built from it stay in SGPRs, no waterfall loops)
   for (int n = blockIdx.x * kDcnWaves + wave; n < B; n += gridDim.x * kDcnWaves) {
     float x0[NPL], xl[NPL];
     row_load<NPL, VEC>(x + (long)n * D, D, lane, x0);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kDcnBwdThreads) void dcn_bwd_kernel(const float* __
   for (int i = threadIdx.x; i < LL * D; i += kDcnBwdThreads) smem[i] = w[i];
   __syncthreads();
   const float* ws = smem;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: descriptors built from it stay in SGPRs, no waterfall loops)
   float acc[LL][NPL], gsum[NPL], dssum[LL];
 #pragma unroll
   for (int l = 0; l < LL; ++l) {
@@ -163,22 +163,27 @@ __global__ __launch_bounds__(kDcnBwdThreads) void dcn_bwd_kernel(const float* __
   int n = blockIdx.x * kDcnBwdWaves + wave;
   float x0[NPL], gv[NPL];
   const int rowb = D * 4;
+  float sv[LL];
   if (n < B) {
     row_load_buf<NPL, VEC>(dcn_rsrc(x + (long)n * D, rowb), lane, x0);
     row_load_buf<NPL, VEC>(dcn_rsrc(g + (long)n * D, rowb), lane, gv);
+#pragma unroll
+    for (int l = 0; l < LL; ++l) sv[l] = s[(long)n * LL + l];
   }
   for (; n < B; n += nstep) {
-    // the next sample's rows are fetched while this one is processed
-    float xn[NPL], gn[NPL];
+    // the next sample's rows AND its saved dots are fetched while this one is processed.  (The dots used to be loaded here,
+    // behind the row prefetch: loads complete in order, so the wait for them also waited for the 2*NPL/VEC row loads just
+    // issued -- an `s_waitcnt vmcnt(0)` in the middle of every sample, i.e. no prefetch at all.)
+    float xn[NPL], gn[NPL], svn[LL];
     const bool more = n + nstep < B;
     {   // (past the last sample the descriptors are empty: the loads return zeros and nothing is fetched)
       const long nn = more ? n + nstep : n;
       row_load_buf<NPL, VEC>(dcn_rsrc(x + nn * D, more ? rowb : 0), lane, xn);
       row_load_buf<NPL, VEC>(dcn_rsrc(g + nn * D, more ? rowb : 0), lane, gn);
-    }
-    float sv[LL], dots[LL + 1];
 #pragma unroll
-    for (int l = 0; l < LL; ++l) sv[l] = s[(long)n * LL + l];
+      for (int l = 0; l < LL; ++l) svn[l] = s[nn * LL + l];
+    }
+    float dots[LL + 1];
     dots[LL] = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) dots[LL] = fmaf(gv[i], x0[i], dots[LL]);
@@ -234,6 +239,8 @@ __global__ __launch_bounds__(kDcnBwdThreads) void dcn_bwd_kernel(const float* __
       x0[i] = xn[i];
       gv[i] = gn[i];
     }
+#pragma unroll
+    for (int l = 0; l < LL; ++l) sv[l] = svn[l];
   }
 
   // block reduction of the per-wave accumulators, fixed wave order, through LDS (one [waves][D] slab at a time):
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void dcn_reduce_closed_kernel(const float* __r
                                                                 float* __restrict__ db, int parts, int D, int L) {
   __shared__ float red[4][64];
   __shared__ float dsr[4][8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: descriptors built from it stay in SGPRs, no waterfall loops)
   const int d = blockIdx.x * 64 + lane, l = blockIdx.y;
   const long pstride = (long)(L + 1) * D + 8;
   // eight partials in flight per thread (they come from L2 / the Infinity Cache: the loop is latency-, not bandwidth-bound)
@@ -333,7 +340,7 @@ constexpr int kDcnMaxL = 6;
 __global__ __launch_bounds__(256) void dcn_bwd_scalars_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ g, float* __restrict__ ds, int B, int D,
                                                               int L) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: descriptors built from it stay in SGPRs, no waterfall loops)
   for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
     float acc[kDcnMaxL + 1];
 #pragma unroll
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restri
 __global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                          float* __restrict__ db, int parts, int LD) {
   __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: descriptors built from it stay in SGPRs, no waterfall loops)
   const int i = blockIdx.x * 64 + lane;
   const int n = 2 * LD;
   float t0 = 0.f, t1 = 0.f;
