@@ -753,9 +753,21 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
     vq[mb] = m < M;
     mq[mb] = vq[mb] ? m : M - 1;
     if constexpr (SYM) {
-      for (int f = half; f < FR; f += 2) {
-        xs[(mb * FR + f) * kSymStride] = (vq[mb] && f < F) ? xT[mq[mb] * F + f] : 0.f;
-        dxs[(mb * FR + f) * kSymStride] = 0.f;
+      // eight loads per batch (unconditional, clamped, masked with an AND), then the LDS writes: the rolled form was one
+      // load -> s_waitcnt vmcnt(0) -> ds_write per field, FR/2 exposed load latencies in a row per 32 rows
+      for (int f0 = half; f0 < FR; f0 += 16) {
+        float xt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xt[u] = xT[mq[mb] * F + min(f0 + 2 * u, F - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + 2 * u;
+          if (f < FR) {
+            const int keep = (vq[mb] && f < F) ? -1 : 0;
+            xs[(mb * FR + f) * kSymStride] = __builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep);
+            dxs[(mb * FR + f) * kSymStride] = 0.f;
+          }
+        }
       }
     } else {
       // all JT loads first (unconditional, clamped, masked with an AND: see the per-period loads below), then the LDS writes:
