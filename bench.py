@@ -109,7 +109,7 @@ def deepfm_benchmark(args):
     vocab = [int(v) for v in np.exp(rng.uniform(np.log(10), np.log(1e5), 39))]
     xd = args.workload == "xdeepfm"
     fi = models.FeatureInput(sparseInfo=models.make_sparse_info(vocab, embed_dim=16), useLinear=True, useAddLinear=xd,
-                             useFlattenLinear=xd)
+                             useFlattenLinear=xd, emitXT=xd)   # (xDeepFM: the gather also emits the layout the CIN kernels read)
     body = models.XDeepFM(conv_size=[128, 128, 128]) if xd else models.DeepFM(hidden_units=[256, 128])
 
     class Bf16Body(torch.nn.Module):

@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 203
+#define FIL_ABI_VERSION 204
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -94,6 +94,9 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *             l >= 1 run on split-bf16 operands (every fp32 value as three bf16 pieces, six bf16 MFMAs with fp32
  *             accumulation per product: the same measured error as modes 0/1, but not their exact-fp32 FMA chain);
  *             the pair-symmetric first layer and the last-layer shortcut stay exact fp32.
+ *         + FIL_CIN_X_TRANSPOSED (16), forward and backward alike: `x` is given transposed, [B*K][F] row-major (x_t[(b*K+k)*F+f]
+ *           = x[b,f,k], as written by fil_embed_gather_xt): no input transpose, saved's own copy of it stays unused.  dx is
+ *           still returned as [B,F,K].
  *         + FIL_CIN_MB2 (4) / FIL_CIN_NOSYM (8): per-call launch-shape overrides (64-row waves in the row-parallel kernels,
  *             i.e. the launch configuration large batches get by themselves; symmetric first-layer kernels off).  Same
  *             function up to summation order; they exist so that tests can reach every instantiation at small sizes.
@@ -142,7 +145,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
-enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8 };
+enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);
@@ -190,6 +193,11 @@ int fil_pattn_bwd(const float* q, const float* k, const float* v, const float* m
  */
 int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
                      int* oob_count, int B, int F, int K, void* stream);
+/* the same gather emitting BOTH the packed block out [B,F,K] and its transposed rows out_t [B*K][F] (out_t[(b*K+k)*F+f] =
+ * out[b,f,k]) -- the layout the CIN kernels read: hand out_t to fil_cin_fwd / fil_cin_bwd as `x` with FIL_CIN_X_TRANSPOSED and
+ * the consumer's input transpose is gone (gather fused into the consumer). */
+int fil_embed_gather_xt(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
+                        float* out_t, int* oob_count, int B, int F, int K, void* stream);
 int fil_embed_scatter_add(const int64_t* offsets, const int64_t* sizes, const int64_t* idx, const float* g, float* dtable,
                           int B, int F, int K, void* stream);
 int fil_embed_row_ids(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "fil_pattn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_pattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_embed_gather": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fil_embed_gather_xt": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_scatter_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_row_ids": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "fil_embed_segment_sum": (_I, [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),

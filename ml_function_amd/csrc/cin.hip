@@ -251,8 +251,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 15) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM)", mode);
+  if (mode < 0 || mode > 31) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
+  const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
   mode &= 1;
   if (B == 0) return FIL_OK;
@@ -274,10 +275,11 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   float* wsum = ws.take<float>((size_t)s.Hp(L - 1) * F);
   float* Wf = ws.take<float>(wf_floats(s));
   Carver sv(saved);
-  float* xT = sv.take<float>((size_t)M * F);
-  {
+  float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
+  const float* xT = xt_in ? x : xT_own;
+  if (!xt_in) {
     ProfScope ps("cin_transpose_in", st, 2.0 * M * F * sizeof(float));
-    hipLaunchKernelGGL(cin_transpose_in_kernel, dim3(B), dim3(256), (size_t)F * (K + 1) * sizeof(float), st, x, xT, F, K);
+    hipLaunchKernelGGL(cin_transpose_in_kernel, dim3(B), dim3(256), (size_t)F * (K + 1) * sizeof(float), st, x, xT_own, F, K);
   }
   FIL_CHECK_LAUNCH();
   const float* xpT = xT;
@@ -358,11 +360,12 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
                            float* const* dbias, float* ddense_w, float* ddense_b, int B, int F, int K, int L, const int* H,
                            int output_dim, int mode, void* const* grad_ready_events, void* workspace, size_t workspace_bytes,
                            void* stream) {
-  (void)bias; (void)x;
+  (void)bias;
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 15) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM)", mode);
+  if (mode < 0 || mode > 31) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED)", mode);
+  const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
   mode &= 1;
@@ -387,7 +390,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     for (int l = 0; l <= L; ++l) ready(l);
     return FIL_OK;
   }
-  FIL_CHECK_ARG(g && dx && saved);
+  FIL_CHECK_ARG(g && dx && saved && (x || !xt_in));
   FIL_CHECK_ARG(output_dim != 1 || (dense_w && pooled && ddense_w && ddense_b));
   if (workspace == nullptr || workspace_bytes < bwd_ws_bytes(s))
     return fail(FIL_ERR_WORKSPACE, "fil_cin_bwd: workspace %zu < %zu bytes", workspace_bytes, bwd_ws_bytes(s));
@@ -412,7 +415,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
 
   // saved tensors
   Carver sv(const_cast<float*>(saved));
-  const float* xT = sv.take<float>((size_t)M * F);
+  const float* xT_own = sv.take<float>((size_t)M * F);
+  const float* xT = xt_in ? x : xT_own;    // (X_TRANSPOSED: the caller's [B*K][F] copy; the forward left saved's own area unused)
   const float* maps[kCinMaxL];
   for (int l = 0; l + 1 < L; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
 

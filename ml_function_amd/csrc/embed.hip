@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
   }
 }
 
+// The same gather, one workgroup per sample through LDS, writing BOTH layouts: the packed [B,F,K] block and the row-major
+// transposed xT [B*K][F] (xT[(b*K + k)*F + f] = out[b,f,k]) that the CIN kernels consume -- the consumer's input transpose
+// (cin_transpose_in: one more read and write of the block) disappears.  Both outputs leave as whole contiguous rows.
+__global__ __launch_bounds__(256) void embed_gather_xt_kernel(const float* __restrict__ table, const int64_t* __restrict__ offsets,
+                                                              const int64_t* __restrict__ sizes, const int64_t* __restrict__ idx,
+                                                              float* __restrict__ out, float* __restrict__ out_t,
+                                                              int* __restrict__ oob_count, int F, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [F][K+1]
+  const long b = blockIdx.x;
+  for (int i = threadIdx.x; i < F * K; i += 256) {
+    const int f = i / K, k = i - f * K;
+    const int64_t id = idx[b * F + f];
+    const bool ok = sizes == nullptr || (id >= 0 && id < sizes[f]);
+    if (!ok && k == 0 && oob_count != nullptr) atomicAdd(oob_count, 1);
+    const float v = ok ? table[(offsets[f] + id) * K + k] : 0.f;
+    smem[f * (K + 1) + k] = v;
+    out[b * F * K + i] = v;
+  }
+  __syncthreads();
+  float* dst = out_t + b * K * F;
+  for (int i = threadIdx.x; i < F * K; i += 256) dst[i] = smem[(i % F) * (K + 1) + (i / F)];
+}
+
 // dtable[offsets[f] + idx[b,f], k] += g[b,f,k]  -- fp32 global atomics (one dword per lane, contiguous per row).
 // The order of additions into a row that is hit several times in a batch is not fixed.
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
@@ -233,6 +256,23 @@ extern "C" int fil_embed_gather(const float* table, const int64_t* offsets, cons
   const int grid = (int)std::min<long>((total + 255) / 256, 256 * 8);
   if (vec) hipLaunchKernelGGL((embed_gather_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, sizes, idx, out, oob_count, rows, F, K);
   else hipLaunchKernelGGL((embed_gather_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, sizes, idx, out, oob_count, rows, F, K);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" int fil_embed_gather_xt(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
+                                   float* out_t, int* oob_count, int B, int F, int K, void* stream) {
+  FIL_CHECK_ARG(B >= 0 && F >= 1 && K >= 1);
+  if (B == 0) return FIL_OK;
+  FIL_CHECK_ARG(table && offsets && idx && out && out_t);
+  const size_t sh = (size_t)F * (K + 1) * sizeof(float);
+  if (sh > 64 * 1024) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_gather_xt: F*(K+1) = %d floats of LDS per sample (> 64 KiB)", F * (K + 1));
+  if (sh > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(embed_gather_xt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FIL_ERR_HIP, "fil_embed_gather_xt: cannot reserve %zu bytes of LDS", sh);
+  }
+  hipLaunchKernelGGL(embed_gather_xt_kernel, dim3(B), dim3(256), sh, (hipStream_t)stream, table, offsets, sizes, idx, out, out_t, oob_count, F, K);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

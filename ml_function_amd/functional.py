@@ -143,10 +143,18 @@ def dcn_cross(x, w, b):
 
 
 # --------------------------------------------------------------------------------------------- A3  CIN
-def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0):
-    """Raw forward through the C ABI.  Returns (out [B,1] or None, pooled [B,L*K], saved uint8 buffer)."""
+CIN_X_TRANSPOSED = 16   # fil.h FIL_CIN_X_TRANSPOSED: x handed over as [B*K, F] (embed_gather(emit_xt=True))
+
+
+def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0, xt=None):
+    """Raw forward through the C ABI.  Returns (out [B,1] or None, pooled [B,L*K], saved uint8 buffer).
+    xt (optional): x already transposed to [B*K, F] by the gather that produced it; the kernels then read it in place."""
     lib = _lib.load()
     B, F, K = x.shape
+    if xt is not None:
+        if tuple(xt.shape) != (B * K, F) or xt.dtype != torch.float32 or not xt.is_contiguous() or xt.device != x.device:
+            raise FilError("cin: xt must be a contiguous float32 [B*K, F] = [%d, %d] tensor on %s" % (B * K, F, x.device))
+        mode |= CIN_X_TRANSPOSED
     L = len(Ws)
     H = [int(w.shape[1]) for w in Ws]
     hp = F
@@ -162,12 +170,12 @@ def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0):
     ws = _workspace(nws, x.device)
     pooled = torch.empty((B, L * K), dtype=torch.float32, device=x.device)
     out = torch.empty((B, 1), dtype=torch.float32, device=x.device) if output_dim == 1 else None
-    check(lib.fil_cin_fwd(ptr(x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(dense_b), ptr(out), ptr(pooled),
-                          ptr(saved), B, F, K, L, Harr, output_dim, mode, ptr(ws), nws, stream_ptr()), "fil_cin_fwd")
+    check(lib.fil_cin_fwd(ptr(xt if xt is not None else x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(dense_b), ptr(out),
+                          ptr(pooled), ptr(saved), B, F, K, L, Harr, output_dim, mode, ptr(ws), nws, stream_ptr()), "fil_cin_fwd")
     return out, pooled, saved
 
 
-def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0, grads=None, ready_events=None):
+def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0, grads=None, ready_events=None, xt=None):
     """Raw backward.  grads (optional): dict with preallocated 'dx','dW'(list),'db'(list),'ddw','ddb' tensors
     (e.g. views into one flat all-reduce bucket).  ready_events (optional): L+1 torch.cuda.Event objects (or None
     entries), recorded as each layer's / the head's parameter gradients become final (fil.h: grad_ready_events).
@@ -191,7 +199,9 @@ def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0,
             if e is not None and not e.cuda_event:
                 e.record()
         evs = (ctypes.c_void_p * (L + 1))(*[None if e is None else e.cuda_event for e in ready_events])
-    check(lib.fil_cin_bwd(ptr(x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(pooled), ptr(saved), ptr(g),
+    if xt is not None:
+        mode |= CIN_X_TRANSPOSED
+    check(lib.fil_cin_bwd(ptr(xt if xt is not None else x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(pooled), ptr(saved), ptr(g),
                           ptr(grads["dx"]), ptr_array(grads["dW"]), ptr_array(grads["db"]), ptr(grads["ddw"]),
                           ptr(grads["ddb"]), B, F, K, L, Harr, output_dim, mode, evs, ptr(ws), nws, stream_ptr()), "fil_cin_bwd")
     return grads
@@ -199,7 +209,7 @@ def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0,
 
 class _CinFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, dense_w, dense_b, output_dim, mode, *params):
+    def forward(ctx, x, dense_w, dense_b, output_dim, mode, xt, *params):
         L = len(params) // 2
         Ws = [_f32c(p) for p in params[:L]]
         bs = [_f32c(p) for p in params[L:]]
@@ -207,8 +217,9 @@ class _CinFn(torch.autograd.Function):
         x = _f32c(x)
         dense_w = _f32c(dense_w)
         dense_b = _f32c(dense_b)
-        out, pooled, saved = cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim, mode)
+        out, pooled, saved = cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim, mode, xt=xt)
         ctx.save_for_backward(x, dense_w, pooled, saved, *Ws, *bs)
+        ctx.xt = xt          # (not a graph tensor: the gather's second output, same values as x)
         ctx.cfg = (L, output_dim, mode)
         return out if output_dim == 1 else pooled
 
@@ -218,13 +229,15 @@ class _CinFn(torch.autograd.Function):
         x, dense_w, pooled, saved = ctx.saved_tensors[:4]
         Ws = list(ctx.saved_tensors[4:4 + L])
         bs = list(ctx.saved_tensors[4 + L:])
-        gr = cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, _f32c(g), output_dim, mode)
-        return (gr["dx"], gr["ddw"], gr["ddb"], None, None, *gr["dW"], *gr["db"])
+        gr = cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, _f32c(g), output_dim, mode, xt=ctx.xt)
+        return (gr["dx"], gr["ddw"], gr["ddb"], None, None, None, *gr["dW"], *gr["db"])
 
 
-def cin(x, Ws, bs, dense_w=None, dense_b=None, output_dim=1, mode=0):
-    """x [B,F,K]; Ws[l] [H_{l-1}*F, H_l]; bs[l] [H_l]; dense_w [L*K,1]; dense_b [1] -> [B,1] (or pooled [B,L*K])."""
-    return _CinFn.apply(x, dense_w, dense_b, output_dim, mode, *Ws, *bs)
+def cin(x, Ws, bs, dense_w=None, dense_b=None, output_dim=1, mode=0, xt=None):
+    """x [B,F,K]; Ws[l] [H_{l-1}*F, H_l]; bs[l] [H_l]; dense_w [L*K,1]; dense_b [1] -> [B,1] (or pooled [B,L*K]).
+    xt (optional) = x transposed to [B*K, F] by the gather that produced x (embed_gather(emit_xt=True) attaches it to its
+    result as `_fil_xt`): the kernels read it in place instead of transposing x again.  Gradients still flow to x."""
+    return _CinFn.apply(x, dense_w, dense_b, output_dim, mode, xt, *Ws, *bs)
 
 
 # --------------------------------------------------------------------------------------------- A4  AutoInt
@@ -456,7 +469,7 @@ def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None):
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key=None):
+    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key=None, xt_out=None):
         _require_cuda(table, offsets, idx)
         table = _f32c(table)
         idx = idx.to(torch.int64).contiguous()
@@ -464,8 +477,12 @@ class _EmbedFn(torch.autograd.Function):
         B, F = idx.shape
         K = table.shape[1]
         out = torch.empty((B, F, K), dtype=torch.float32, device=table.device)
-        check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(oob_count), B, F, K,
-                                           stream_ptr()), "fil_embed_gather")
+        if xt_out is not None:     # both layouts in one pass: the packed block and its [B*K, F] transpose (fil.h)
+            check(_lib.load().fil_embed_gather_xt(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(xt_out), ptr(oob_count),
+                                                  B, F, K, stream_ptr()), "fil_embed_gather_xt")
+        else:
+            check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(oob_count), B, F, K,
+                                               stream_ptr()), "fil_embed_gather")
         ctx.save_for_backward(offsets, idx, *[t for t in (sizes, frozen) if t is not None])
         ctx.cfg = (tuple(table.shape), sizes is not None, frozen is not None, bool(sparse_grad), bool(atomic), layout_key)
         return out
@@ -495,12 +512,21 @@ class _EmbedFn(torch.autograd.Function):
             sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key)
             dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
             check(lib.fil_embed_run_sum(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, stream_ptr()), "fil_embed_run_sum")
-        return dtable, None, None, None, None, None, None, None, None
+        return dtable, None, None, None, None, None, None, None, None, None
 
 
-def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False, atomic=False, oob_count=None, layout_key=None):
+def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False, atomic=False, oob_count=None, layout_key=None,
+                 emit_xt=False):
     """table [sum V_f, K] (all fields concatenated), offsets [F], idx [B,F] -> packed [B,F,K].
     sizes [F] int64: ids outside [0, V_f) give zero rows (counted in oob_count, an int32 device scalar) and no gradient.
     The gradient is deterministic (sorted segment sums); sparse_grad=True returns it as a sparse COO tensor over the touched
     rows instead of a dense table; atomic=True selects the fp32-atomic scatter-add instead."""
-    return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key)
+    if not emit_xt:
+        return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key)
+    # emit_xt: the same launch also writes the block transposed to [B*K, F], the layout the CIN kernels read; it rides on the
+    # result as `_fil_xt` (the CIN layer picks it up: no second pass over the block)
+    B, F = idx.shape
+    xt = torch.empty((B * table.shape[1], F), dtype=torch.float32, device=table.device)
+    out = _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key, xt)
+    out._fil_xt = xt
+    return out

@@ -214,10 +214,14 @@ class CIN(Layer):
 
     def call(self, inputs, **kwargs):
         x = pack_fields(inputs)
+        # SparseEmbed(emit_xt=True) leaves the block's [B*K, F] transpose on it: the kernels then read that in place
+        xt = getattr(x, "_fil_xt", None)
+        if xt is not None and (x.dim() != 3 or tuple(xt.shape) != (x.shape[0] * x.shape[2], x.shape[1]) or xt.device != x.device):
+            xt = None
         Ws = [w[0] for w in self.conv_kernels]
         if self.output_dim == 1:
-            return Fn.cin(x, Ws, self.conv_biases, self.logit_kernel, self.logit_bias, output_dim=1, mode=self.mode)
-        return Fn.cin(x, Ws, self.conv_biases, None, None, output_dim=self.output_dim, mode=self.mode)
+            return Fn.cin(x, Ws, self.conv_biases, self.logit_kernel, self.logit_bias, output_dim=1, mode=self.mode, xt=xt)
+        return Fn.cin(x, Ws, self.conv_biases, None, None, output_dim=self.output_dim, mode=self.mode, xt=xt)
 
 
 class SparseEmbed(Layer):
@@ -240,7 +244,7 @@ class SparseEmbed(Layer):
     instead of a dense table; either way it is deterministic (sorted segment sums, no atomics)."""
 
     def __init__(self, sparse_info: list, is_linear=False, use_flatten=True, use_add=False, seed=2020, support_masking=True,
-                 mask_zero=False, packed=False, check_ids=None, sparse_grad=False):
+                 mask_zero=False, packed=False, check_ids=None, sparse_grad=False, emit_xt=False):
         super().__init__()
         self.sparse_info = sparse_info
         self.is_linear = is_linear
@@ -252,6 +256,7 @@ class SparseEmbed(Layer):
         self.packed = packed
         self.check_ids = _CHECK_IDS if check_ids is None else bool(check_ids)
         self.sparse_grad = sparse_grad
+        self.emit_xt = emit_xt      # extension: also emit the block transposed to [B*K, F] for a CIN consumer (fil_embed_gather_xt)
 
     def build(self, input_shape):
         dims = {int(i.linear_unit if self.is_linear else i.cross_unit) for i in self.sparse_info}
@@ -304,7 +309,8 @@ class SparseEmbed(Layer):
         idx = idx.to(torch.int64)
         oob = torch.zeros((), dtype=torch.int32, device=idx.device) if self.check_ids else None
         block = Fn.embed_gather(self.embeddings, self.offsets, idx, sizes=self.sizes, frozen=self.frozen,
-                                sparse_grad=self.sparse_grad, oob_count=oob, layout_key=self._layout_key)  # [B,F,K]
+                                sparse_grad=self.sparse_grad, oob_count=oob, layout_key=self._layout_key,
+                                emit_xt=self.emit_xt)  # [B,F,K]
         if oob is not None and int(oob) > 0:
             bad = ((idx < 0) | (idx >= self.sizes)).nonzero()[0].tolist()
             raise IndexError("SparseEmbed: %d ids outside their vocabulary, first at sample %d, field %s (id %d, word_size %d)"

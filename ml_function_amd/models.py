@@ -12,6 +12,7 @@ import torch
 from .layers import (CIN, AttentionBaseLayer, CrossLayer, DnnLayer, FmLayer, InnerLayer, IPnnLayer, MergeScoreLayer,
                      MultHeadAttentionLayer, OPnnLayer, ScoreLayer, SparseEmbed, StackLayer)
 from .layers.base import Layer
+from .layers.interactive_layer import pack_fields
 from .layers.core_layer import keras_add
 
 sparseFea = namedtuple("sparseFea", ["fea_name", "word_size", "input_dim", "cross_unit", "linear_unit", "pre_weight", "mask_zero",
@@ -48,12 +49,13 @@ class FeatureInput(Layer):
     optional linear embeddings) and passes the dense columns through as F_d tensors [B,1]."""
 
     def __init__(self, sparseInfo=None, denseInfo=None, useLinear=False, useAddLinear=False, useFlattenLinear=False,
-                 useFlattenSparse=False):
+                 useFlattenSparse=False, emitXT=False):
         super().__init__()
         self.sparse_info = sparseInfo or []
         self.dense_info = denseInfo or []
         self.use_linear = useLinear
-        self.sparse_embed = SparseEmbed(self.sparse_info, use_flatten=useFlattenSparse) if self.sparse_info else None
+        # emitXT (extension): the embedding gather also writes the block in the layout the CIN kernels read (XDeepFM)
+        self.sparse_embed = SparseEmbed(self.sparse_info, use_flatten=useFlattenSparse, emit_xt=emitXT) if self.sparse_info else None
         self.linear_embed = (SparseEmbed(self.sparse_info, use_flatten=useFlattenLinear, is_linear=True, use_add=useAddLinear)
                              if (useLinear and self.sparse_info) else None)
 
@@ -204,7 +206,7 @@ class XDeepFM(torch.nn.Module):
         self.score = ScoreLayer(use_add=True)
 
     def forward(self, inputFea):
-        cin_inputs = torch.cat(list(inputFea.sparse_embed), dim=1)  # Concatenate(axis=1)
+        cin_inputs = pack_fields(list(inputFea.sparse_embed))    # Concatenate(axis=1); views of one packed block re-pack without a copy
         dnn_inputs = self.stack(list(inputFea.dense_inputs) + list(inputFea.sparse_embed))
         return self.score([inputFea.linear_embed, self.cin(cin_inputs), self.dnn(dnn_inputs)])
 

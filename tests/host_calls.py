@@ -77,6 +77,8 @@ def run(lib):
     expect(lib.fil_embed_row_ids(None, None, None, None, None, 4, 0, None), -1)
     expect(lib.fil_embed_segment_sum(None, None, None, None, None, None, 5, 300, None), -4)
     expect(lib.fil_embed_run_sum(None, None, None, None, 0, 8, None), 0)
+    expect(lib.fil_embed_gather_xt(None, None, None, None, None, None, None, 4, 3, 8, None), -1)
+    expect(lib.fil_embed_gather_xt(None, None, None, None, None, None, None, 0, 3, 8, None), 0)
     # the profiler's text protocol (no launches recorded: an empty table, correctly terminated, whatever the buffer size)
     assert lib.fil_profile_begin(b"cin_fwd_l,attn") == 0
     buf = ctypes.create_string_buffer(64)

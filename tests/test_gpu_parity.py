@@ -872,3 +872,58 @@ def test_roctx_ranges_opt_in():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+def test_embed_gather_xt_and_cin_transposed_input():
+    """N1 fused into its consumer: fil_embed_gather_xt writes the packed block AND its [B*K, F] transpose in one pass (bit-exact
+    row copies, out-of-range ids -> zero rows in both), and the CIN kernels read that transpose in place
+    (FIL_CIN_X_TRANSPOSED): outputs and every gradient are bit-identical to the path that transposes x itself."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(21)
+    vocab = [7, 40, 3, 11, 5, 9]
+    B, K, conv = 37, 8, [16, 24, 8]
+    F = len(vocab)
+    table = dev(rng.standard_normal((sum(vocab), K)).astype(np.float32)).requires_grad_()
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(vocab)[:-1]]), device="cuda")
+    sizes = torch.tensor(vocab, device="cuda")
+    idx = np.stack([rng.integers(0, v, B) for v in vocab], 1)
+    idx[2, 1] = 40          # out of range: zero row in both layouts
+    idx_t = torch.tensor(idx, device="cuda")
+    cnt = torch.zeros((), dtype=torch.int32, device="cuda")
+    blk = Fn.embed_gather(table, offsets, idx_t, sizes=sizes, emit_xt=True, oob_count=cnt)
+    ref = Fn.embed_gather(table, offsets, idx_t, sizes=sizes)
+    assert int(cnt) == 1 and torch.equal(blk.detach(), ref.detach())
+    xt = blk._fil_xt
+    assert tuple(xt.shape) == (B * K, F) and torch.equal(xt, ref.detach().permute(0, 2, 1).reshape(B * K, F))
+    c = synth.cin_case(B, F, K, conv, dist="uniform")
+    for mode in (0, 1, 2):
+        res = []
+        for use_xt in (False, True):
+            x = ref.detach().clone().requires_grad_()
+            Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+            bs = [dev(b).requires_grad_() for b in c["bs"]]
+            dw, db = dev(c["dense_w"]).requires_grad_(), dev(c["dense_b"]).requires_grad_()
+            out = Fn.cin(x, Ws, bs, dw, db, output_dim=1, mode=mode, xt=xt if use_xt else None)
+            out.backward(dev(c["g"]))
+            res.append([out.detach(), x.grad] + [w.grad for w in Ws] + [b.grad for b in bs] + [dw.grad, db.grad])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    # through the layers: SparseEmbed(emit_xt=True) -> CIN picks the transpose up from the re-packed views
+    from ml_function_amd.layers import CIN, SparseEmbed
+    from ml_function_amd.layers.interactive_layer import pack_fields
+    from ml_function_amd.models import make_sparse_info
+    info = make_sparse_info(vocab, embed_dim=K)
+    outs = []
+    for emit in (False, True):
+        torch.manual_seed(5)
+        emb = SparseEmbed(info, use_flatten=False, emit_xt=emit)
+        cin = CIN(conv_size=conv, output_dim=1)
+        views = emb(idx_t.clamp(max=2))       # (every id valid for every field)
+        if emit:
+            assert getattr(views[0]._base, "_fil_xt", None) is not None
+        y = cin(pack_fields(views))
+        y.sum().backward()
+        outs.append((y.detach(), emb.embeddings.grad.clone(), [p.grad.clone() for p in cin.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
