@@ -422,7 +422,9 @@ def product_attention(q, k, v, use_scale=False, mask=None, mask_mod=1):
 # --------------------------------------------------------------------------------------------- N1  embeddings
 # (sorted row ids, permutation) of the most recent index tensors.  A model usually looks the SAME ids up in two tables (the
 # embeddings and the linear weights): their gradients need the same sort.  An entry keeps its idx tensor alive, so an equal
-# (data_ptr, _version) really is the same contents; in-place updates bump the version and miss.
+# (data_ptr, _version) really is the same contents; in-place updates bump the version and miss -- and every gather (forward)
+# empties the cache, so that an entry only ever serves the backward passes that follow the forwards which saw these ids
+# (an update of idx that bypasses the version counter, e.g. through `.data`, cannot meet a stale entry).
 _SORT_CACHE = []
 
 
@@ -476,6 +478,7 @@ class _EmbedFn(torch.autograd.Function):
         offsets = offsets.to(torch.int64).contiguous()
         B, F = idx.shape
         K = table.shape[1]
+        del _SORT_CACHE[:]
         out = torch.empty((B, F, K), dtype=torch.float32, device=table.device)
         if xt_out is not None:     # both layouts in one pass: the packed block and its [B*K, F] transpose (fil.h)
             check(_lib.load().fil_embed_gather_xt(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(xt_out), ptr(oob_count),
