@@ -550,7 +550,7 @@ def main():
                          "fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate) for every layer's fwd/dW/dZ incl. the "
                          "pair-symmetric first layer; same 1e-5 / 2e-5 parity bars as the exact mode, green at this shape and "
                          "over 1e-36..1e30 magnitudes, subnormal and non-finite inputs "
-                         "(tests/test_gpu_parity.py::test_cin_split_promotion_*, test_cin_bench_shape_*; DESIGN.md 4.1)",
+                         "(tests/test_gpu_parity.py::test_cin_split_promotion_*, test_cin_at_the_benchmark_shape; DESIGN.md 4.1)",
                  "value": world * shape["batch"] * args.steps / dt2 if args.scaling == "weak" else ns["shape"]["batch"] * args.steps / dt2,
                  "unit": "samples/s", "ms_per_step": dt2 / args.steps * 1e3,
                  "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(prof2.items())}}
