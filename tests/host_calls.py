@@ -79,6 +79,8 @@ def run(lib):
     expect(lib.fil_embed_run_sum(None, None, None, None, 0, 8, None), 0)
     expect(lib.fil_embed_gather_xt(None, None, None, None, None, None, None, 4, 3, 8, None), -1)
     expect(lib.fil_embed_gather_xt(None, None, None, None, None, None, None, 0, 3, 8, None), 0)
+    one = ctypes.c_void_p(8)   # (never dereferenced: the LDS limit is checked before the launch)
+    expect(lib.fil_embed_gather_xt(one, one, None, one, one, one, None, 4, 400, 64, None), -4, b"LDS")
     # the profiler's text protocol (no launches recorded: an empty table, correctly terminated, whatever the buffer size)
     assert lib.fil_profile_begin(b"cin_fwd_l,attn") == 0
     buf = ctypes.create_string_buffer(64)

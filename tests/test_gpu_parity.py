@@ -895,6 +895,11 @@ def test_embed_gather_xt_and_cin_transposed_input():
     assert int(cnt) == 1 and torch.equal(blk.detach(), ref.detach())
     xt = blk._fil_xt
     assert tuple(xt.shape) == (B * K, F) and torch.equal(xt, ref.detach().permute(0, 2, 1).reshape(B * K, F))
+    # an odd embedding width and a single field (scalar path of the plain gather, one LDS row per sample)
+    t2 = dev(rng.standard_normal((9, 5)).astype(np.float32))
+    off2, i2 = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor(rng.integers(0, 9, (11, 1)), device="cuda")
+    b2 = Fn.embed_gather(t2, off2, i2, emit_xt=True)
+    assert torch.equal(b2, Fn.embed_gather(t2, off2, i2)) and torch.equal(b2._fil_xt, b2.permute(0, 2, 1).reshape(55, 1))
     c = synth.cin_case(B, F, K, conv, dist="uniform")
     for mode in (0, 1, 2):
         res = []
