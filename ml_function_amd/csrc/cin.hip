@@ -331,8 +331,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         if (fuse_next) {
           FIL_CHECK_ARG(W[l + 1] && bias[l + 1]);
           float* wsn_buf = Wf + (size_t)npack;   // behind this layer's packed weights
-          hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hl * F, 8)), dim3(256), 0, st, W[l + 1], wsum, Hl * F, H[l + 1]);
-          hipLaunchKernelGGL(cin_pack_wsn_kernel, dim3(cdiv(chunks * 2 * JT * 128, 256)), dim3(256), 0, st, wsum, wsn_buf, Hl, F, 2 * JT, chunks);
+          hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hl * F, 8)), dim3(256), 0, st, W[l + 1], wsum, Hl * F, H[l + 1], wsn_buf, Hl, F, 2 * JT,
+                             chunks);
           wsn = wsn_buf;
           pa.chunks[l + 1] = chunks;
           fused_last = true;
@@ -446,7 +446,10 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
     const size_t shw = (size_t)Hp * ((F + 3) & ~3) * sizeof(float);
     ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hp * F);
-    hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hp * F, 8)), dim3(256), 0, st, W[l], wsum, Hp * F, Hl);
+    // (l > 0: wsum also in the MFMA operand layout of cin_last_bwd2_kernel -- the dZ kernels' packed-W buffer is idle until
+    // the first general layer packs into it, and nothing between here and that kernel touches it)
+    hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hp * F, 8)), dim3(256), 0, st, W[l], wsum, Hp * F, Hl, l > 0 ? Wz : nullptr, Hp, F, 2 * JT,
+                       chunks_of(Hp));
     hipLaunchKernelGGL(cin_slice_sum_kernel, dim3(nblk), dim3(256), 0, st, dPl, (int)LK, small, B, K, kHeadChunk);
     hipLaunchKernelGGL(cin_fill_sum_kernel, dim3(1), dim3(256), 0, st, small, nblk, dbias[l], Hl);
     // dW_L[c,:] = v[c],  v[h,f] = sum_m x^{L-1}[m,h] * (x[m,f] dP[m]): the weight-gradient kernel with a single
@@ -470,9 +473,6 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ready(l);
     // G^{L-1} and dX
     if (l > 0) {
-      // (the dZ kernels' packed-W buffer is idle here: scratch for wsum in the MFMA operand layout)
-      const int chunks = chunks_of(Hp);
-      hipLaunchKernelGGL(cin_pack_wsn_kernel, dim3(cdiv(chunks * 2 * JT * 128, 256)), dim3(256), 0, st, wsum, Wz, Hp, F, 2 * JT, chunks);
       cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPl, (int)LK, dPprev, Gbuf[cur], s.HS(l - 1), dxT, (int)M, F, K, Hp);
     } else {
       const size_t shb = shw + (size_t)kLastRows * (kLastFMax + 1) * sizeof(float);

@@ -1469,15 +1469,29 @@ static __global__ __launch_bounds__(256) void cin_wsum_kernel(const float* __res
   if (row < C && l == 0) wsum[row] = t;
 }
 
-// wsn[chunk][fp < JT2][128] = wsum[(chunk*128 + col)*F + fp]  (zero for fp >= F or n >= Hp): the last layer's pooled
-// weights in the operand layout of the forward kernel (see the fused epilogue of cin_fwd3_kernel)
-static __global__ __launch_bounds__(256) void cin_pack_wsn_kernel(const float* __restrict__ wsum, float* __restrict__ wsn, int Hp, int F, int JT2,
-                                                           int chunks) {
-  const int total = chunks * JT2 * 128;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int col = i & 127, fp = (i >> 7) % JT2, chunk = (i >> 7) / JT2;
-    const int n = chunk * 128 + col;
-    wsn[i] = (fp < F && n < Hp) ? wsum[n * F + fp] : 0.f;
+// wsum and, when wsn != nullptr, its copy in the forward kernel's operand layout, wsn[chunk][fp < JT2][128] = wsum[(chunk*128 + col)*F + fp], from ONE launch: the
+// workgroup that sums row (n, fp) of W also stores it at wsn[chunk][fp][col]; the padding of wsn (fp >= F, n >= Hp) is zeroed
+// by a grid-stride pass over its index space.  (A kernel this small costs its ~4.5 us of dispatch, not its work.)
+static __global__ __launch_bounds__(256) void cin_wsum_wsn_kernel(const float* __restrict__ W, float* __restrict__ wsum, int C, int H,
+                                                           float* __restrict__ wsn, int Hp, int F, int JT2, int chunks) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  float t = 0.f;
+  if (row < C)
+    for (int n = l; n < H; n += 32) t += W[(long)row * H + n];
+  t = half_wave_sum(t);
+  if (row < C && l == 0) {
+    wsum[row] = t;
+    if (wsn != nullptr) {
+      const int n = row / F, fp = row - n * F;          // row = n*F + fp (n < Hp, fp < F)
+      wsn[(((n >> 7) * JT2) + fp) * 128 + (n & 127)] = t;
+    }
+  }
+  if (wsn != nullptr) {
+    const int total = chunks * JT2 * 128;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const int col = i & 127, fp = (i >> 7) % JT2, chunk = (i >> 7) / JT2;
+      if (fp >= F || chunk * 128 + col >= Hp) wsn[i] = 0.f;
+    }
   }
 }
 
@@ -1604,7 +1618,7 @@ static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* 
 // MFMA form of the last layer's data gradients (mode 0, L >= 2; the VALU kernel above stays for L == 1):
 //   t[m,n] = sum_f x[m,f] wsum[n,f]         -> G^{L-1}[m,n] = dP[m] t[m,n] + dPprev[m]     (A = x fragment, B = wsn)
 //   u[m,f] = sum_h x^{L-1}[m,h] wsum[h,f]   -> dX[m,f]      = dP[m] u[m,f]                 (A = the lane's x^{L-1} row)
-// Wave = 32 rows.  wsn is wsum in the forward kernel's operand layout (cin_pack_wsn_kernel) so lane r owns columns
+// Wave = 32 rows.  wsn is wsum in the forward kernel's operand layout (cin_wsum_wsn_kernel) so lane r owns columns
 // 4r..4r+3 of a chunk and G^{L-1} leaves as 16-byte stores; for u the reduction order is permuted (free in a GEMM)
 // so that wave half `half` takes h = 4q + 2*half + {0,1}: one 8-byte load of its own row per two steps.
 template <int JT>
