@@ -451,7 +451,6 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hp * F, 8)), dim3(256), 0, st, W[l], wsum, Hp * F, Hl, l > 0 ? Wz : nullptr, Hp, F, 2 * JT,
                        chunks_of(Hp));
     hipLaunchKernelGGL(cin_slice_sum_kernel, dim3(nblk), dim3(256), 0, st, dPl, (int)LK, small, B, K, kHeadChunk);
-    hipLaunchKernelGGL(cin_fill_sum_kernel, dim3(1), dim3(256), 0, st, small, nblk, dbias[l], Hl);
     // dW_L[c,:] = v[c],  v[h,f] = sum_m x^{L-1}[m,h] * (x[m,f] dP[m]): the weight-gradient kernel with a single
     // all-ones field (F' = 1, so c = h) and G' = x * dP ([M][128], zero padded) as its right-hand side
     {
@@ -467,8 +466,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       if (swap) nb = launch_dw3(st, dw_plan(M, F, Hp), xpT, xps, nullptr, yT, YS, part, M, /*F=*/1, /*Hp=*/F, /*H=*/Hp);
       else nb = launch_dw3(st, dw_plan(M, Hp, F), yT, YS, nullptr, xpT, xps, part, M, /*F=*/1, Hp, /*H=*/F);
       hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)cl, 64)), dim3(256), 0, st, part, vlast, (long)cl, nb);
+      // (the same launch finishes dbias_L from the slice sums above)
       hipLaunchKernelGGL(cin_fill_rows_kernel, dim3((int)std::min<long>(((long)cl * Hl + 255) / 256, 2048)), dim3(256), 0, st, vlast, dW[l], (long)cl, Hl,
-                         swap ? F : 0, Hp);
+                         swap ? F : 0, Hp, small, nblk, dbias[l]);
     }
     ready(l);
     // G^{L-1} and dX

@@ -1434,21 +1434,6 @@ static __global__ __launch_bounds__(256) void cin_slice_sum_kernel(const float* 
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-// dbias[n] = sum_p part[p] for every n < H
-static __global__ __launch_bounds__(256) void cin_fill_sum_kernel(const float* __restrict__ part, int parts, float* __restrict__ dbias, int H) {
-  __shared__ float red[256];
-  float t = 0.f;
-  for (int p = threadIdx.x; p < parts; p += 256) t += part[p];   // (every thread used to walk all partials serially)
-  red[threadIdx.x] = t;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  const float tot = red[0];
-  for (int n = threadIdx.x; n < H; n += 256) dbias[n] = tot;
-}
-
 // =================================================================================================
 // Last-layer shortcut.  The last feature map x^L is only ever sum-pooled over its feature-map axis n
 // (reference :322), so with wsum[c] = sum_n W_L[c,n]:
@@ -1606,8 +1591,24 @@ static __global__ __launch_bounds__(256) void cin_last_bwd_kernel(const float* _
 }
 
 // dW[c,n] = v[c] for every n;  Ft > 0: v arrives transposed, v^T [Ft][Hp], c = h*Ft + f
+// bpart != nullptr: workgroup 0 also finishes the layer's dbias (the same value for every n: the sum of the `bparts` slice
+// partials, folded through LDS in a fixed order) -- one launch less
 static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* __restrict__ v, float* __restrict__ dW, long C, int H, int Ft,
-                                                            int Hp) {
+                                                            int Hp, const float* __restrict__ bpart = nullptr, int bparts = 0,
+                                                            float* __restrict__ dbias = nullptr) {
+  if (bpart != nullptr && blockIdx.x == 0) {
+    __shared__ float red[256];
+    float t = 0.f;
+    for (int p = threadIdx.x; p < bparts; p += 256) t += bpart[p];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float tot = red[0];
+    for (int n = threadIdx.x; n < H; n += 256) dbias[n] = tot;
+  }
   const long total = C * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long c = i / H;
