@@ -70,8 +70,9 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(sample_b=1024, steps=10):
-    """Reference-graph restatement (oracle/graph.py) on the host CPU, fp32, all cores, bounded sample."""
+def cpu_baseline(sample_b=B_PER_GPU, steps=3):
+    """Reference-graph restatement (oracle/graph.py) on the host CPU, fp32, all usable cores: the benchmark's own batch
+    (B=4096, BASELINE.md section 2 protocol), 1 warm-up + 3 timed steps (a step is seconds of CPU work), median."""
     from ml_function_amd import synth
     from oracle import graph
     torch.set_num_threads(usable_cpus())
@@ -90,8 +91,9 @@ def cpu_baseline(sample_b=1024, steps=10):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times[1:]))
     return dict(value=sample_b / med, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample="B=%d of the same config (F=39,K=16,3x128), %d timed fwd+bwd steps after 1 warm-up, fp32, "
-                       "op-for-op torch-CPU restatement of the reference TF2 graph (TF not installable)" % (sample_b, steps))
+                sample="the full batch B=%d of the same config (F=39,K=16,3x128), %d timed fwd+bwd steps after 1 warm-up (median %.2f s "
+                       "per step), fp32, op-for-op torch-CPU restatement of the reference TF2 graph with the outer product "
+                       "materialised as TF would (TF not installable)" % (sample_b, steps, med))
 
 
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
@@ -168,11 +170,11 @@ def deepfm_benchmark(args):
         graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
     name = ("xDeepFM whole model (linear + CIN 3x128 + MLP 256-128-64) fwd+bwd, 39 fields K=16, fp32, B=%d" % B if xd else
             "DeepFM (FM + MLP 256-128) whole-model fwd+bwd, 39 fields K=16, bf16, B=%d (BASELINE.json configs[1])" % B)
-    print(json.dumps({"metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
-                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "f32" if xd else "bf16 (fp32 accumulate)", "data": "synthetic",
-                      "config": {"workload": name}, "hipgraph_replay_ms_per_step": graph_ms,
-                      "hipgraph_samples_per_s": (B / (graph_ms * 1e-3)) if graph_ms else None}))
+    return {"metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if xd else "bf16 (fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": name}, "hipgraph_replay_ms_per_step": graph_ms,
+            "hipgraph_samples_per_s": (B / (graph_ms * 1e-3)) if graph_ms else None}
 
 
 def side_benchmark(args):
@@ -279,7 +281,7 @@ def side_benchmark(args):
         rate = d["work"] / (d["avg_ms"] * 1e-3)
     peak, unit, ach = PEAK_HBM_GBPS, "GB/s", rate / 1e9
     traffic, traffic_src = side_traffic(name, dom)
-    print(json.dumps({
+    return ({
         "metric": "samples/sec fwd+bwd " + name, "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16 products, f32 accumulate" if f16 else "f32", "data": "synthetic",
@@ -290,7 +292,37 @@ def side_benchmark(args):
         **extra,
         "kernels": {k: dict(avg_ms=round(v["avg_ms"], 4), work=v["work"]) for k, v in sorted(ks.items())},
         "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in ks.values()) / args.steps,
-        "hipgraph_replay_ms_per_step": graph_ms}))
+        "hipgraph_replay_ms_per_step": graph_ms})
+
+
+def side_workloads(args):
+    """The other BASELINE configs, a few steps each, AFTER the headline's timed region and in the same process (so the driver's
+    one run timestamps them): c2 DeepFM whole model bf16, c3 DCN cross layers, c5 AutoInt 3-layer f16-MFMA stack, and the
+    north-star layer inside its model (xDeepFM).  Compact: ms_per_step, samples/s, the dominant kernel's roofline fraction."""
+    import copy
+    out = {}
+    for name, kw in (("c2_deepfm_bf16", dict(workload="deepfm", graph=True)), ("c3_dcn", dict(workload="dcn", graph=True)),
+                     ("c5_autoint_f16_L3", dict(workload="autoint", precision="f16_mfma", layers=3, graph=False)),
+                     ("c4_xdeepfm_whole_model", dict(workload="xdeepfm", graph=True))):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.batch = 10, 3, 0
+        for k, v in kw.items():
+            setattr(a, k, v)
+        try:
+            r = deepfm_benchmark(a) if a.workload in ("deepfm", "xdeepfm") else side_benchmark(a)
+            e = {"workload": r["config"]["workload"], "ms_per_step": round(r["ms_per_step"], 4), "samples_per_s": round(r["value"], 1),
+                 "dtype": r["dtype"], "steps": a.steps}
+            if r.get("hipgraph_replay_ms_per_step"):
+                e["hipgraph_replay_ms_per_step"] = round(r["hipgraph_replay_ms_per_step"], 4)
+            if "roofline" in r:
+                e["roofline"] = {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+            if "valu_roofline" in r:
+                e["valu_issue_frac"] = r["valu_roofline"]["frac_per_kernel"]
+            out[name] = e
+        except Exception as exc:     # a side workload must never take the headline line down with it
+            out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
+    return out
 
 
 def side_traffic(workload_name, kernel_scope):
@@ -325,20 +357,27 @@ def pmc_traffic(scope):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
-    m = re.match(r"cin_(fwd|bwd_dz|bwd_dw)_l(\d)$", scope)
+    m = re.match(r"cin_(fwd|bwd_dz|bwd_dw)_(l\d|tail)$", scope)
     if not files or not m:
         return None, None
-    prefix = {"fwd": "cin_fwd3_kernel", "bwd_dz": "cin_dz3_kernel", "bwd_dw": "cin_dw3_kernel<1,false"}[m.group(1)]
     with open(files[-1]) as fh:
         per = json.load(fh)["per_launch"]
+    src = "committed profile " + os.path.basename(files[-1])
+    if m.group(2) == "tail":
+        prefix = {"fwd": "cin_tail_fwd_kernel", "bwd_dz": "cin_tail_dz_kernel", "bwd_dw": "cin_tail_dw_kernel"}[m.group(1)]
+        hits = [v["hbm_bytes"] for k, v in per.items() if k.startswith(prefix)]
+        return (hits[0], src) if len(hits) == 1 else (None, None)
+    prefix = {"fwd": "cin_fwd3_kernel", "bwd_dz": "cin_dz3_kernel", "bwd_dw": "cin_dw3_kernel<1,false"}[m.group(1)]
     # (template instantiations whose last argument is SPLIT = true belong to the split-bf16 experiment, not to the headline)
     hits = sorted((v["first_dispatch"], v["hbm_bytes"]) for k, v in per.items()
                   if k.startswith(prefix) and not k.split(" grid=")[0].endswith(",true>"))
+    if len(hits) == 1:
+        return hits[0][1], src
     if len(hits) != 2:
         return None, None
     # two MFMA layers (l = 1, 2): the forward visits l1 then l2, the backward l2 then l1
     first_is_l1 = m.group(1) == "fwd"
-    return hits[0 if (m.group(2) == "1") == first_is_l1 else 1][1], "committed profile " + os.path.basename(files[-1])
+    return hits[0 if (m.group(2) == "l1") == first_is_l1 else 1][1], src
 
 
 def mfma_util(scope):
@@ -390,6 +429,11 @@ class stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:   # RCCL prints through C stdio, which is block-buffered when stdout is a file or pipe: flush it while fd 1 still
+            import ctypes   # points at stderr, or the banner comes out at exit, behind the JSON line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
 
@@ -409,6 +453,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the compact side_workloads block (configs 2, 3, 5 + the whole model)")
     ap.add_argument("--workload", default="cin", choices=["cin", "fm", "dcn", "autoint", "deepfm", "xdeepfm"],
                     help="cin = the headline benchmark (default); the others are single-GPU side benchmarks of the "
                          "remaining hot-path rows (BASELINE.json configs 2, 3, 5)")
@@ -425,9 +470,11 @@ def main():
     ap.add_argument("--stub", default="", help=argparse.SUPPRESS)   # tests: module with install(namespace) -> CPU/gloo stand-ins
     args = ap.parse_args()
     if args.workload in ("deepfm", "xdeepfm"):
-        return deepfm_benchmark(args)
+        print(json.dumps(deepfm_benchmark(args)))
+        return 0
     if args.workload != "cin":
-        return side_benchmark(args)
+        print(json.dumps(side_benchmark(args)))
+        return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
 
@@ -465,7 +512,7 @@ def main():
         shape["batch"] = hi - lo
     inp = make_inputs(rank, device, **shape)
     flat, grads, segments = make_bucket(inp, device)
-    reducer = dp.LayerwiseAllReduce(flat, segments if not args.no_overlap else [(0, flat.numel())])
+    reducer = dp.LayerwiseAllReduce(flat, segments if not args.no_overlap else [(0, flat.numel())], force=args.force_collective)
     L = len(inp["Ws"])
     # event i of the reducer <-> the library's grad_ready slot: segment 0 = head + top layer (ready with layer L-1), ...
     ready = None
@@ -495,24 +542,30 @@ def main():
         if device.type == "cuda":
             torch.cuda.synchronize()
 
-    def max_over_ranks(dt):
+    per_rank = {}
+
+    def max_over_ranks(dt, tag=None):
         if not use_dist:
             return dt
         t = torch.tensor([dt], dtype=torch.float64, device=device)
+        if tag is not None:      # every rank's own time of the headline region (the JSON carries min / max / all of them)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank[tag] = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     prof_on = ns["profile"]
     if prof_on:
         from ml_function_amd import _lib
-    GEMMS = "cin_fwd_l,cin_bwd_dw_l,cin_bwd_dz_l"
+    GEMMS = "cin_fwd_,cin_bwd_dw_,cin_bwd_dz_"     # the MFMA GEMM scopes: _l1 (pair-symmetric first layer), _l2.., _tail (fused tail)
     for _ in range(args.warmup):
         step()
     # timed region: HIP events around the three GEMM kernels of every layer only (an event pair costs ~5 us of
     # stream time; with all 13 scopes recorded the step is 2.3 % slower)
     if prof_on:
         _lib.profile_begin(GEMMS)
-    dt = max_over_ranks(timed_steps(step, fence, args.steps))
+    dt = max_over_ranks(timed_steps(step, fence, args.steps), tag="headline")
     prof = _lib.profile_end() if prof_on else {}
 
     # collective evidence: the same steps without the all-reduce (exposed = difference) and the collectives alone
@@ -533,6 +586,10 @@ def main():
                 "allreduce_bytes": int(flat.numel() * 4), "segments_bytes": [int((b - a) * 4) for a, b in reducer.segments],
                 "overlap": "per layer on a side stream, from the top layer down (fil.h grad_ready_events)" if not args.no_overlap
                            else "none: one all-reduce after the backward",
+                "collectives_forced_at_world_size_1": bool(args.force_collective and world == 1),
+                "ms_per_step_per_rank": [t / args.steps * 1e3 for t in per_rank.get("headline", [])],
+                "ms_per_step_min_rank": min(per_rank["headline"]) / args.steps * 1e3 if per_rank.get("headline") else None,
+                "ms_per_step_max_rank": max(per_rank["headline"]) / args.steps * 1e3 if per_rank.get("headline") else None,
                 "allreduce_alone_ms": dt_comm / args.steps * 1e3,
                 "step_without_allreduce_ms": dt_nocomm / args.steps * 1e3,
                 "exposed_allreduce_ms": (dt - dt_nocomm) / args.steps * 1e3}
@@ -556,10 +613,10 @@ def main():
                  "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(prof2.items())}}
         dom2 = max(prof2, key=lambda k: prof2[k]["total_ms"])
         # priced as what the pipe executes: 6 bf16 MFMA products per algorithmic multiply-add, against the dense bf16 peak
-        exe = 6.0 * prof2[dom2]["work"] / (prof2[dom2]["avg_ms"] * 1e-3) / 1e12
+        exe = 6.0 * prof2[dom2]["executed"] / (prof2[dom2]["avg_ms"] * 1e-3) / 1e12
         split["roofline"] = {"bound": "mfma", "kernel": dom2, "achieved": exe, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": exe / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": prof2[dom2]["avg_ms"],
-                             "flops_per_launch": prof2[dom2]["work"], "executed_flops_per_launch": 6.0 * prof2[dom2]["work"]}
+                             "flops_per_launch": prof2[dom2]["executed"], "executed_flops_per_launch": 6.0 * prof2[dom2]["executed"]}
     # separate, untimed pass with every scope recorded: the per-kernel table of the small kernels
     prof_all, n_all = {}, max(2, args.steps // 4)
     if prof_on:
@@ -583,21 +640,31 @@ def main():
                        "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if use_dist else 0},
         }
         if prof:
-            # dominant kernel = largest total time among the MFMA kernels
-            mf = {k: v for k, v in prof.items() if k.startswith(("cin_fwd_l", "cin_bwd_dw_l", "cin_bwd_dz_l"))}
+            # dominant kernel = largest total time among the MFMA GEMM scopes.  Every rate below is priced on EXECUTED flops --
+            # the products the kernel's algorithm really performs (pair-symmetric first layer: F(F/2+1) of the F^2 channels;
+            # fused tail: F+1 instead of H columns; no padding counted) -- so nothing here can exceed the pipe's peak; the
+            # algorithmic flops of the reference graph's step that a scope stands for are reported next to them.
+            is_gemm = lambda k: k.startswith(("cin_fwd_", "cin_bwd_dw_", "cin_bwd_dz_"))
+            mf = {k: v for k, v in prof.items() if is_gemm(k)}
             dom = max(mf, key=lambda k: mf[k]["total_ms"])
             d = mf[dom]
-            achieved = d["work"] / (d["avg_ms"] * 1e-3) / 1e12
-            kernels = {k: dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / n_all,
-                               tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2) if k in mf else None)
-                       for k, v in sorted(prof_all.items())}
+            tf = lambda flops, ms: flops / (ms * 1e-3) / 1e12
+            achieved = tf(d["executed"], d["avg_ms"])
+            kernels = {}
+            for k, v in sorted(prof_all.items()):
+                kernels[k] = dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / n_all)
             for k, v in mf.items():  # the GEMM kernels: numbers of the timed region itself
                 kernels[k] = dict(avg_ms=round(v["avg_ms"], 4), launches_per_step=v["count"] / args.steps,
-                                  tflops=round(v["work"] / (v["avg_ms"] * 1e-3) / 1e12, 2))
+                                  executed_flops_per_launch=v["executed"], executed_tflops=round(tf(v["executed"], v["avg_ms"]), 2),
+                                  executed_frac_of_peak=round(tf(v["executed"], v["avg_ms"]) / PEAK_F32_MFMA_TFLOPS, 4),
+                                  algorithmic_flops_per_launch=v["work"])
             traffic, traffic_src = pmc_traffic(dom)
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                               "traffic_source": traffic_src, "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["work"]}
+                               "traffic_source": traffic_src, "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["executed"],
+                               "flops_are": "executed by the kernel (exact fp32 MFMA products, padding not counted); the reference "
+                                            "graph spends algorithmic_flops_per_launch on the same step",
+                               "algorithmic_flops_per_launch": d["work"]}
             util = mfma_util(dom)
             if util is not None:
                 res["roofline"].update(util)
@@ -605,10 +672,20 @@ def main():
                 res["roofline"]["hbm_frac"] = traffic / (d["avg_ms"] * 1e-3) / (PEAK_HBM_GBPS * 1e9)
             res["kernels"] = kernels
             res["gpu_kernel_ms_per_step"] = sum(v["total_ms"] for v in prof_all.values()) / n_all
+            # whole step: executed MFMA flops of all GEMM scopes over the step time (the small VALU kernels add ~1 %)
+            exe_step = sum(v["executed"] * v["count"] for v in mf.values()) / args.steps
+            sh = shape
+            algo_step = 3.0 * 2.0 * sh["embed"] * sh["batch"] * sum(
+                (sh["fields"] if l == 0 else sh["conv"][l - 1]) * sh["fields"] * h for l, h in enumerate(sh["conv"]))
+            res["executed_flops_per_step"] = exe_step
+            res["algorithmic_flops_per_step"] = algo_step
+            res["executed_frac"] = exe_step / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12)
         if rccl is not None:
             res["rccl"] = rccl
         if split is not None:
             res["candidate_split_bf16"] = split
+        if world == 1 and not args.stub and not args.no_side:
+            res["side_workloads"] = side_workloads(args)
         if not args.no_cpu_baseline and world == 1 and not args.stub:  # reported at N=1 only (rank 0)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -69,6 +69,8 @@ def main():
     model(torch.tensor(table[0][:args.batch], device=device) if use_dense else None,
           torch.tensor(table[1][:args.batch], device=device))  # builds the lazily created weights
     tables = [p for n, p in model.named_parameters() if n.endswith("embeddings")]
+    # l2(emb_reg) of the tables: added analytically after the sparse exchange (see dp.add_table_l2_grad_), identically per replica
+    table_l2 = {id(m.embeddings): m.table_l2_ranges() for m in model.modules() if hasattr(m, "table_l2_ranges") and m.built}
     others = [p for n, p in model.named_parameters() if not n.endswith("embeddings")]
     opt = torch.optim.Adam(model.parameters(), lr=args.lr, eps=1e-7)      # Keras 'adam' (un_seq.py:61)
     pipe = data.data_pipeline(table, batch_size=args.batch, shuffle_buffer=2048, repeat=2, prefetch=2, seed=rank, device=device)
@@ -77,7 +79,7 @@ def main():
         out = model(dense if use_dense else None, idx)
         p = (out[:, 1] if out.shape[1] == 2 else out[:, 0]).clamp(1e-6, 1 - 1e-6)
         bce = torch.nn.functional.binary_cross_entropy(p, y)
-        loss = (bce + collect_regularization_loss(model)) / world
+        loss = (bce + collect_regularization_loss(model, skip_tables=True)) / world
         loss.backward()
         if world > 1:
             bucket = dp.GradBucket.for_params(others)
@@ -89,6 +91,9 @@ def main():
             for t in tables:
                 if t.grad is not None:
                     dp.exchange_sparse_rows(t.grad, rows)
+        for t in tables:
+            if t.grad is not None and table_l2.get(id(t)):
+                dp.add_table_l2_grad_(t.grad, t.detach(), table_l2[id(t)])
         opt.step()
         if rank == 0 and (step % 20 == 0 or step == len(pipe) - 1):
             print("step %4d  loss %.4f  auc %.4f" % (step, float(bce.detach()), metrics.auc(y, p.detach())), flush=True)

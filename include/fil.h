@@ -39,14 +39,16 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 204
+#define FIL_ABI_VERSION 205
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
 /* Opt-in per-kernel timing for bench.py's roofline line (off by default).  Between begin and end every major
  * kernel launch made through this library is bracketed by HIP events recorded ON THE LAUNCH STREAM.
  * fil_profile_end synchronises those events and writes one text line per kernel name into buf:
- *   "<name> <launches> <total_ms> <algorithmic work per launch: flops for MFMA kernels, bytes for streaming>\n"
+ *   "<name> <launches> <total_ms> <algorithmic work per launch: flops for MFMA kernels, bytes for streaming> <executed work>\n"
+ * (algorithmic = what the reference graph spends on that step; executed = what the kernels really compute -- smaller where an
+ * exact algebraic restructuring removes products, e.g. the pair-symmetric first CIN layer; equal otherwise)
  * and returns the number of bytes needed (including the NUL).  Not for use under graph capture. */
 int fil_profile_begin(const char* filter);   /* filter: "substr[,substr...]" of kernel names to time, NULL = all */
 size_t fil_profile_end(char* buf, size_t cap);
@@ -87,8 +89,10 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *                never materialised).
  *   bwd: g = dL/dout [B] (output_dim==1) or dL/dpooled [B,L*K];
  *        writes dx [B,F,K], dW[l], dbias[l], ddense_w [L*K], ddense_b [1] (dense grads only if output_dim==1).
- *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products) with the last layer contracted against
- *             sum_n W_L[c,n] (its feature map is only ever sum-pooled, so this is the same function at 1/H_L of the flops);
+ *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact fp32 products) with the last layer contracted against
+ *             wsum_L[c] = sum_n W_L[c,n] (its feature map is only ever sum-pooled, so this is the same function at 1/H_L of
+ *             the flops) and, for L >= 3, the layer below it contracted against [1 | wsum_L] (its map is only ever sum-pooled
+ *             or fed to the last layer: F+1 observable columns instead of H_{L-1}; the "fused tail", csrc/cin_tail.h);
  *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
  *         + FIL_CIN_SPLIT_BF16 (2), opt-in and experimental: the three GEMMs (forward, dW, dZ) of the general layers
  *             l >= 1 run on split-bf16 operands (every fp32 value as three bf16 pieces, six bf16 MFMAs with fp32
@@ -97,6 +101,9 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *         + FIL_CIN_X_TRANSPOSED (16), forward and backward alike: `x` is given transposed, [B*K][F] row-major (x_t[(b*K+k)*F+f]
  *           = x[b,f,k], as written by fil_embed_gather_xt): no input transpose, saved's own copy of it stays unused.  dx is
  *           still returned as [B,F,K].
+ *         + FIL_CIN_NOTAIL (32): mode 0 without the fused tail (last layer through wsum_L only: the round-2 path);
+ *           FIL_CIN_TAIL_ALWAYS (64): the fused tail whenever it is defined (L >= 3, F <= 62), also where it saves nothing
+ *           (by default it is used when F+2 columns padded to 16 are at most 3/4 of H_{L-1}); both exist for tests / comparison.
  *         + FIL_CIN_MB2 (4) / FIL_CIN_NOSYM (8): per-call launch-shape overrides (64-row waves in the row-parallel kernels,
  *             i.e. the launch configuration large batches get by themselves; symmetric first-layer kernels off).  Same
  *             function up to summation order; they exist so that tests can reach every instantiation at small sizes.
@@ -104,7 +111,7 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *       dW[l] and dbias[l] are final, [L] once the dense head's gradients are -- from the top layer down, each before the
  *       data-gradient kernel of its layer starts -- so a data-parallel caller can start the all-reduce of a layer's
  *       gradients on another stream while the rest of the backward is still running.
- *   Limits: F <= 64, H_l <= 256, L <= 8, L*K <= 255, B*K <= 2^28.
+ *   Limits: F <= 64, H_l <= 256, L <= 8, B*K <= 2^28.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
 size_t fil_cin_fwd_workspace_bytes(int B, int F, int K, int L, const int* H);
@@ -145,7 +152,8 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
-enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16 };
+enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
+                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);

@@ -126,12 +126,14 @@ def profile_begin(filter=None):
 
 
 def profile_end():
-    """Returns {kernel name: dict(count, total_ms, avg_ms, work)} for the launches since profile_begin()."""
+    """Returns {kernel name: dict(count, total_ms, avg_ms, work, executed)} for the launches since profile_begin():
+    work = algorithmic flops / bytes per launch (the reference graph's), executed = what the kernels of the scope compute."""
     lib = load()
     buf = ctypes.create_string_buffer(1 << 16)
     lib.fil_profile_end(buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
-        name, count, ms, work = line.split()
-        out[name] = dict(count=int(count), total_ms=float(ms), avg_ms=float(ms) / max(int(count), 1), work=float(work))
+        name, count, ms, work, executed = line.split()
+        out[name] = dict(count=int(count), total_ms=float(ms), avg_ms=float(ms) / max(int(count), 1), work=float(work),
+                         executed=float(executed))
     return out

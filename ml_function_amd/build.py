@@ -27,8 +27,26 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _flags_changed(obj_dir, flags):
+    """The object cache is keyed on source mtimes; the compiler flags (FIL_HIPCC_FLAGS changes codegen) are remembered in a
+    stamp file next to the objects, and a mismatch rebuilds everything -- a diagnostic build (e.g. -DFIL_ATTN_STAMPS) can then
+    never linger in libfil_hip.so under a later plain build."""
+    stamp = os.path.join(obj_dir, "flags.stamp")
+    want = " ".join(flags)
+    try:
+        with open(stamp) as fh:
+            same = fh.read() == want
+    except OSError:
+        same = not any(f.endswith(".o") for f in os.listdir(obj_dir))   # fresh directory: nothing stale to distrust
+    if not same:
+        with open(stamp, "w") as fh:
+            fh.write(want)
+    return not same
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _flags_changed(OBJ, FLAGS)
     hdr_m = _deps_mtime()
     jobs = []
     objs = []

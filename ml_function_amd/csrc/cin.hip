@@ -8,6 +8,7 @@
 //         per remaining layer: dbias (column sums of G), cin_dw3 (+ fixed-order reduce) -> dW_l,
 //         pack W_l -> Wz, cin_dz3 -> G^{l-1}, dX;   finally dxT (+ Gx^0) --transpose--> dx [B,F,K]
 #include "cin_kernels.h"
+#include "cin_tail.h"
 #include "cin_launch.h"
 
 #include <stdlib.h>
@@ -53,14 +54,15 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_MB=1|2        rows per wave (x32) of the row-parallel kernels (default: by M)
 //   FIL_CIN_SYM=0         symmetric first-layer kernels off
 //   FIL_CIN_DW_MB, FIL_CIN_DW_SPLITS, FIL_CIN_DZ_MB   launch shape of the dW / dZ kernels
+//   FIL_CIN_TAIL_SPLITS   row splits of the fused tail's weight-gradient kernel
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -152,12 +154,75 @@ static int launch_dw3(hipStream_t st, const DwPlan& p, const float* gT, int HS, 
   return p.splits;
 }
 
+// ---- fused tail (cin_tail.h): geometry of the last two layers handled as one implicit GEMM with F+2 columns
+struct TailGeom {
+  bool on = false;
+  int p = 0;                       // index of the lower tail layer (L-2); the upper one is L-1
+  int NCB = 0, JP = 0, JT4 = 0, NQ = 0, JHp = 0;
+  int Hpp = 0, Hq = 0, HL = 0, Cp = 0, C1 = 0;
+  int periods = 0, tiles = 0;      // dZ stream (slot order of cin_pack_wz_kernel, one tile past the end)
+  size_t uf_floats = 0, uz_floats = 0;
+};
+static TailGeom tail_geom(const CinShape& s) {   // what the tail WOULD look like (independent of mode: buffer sizes use it)
+  TailGeom g;
+  if (s.L < 3 || !cin_tail_supported(s.F)) return g;
+  g.on = true;
+  g.p = s.L - 2;
+  g.NCB = cin_tail_ncb(s.F);
+  g.JP = 16 * g.NCB;
+  g.JT4 = cin_tail_jt4(s.F);
+  g.NQ = cin_tail_nq(s.F);
+  g.JHp = 4 * g.NQ;
+  g.Hpp = s.H[g.p - 1];
+  g.Hq = s.H[g.p];
+  g.HL = s.H[s.L - 1];
+  g.Cp = g.Hpp * s.F;
+  g.C1 = g.Cp + 1;
+  const int JT = s.JT();
+  g.periods = cdiv(g.Hpp, cin_dz_h_per_period(JT));
+  g.tiles = g.periods * cin_dz_tiles_per_period(JT) + 1;
+  g.uf_floats = (size_t)g.Hpp * g.JT4 * 64 * g.NCB + (size_t)align_up(g.JP + 1, 64);   // Uf | consts (beff[JP], sum bias_L)
+  g.uz_floats = (size_t)g.tiles * 64 * g.JHp;
+  return g;
+}
+// is the tail used by a call with these mode bits?  (the split-bf16 experiment keeps the round-2 layer structure)
+static bool tail_used(const CinShape& s, int mode) {
+  if ((mode & (FIL_CIN_GENERAL | FIL_CIN_NOTAIL | FIL_CIN_SPLIT_BF16)) != 0) return false;
+  const TailGeom g = tail_geom(s);
+  if (!g.on) return false;
+  return (mode & FIL_CIN_TAIL_ALWAYS) != 0 || 4 * g.JP <= 3 * g.Hq;
+}
+struct TailDwPlan {
+  int blocks_x, splits, rows_per_split;
+};
+static TailDwPlan tail_dw_plan(long M, int C1) {
+  TailDwPlan p;
+  p.blocks_x = cdiv(cdiv(C1, 16 * kTailCbw), 4);
+  const long unit = 4L * kTailDwDepth;
+  // two workgroups per CU (two waves per SIMD: the second covers the first one's operand waits), all resident at once
+  long want = knobs().tail_splits > 0 ? knobs().tail_splits : std::max<long>(1, 2L * cu_count() / p.blocks_x);
+  want = std::max<long>(want, (M + (1L << 22) - 1) >> 22);   // byte offsets of a split (rows * 256) stay below 2^31
+  const long rows = std::max(unit, ((M + want - 1) / want + unit - 1) / unit * unit);
+  p.rows_per_split = (int)rows;
+  p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
+  return p;
+}
+
 constexpr int kHeadChunk = 16;    // samples per block in the head partial reductions
 constexpr int kColRows = 128;     // rows per block in the dbias (column-sum) partial reductions
 
 static size_t saved_bytes(const CinShape& s) {
   size_t t = align_up((size_t)s.M() * s.F * sizeof(float), 256);  // xT
   for (int l = 0; l + 1 < s.L; ++l) t += align_up((size_t)s.M() * s.HS(l) * sizeof(float), 256);
+  // fused tail: xT | maps 0..L-3 | Y [M][JP] | Uz | wsum_L   (whichever layout the call's mode picks must fit)
+  const TailGeom g = tail_geom(s);
+  if (g.on) {
+    size_t u = align_up((size_t)s.M() * s.F * sizeof(float), 256);
+    for (int l = 0; l < g.p; ++l) u += align_up((size_t)s.M() * s.HS(l) * sizeof(float), 256);
+    u += align_up((size_t)s.M() * g.JP * sizeof(float), 256) + align_up(g.uz_floats * sizeof(float), 256) +
+         align_up((size_t)g.Hq * s.F * sizeof(float), 256);
+    t = std::max(t, u);
+  }
   return t;
 }
 static size_t wf_floats(const CinShape& s) {
@@ -167,7 +232,8 @@ static size_t wf_floats(const CinShape& s) {
     w = std::max(w, cin_wb_floats(s.Hp(l), s.JT(), chunks_of(s.H[l])));   // split-bf16 planes (mode bit 1)
   }
   w = std::max(w, cin_wb_sym_floats(s.F, cin_jt_sym(s.F), chunks_of(s.H[0])));   // ... of the pair-symmetric first layer
-  return w + (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
+  w += (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
+  return std::max(w, tail_geom(s).uf_floats);   // fused tail: Uf | consts
 }
 static int dz_periods(const CinShape& s, int l) { return cdiv(s.Hp(l), cin_dz_h_per_period(s.JT())); }
 static size_t wz_floats(const CinShape& s) {
@@ -175,7 +241,10 @@ static size_t wz_floats(const CinShape& s) {
   size_t w = ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
   w = std::max(w, (size_t)s.F * (s.F / 2 + 1) * s.H[0]);
   for (int l = 0; l < s.L; ++l) w = std::max(w, ((size_t)dz_periods(s, l) * cin_dz_tiles_per_period(s.JT()) + 1) * 32 * s.HS(l));
-  return w + w / 2;   // the split-bf16 planes (mode bit 1) take 6 bytes per weight instead of 4
+  w = w + w / 2;   // the split-bf16 planes (mode bit 1) take 6 bytes per weight instead of 4
+  const TailGeom g = tail_geom(s);
+  if (g.on) w = std::max(w, (size_t)g.C1 * g.JP);   // fused tail: the reduced Q [C_p + 1][JP] sits here until the first pack
+  return w;
 }
 // column chunks a layer's pooled partials may come in: its own, or (last layer pooled by the epilogue of the layer
 // below) that layer's
@@ -196,6 +265,11 @@ static size_t dw_part_floats(const CinShape& s) {
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
+  const TailGeom g = tail_geom(s);
+  if (g.on) {   // fused tail: Q partials, then the dwsum_L partials of cin_tail_params_kernel
+    pmax = std::max(pmax, (size_t)tail_dw_plan(s.M(), g.C1).splits * g.C1 * g.JP);
+    pmax = std::max(pmax, (size_t)cdiv(g.Cp, kTailPc) * g.Hq * s.F);
+  }
   return pmax;
 }
 // bytes of G as three bf16 planes in row blocks of 16 (cin_split_g_kernel)
@@ -251,16 +325,17 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 31) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED)", mode);
+  if (mode < 0 || mode > 127)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
+  const bool tail = tail_used(s, mode);                    // last two layers as one implicit GEMM (cin_tail.h)
+  const TailGeom tg = tail_geom(s);
   mode &= 1;
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && W && bias && pooled && saved);
   FIL_CHECK_ARG(output_dim != 1 || (dense_w && dense_b && out));
-  // (the same limit as the backward's head kernel: a forward that succeeds must have a backward that can run)
-  if (output_dim == 1 && (size_t)L * K + 1 > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: L*K=%zu > 255", (size_t)L * K);
   if (workspace == nullptr || workspace_bytes < fwd_ws_bytes(s))
     return fail(FIL_ERR_WORKSPACE, "fil_cin_fwd: workspace %zu < %zu bytes", workspace_bytes, fwd_ws_bytes(s));
   hipStream_t st = (hipStream_t)stream;
@@ -286,6 +361,37 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   bool fused_last = false;   // the last layer's sum-pool was produced by the epilogue of the layer below
   for (int l = 0; l < L; ++l) {
     FIL_CHECK_ARG(W[l] && bias[l]);
+    if (tail && l == tg.p) {
+      // ---- fused tail: layers p = L-2 and L-1 through Ueff = W_p [1 | wsum_L]: F+1 output columns instead of H_p
+      const int lL = L - 1;
+      FIL_CHECK_ARG(W[lL] && bias[lL]);
+      float* Y = sv.take<float>((size_t)M * tg.JP);
+      float* Uz = sv.take<float>(tg.uz_floats);
+      float* wsumL = sv.take<float>((size_t)tg.Hq * F);
+      float* Uf = Wf;
+      float* consts = Wf + (size_t)tg.Hpp * tg.JT4 * 64 * tg.NCB;
+      {
+        ProfScope ps("cin_tail_prep", st);
+        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(tg.Hq * F, 8)), dim3(256), 0, st, W[lL], wsumL, tg.Hq * F, tg.HL);
+        (void)hipMemsetAsync(Uf, 0, tg.uf_floats * sizeof(float), st);   // padding of the operand layouts (f >= F, j > F, spare slots)
+        (void)hipMemsetAsync(Uz, 0, tg.uz_floats * sizeof(float), st);
+        const size_t sh = (size_t)(F + 1) * (tg.Hq + 1) * sizeof(float);
+        allow_lds(cin_tail_ueff_kernel, sh);
+        hipLaunchKernelGGL(cin_tail_ueff_kernel, dim3(cdiv(tg.C1, 4)), dim3(256), sh, st, W[l], bias[l], wsumL, bias[lL], tg.HL, Uf, Uz, consts,
+                           tg.Hpp, F, tg.Hq, tg.JT4, tg.JP, JT, tg.JHp);
+      }
+      FIL_CHECK_LAUNCH();
+      {
+        const double algo = gemm_flops(M, tg.Hpp, F, tg.Hq) + gemm_flops(M, tg.Hq, F, tg.HL);   // the two layers of the reference graph
+        ProfScope ps("cin_fwd_tail", st, algo, 2.0 * (double)M * tg.Cp * (F + 1));
+        const int RB = tune.mb_rows(M) == 2 ? 4 : 2;
+        TailFwdArgs a{xT, xpT, s.xps(l), Uf, consts, Y, tg.JP, const_cast<float*>(pa.part[l]), const_cast<float*>(pa.part[lL]), (int)M, F, tg.Hpp};
+        cin_launch_tail_fwd(st, RB, tg.JT4, tg.NCB, a);
+        pa.chunks[l] = pa.chunks[lL] = 1;
+      }
+      FIL_CHECK_LAUNCH();
+      break;
+    }
     const int Hp = s.Hp(l), Hl = H[l], xps = s.xps(l);
     float* xoutT = l + 1 < L ? sv.take<float>((size_t)M * s.HS(l)) : nullptr;
     float* part = const_cast<float*>(pa.part[l]);
@@ -315,7 +421,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
           const long npack = (long)chunks * F * 2 * JTs * 128;
           hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
         }
-        ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl));
+        ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));   // (executed: unordered pairs)
         cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl, split);
       } else {
         long npack = (long)chunks * Hp * 2 * JT * 128;
@@ -360,14 +466,16 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
                            float* const* dbias, float* ddense_w, float* ddense_b, int B, int F, int K, int L, const int* H,
                            int output_dim, int mode, void* const* grad_ready_events, void* workspace, size_t workspace_bytes,
                            void* stream) {
-  (void)bias;
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 31) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED)", mode);
+  if (mode < 0 || mode > 127)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
+  const bool tail = tail_used(s, mode);
+  const TailGeom tg = tail_geom(s);
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
   hipStream_t st = (hipStream_t)stream;
@@ -418,12 +526,19 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   const float* xT_own = sv.take<float>((size_t)M * F);
   const float* xT = xt_in ? x : xT_own;    // (X_TRANSPOSED: the caller's [B*K][F] copy; the forward left saved's own area unused)
   const float* maps[kCinMaxL];
-  for (int l = 0; l + 1 < L; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
+  const float *tailY = nullptr, *tailUz = nullptr, *tailWsum = nullptr;
+  if (tail) {   // saved layout of the fused tail: xT | maps 0..L-3 | Y | Uz | wsum_L
+    for (int l = 0; l < tg.p; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
+    tailY = sv.take<float>((size_t)M * tg.JP);
+    tailUz = sv.take<float>(tg.uz_floats);
+    tailWsum = sv.take<float>((size_t)tg.Hq * F);
+  } else {
+    for (int l = 0; l + 1 < L; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
+  }
 
   // ---- head backward: dP, ddense_w, ddense_b
   const float* dPsrc = g;  // output_dim != 1: g is already dL/dpooled
   if (output_dim == 1) {
-    if (LK + 1 > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: L*K=%zu > 255", LK);
     ProfScope ps("cin_head_bwd", st);
     hipLaunchKernelGGL(cin_head_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, dense_w, pooled, dP, small, B, (int)LK, kHeadChunk);
     hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
@@ -436,7 +551,52 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   int ltop = L - 1;          // first layer handled by the general kernels
   bool dx_started = false;   // has dxT been initialised yet
   bool have_gx0 = false;     // did a general layer-1 kernel produce Gx^0
-  if (mode == 0) {
+  if (tail) {
+    // ---- fused tail: both top layers' parameter gradients from Q = Z_p^T A (F+2 columns), data gradients from A Ueff^T
+    const int p = tg.p, lL = L - 1;
+    FIL_CHECK_ARG(bias && W[p] && W[lL] && bias[p] && dW[p] && dW[lL] && dbias[p] && dbias[lL]);
+    const float* xpT = maps[p - 1];
+    const int xps = s.xps(p);
+    const double algo = gemm_flops(M, tg.Hpp, F, tg.Hq) + gemm_flops(M, tg.Hq, F, tg.HL);   // the two layers of the reference graph
+    float* Apk = Gbuf[1];
+    {
+      ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
+      hipLaunchKernelGGL(cin_tail_a_kernel, dim3((int)std::min<long>((M * 16 * tg.NCB + 255) / 256, 8192)), dim3(256), 0, st, xT, dPsrc, (int)LK, K,
+                         p, lL, Apk, (int)M, F, tg.NCB);
+    }
+    FIL_CHECK_LAUNCH();
+    const TailDwPlan tp = tail_dw_plan(M, tg.C1);
+    {
+      ProfScope ps("cin_bwd_dw_tail", st, algo, 2.0 * (double)M * tg.C1 * (F + 2));
+      TailDwArgs a{Apk, xT, xpT, xps, part, (int)M, F, tg.Hpp, tg.JP, tp.rows_per_split, tp.blocks_x, tp.blocks_x * tp.splits, knobs().tail_settle != 0};
+      cin_launch_tail_dw(st, tg.NCB, a);
+    }
+    FIL_CHECK_LAUNCH();
+    float* Q = Wz;   // (the dZ kernels' packed-W buffer is idle until the first general layer packs into it)
+    {
+      ProfScope ps("cin_tail_params", st);
+      const long nQ = (long)tg.C1 * tg.JP;
+      hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nQ + 63) / 64)), dim3(256), 0, st, part, Q, nQ, tp.splits);
+      const int nblk_p = cdiv(tg.Cp, kTailPc);
+      const size_t sh = ((size_t)(F + 1) * (tg.Hq + 1) + (size_t)(kTailPc + 1) * tg.JP) * sizeof(float);
+      allow_lds(cin_tail_params_kernel, sh);
+      // (the Q partials have been reduced: `part` now takes the dwsum_L partials)
+      hipLaunchKernelGGL(cin_tail_params_kernel, dim3(nblk_p), dim3(256), sh, st, Q, W[p], tailWsum, dW[p], dbias[p], part, tg.Cp, F, tg.Hq, tg.JP);
+      hipLaunchKernelGGL(cin_tail_fill_kernel, dim3(cdiv(tg.Hq * F, 64)), dim3(256), 0, st, part, nblk_p, Q, bias[p], dW[lL], dbias[lL], tg.Cp, F,
+                         tg.Hq, tg.HL, tg.JP);
+    }
+    FIL_CHECK_LAUNCH();
+    ready(lL);
+    ready(p);
+    {
+      ProfScope ps("cin_bwd_dz_tail", st, algo, 2.0 * (double)M * tg.Cp * (F + 1));
+      TailDzArgs a{tailUz, xT, xpT, xps, tailY, tg.JP, dPsrc, (int)LK, K, p, lL, Gbuf[cur], s.HS(p - 1), dxT, (int)M, F, tg.Hpp, tg.periods};
+      cin_launch_tail_dz(st, JT, tg.NQ, a);
+    }
+    FIL_CHECK_LAUNCH();
+    dx_started = true;
+    ltop = p - 1;
+  } else if (mode == 0) {
     // ---- last layer through the pooled-weights shortcut (see cin_last_* kernels)
     const int l = L - 1;
     FIL_CHECK_ARG(W[l] && dW[l] && dbias[l]);
@@ -508,7 +668,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const int symD = (l == 0 && tune.sym) ? F / 2 + 1 : 0;   // unordered field pairs: half the channels
     const int Cl = symD > 0 ? F * symD : Hp * F;
     {
-      ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl));
+      ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, Cl, Hl));
       if (split) {
         // opt-in split-bf16 GEMM: G re-laid as three bf16 planes (inside the scope: it is part of this GEMM's cost)
         const long nthr = ((M + 15) / 16) * (HSl / 128) * 64;
@@ -557,7 +717,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
         } else {
           hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
         }
-        ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
+        ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));
         cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(cdiv((int)M, 128 * MBs)), G, HSl, Wz, xT, gx0T, dxT, dx_started ? 1 : 0, (int)M, F, Hl, periods, split);
       } else {
         const int periods = dz_periods(s, l);

@@ -1810,20 +1810,21 @@ static __global__ __launch_bounds__(256) void cin_head_bwd_kernel(const float* _
     __syncthreads();
     if (w == 0 && j <= LK) part[(long)blockIdx.x * (LK + 1) + j] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
   } else {
-    const int j = threadIdx.x;
-    if (j > LK) return;
-    const float wj = j < LK ? dense_w[j] : 0.f;
-    float t = 0.f;
-    for (int b = b_lo; b < b_hi; ++b) {
-      const float gb = g[b];
-      if (j < LK) {
-        dP[(long)b * LK + j] = gb * wj;
-        t = fmaf(gb, pooled[(long)b * LK + j], t);
-      } else {
-        t += gb;
+    // wide heads (L*K + 1 > 64): a thread per column, looping when there are more columns than threads
+    for (int j = threadIdx.x; j <= LK; j += 256) {
+      const float wj = j < LK ? dense_w[j] : 0.f;
+      float t = 0.f;
+      for (int b = b_lo; b < b_hi; ++b) {
+        const float gb = g[b];
+        if (j < LK) {
+          dP[(long)b * LK + j] = gb * wj;
+          t = fmaf(gb, pooled[(long)b * LK + j], t);
+        } else {
+          t += gb;
+        }
       }
+      part[(long)blockIdx.x * (LK + 1) + j] = t;
     }
-    part[(long)blockIdx.x * (LK + 1) + j] = t;
   }
 }
 

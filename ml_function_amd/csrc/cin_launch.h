@@ -49,4 +49,45 @@ inline int cin_dz_h_per_period(int JT) { return 16 * cin_dz_tiles_per_period(JT)
 // LDS field rows of the symmetric dZ kernel: h + 2j + half stays below F + rows for every (padded) slot
 inline int cin_dz_sym_rows(int F, int JT) { return F > cin_dz_h_per_period(JT) + 2 * JT ? F : cin_dz_h_per_period(JT) + 2 * JT; }
 
+// ---- fused tail (cin_tail.h): the last two layers through the pooled weights of the last one
+// A / Y / Q carry F+2 columns (dP_p | dP_L x_f | dP_L) in 16-column blocks; the forward walks the fields 4 per step
+inline bool cin_tail_supported(int F) { return F >= 1 && F <= 62; }           // <= 4 column blocks (one float4 per lane and step)
+inline int cin_tail_ncb(int F) { return (F + 2 + 15) / 16; }
+inline int cin_tail_jt4(int F) {                                               // steps per h, on the kernel menu
+  const int v = (F + 3) / 4;
+  return v == 11 ? 12 : (v == 13 ? 14 : v);
+}
+inline int cin_tail_nq(int F) { return ((F + 2) / 2 + 3) / 4; }               // float4 per tile and lane of the dZ A stream
+struct TailFwdArgs {
+  const float *xT, *xpT;
+  int xps;
+  const float *Uf, *consts;
+  float* Y;
+  int JP;
+  float *pool_p, *pool_L;
+  int M, F, Hp;
+};
+void cin_launch_tail_fwd(hipStream_t st, int RB, int JT4, int NCB, const TailFwdArgs& a);
+struct TailDwArgs {
+  const float *Apk, *xT, *xpT;
+  int xps;
+  float* part;
+  int M, F, Hp, JP, rows_per_split, blocks_x, items;
+  bool settle;
+};
+void cin_launch_tail_dw(hipStream_t st, int NCB, const TailDwArgs& a);
+struct TailDzArgs {
+  const float *Uz, *xT, *xpT;
+  int xps;
+  const float* Y;
+  int JP;
+  const float* dP;
+  int ldp, K, lp, lL;
+  float* GprevT;
+  int HSp;
+  float* dxT;
+  int M, F, Hp, periods;
+};
+void cin_launch_tail_dz(hipStream_t st, int JT, int NQ, const TailDzArgs& a);
+
 }  // namespace fil

@@ -32,7 +32,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Opt-in per-kernel timing (fil_profile_begin/_end in include/fil.h): when enabled, every major launch is
 // bracketed by a pair of HIP events recorded on the launch stream.  Off by default (zero overhead, capture-safe).
 bool prof_enabled();
-bool prof_begin_scope(const char* name, hipStream_t st, double work);
+bool prof_begin_scope(const char* name, hipStream_t st, double work, double executed);
 void prof_end_scope(hipStream_t st);
 // roctx ranges around the same scopes (host-side push/pop; `rocprofv3 --marker-trace --kernel-trace` shows which launches
 // belong to which step of the layer).  Off unless FIL_ROCTX=1 was set when the library was loaded (read once).
@@ -42,10 +42,12 @@ void roctx_pop();
 struct ProfScope {
   hipStream_t st;
   bool on, rx;
-  // work = algorithmic flops (MFMA kernels) or bytes (streaming kernels) of this launch, reported back verbatim
-  ProfScope(const char* name, hipStream_t s, double work = 0.0) : st(s), on(prof_enabled()), rx(roctx_enabled()) {
+  // work = algorithmic flops (MFMA kernels) or bytes (streaming kernels) of this launch -- what the REFERENCE graph spends on
+  // the step this scope stands for; executed = what the kernels inside the scope really compute (< work where an exact algebraic
+  // restructuring -- pair symmetry, pooled-weight contraction -- removes products; default: the same).  Both reported verbatim.
+  ProfScope(const char* name, hipStream_t s, double work = 0.0, double executed = -1.0) : st(s), on(prof_enabled()), rx(roctx_enabled()) {
     if (rx) roctx_push(name);
-    if (on) on = prof_begin_scope(name, st, work);
+    if (on) on = prof_begin_scope(name, st, work, executed < 0.0 ? work : executed);
   }
   ~ProfScope() {
     if (on) prof_end_scope(st);

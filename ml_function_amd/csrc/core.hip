@@ -32,7 +32,7 @@ int fail(int code, const char* fmt, ...) {
 // ---- opt-in kernel timing ------------------------------------------------------------------------
 struct ProfRec {
   const char* name;
-  double work;
+  double work, executed;
   hipEvent_t e0, e1;
 };
 static std::mutex g_prof_mu;
@@ -77,10 +77,10 @@ static bool scope_selected(const char* name) {
   return false;
 }
 
-bool prof_begin_scope(const char* name, hipStream_t st, double work) {
+bool prof_begin_scope(const char* name, hipStream_t st, double work, double executed) {
   if (!scope_selected(name)) return false;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  ProfRec r{name, work, pool_event(), pool_event()};
+  ProfRec r{name, work, executed, pool_event(), pool_event()};
   (void)hipEventRecord(r.e0, st);
   g_prof.push_back(r);
   return true;
@@ -131,11 +131,11 @@ extern "C" int fil_profile_begin(const char* filter) {
   return FIL_OK;
 }
 
-// Writes one line per kernel name: "name count total_ms work_per_launch\n"; returns bytes needed (incl. NUL).
+// Writes one line per kernel name: "name count total_ms work_per_launch executed_per_launch\n"; returns bytes needed (incl. NUL).
 extern "C" size_t fil_profile_end(char* buf, size_t cap) {
   std::lock_guard<std::mutex> lk(fil::g_prof_mu);
   fil::g_prof_on = false;
-  struct Agg { std::string name; long count; double ms; double work; };
+  struct Agg { std::string name; long count; double ms; double work; double executed; };
   std::vector<Agg> aggs;
   for (auto& r : fil::g_prof) {
     (void)hipEventSynchronize(r.e1);
@@ -143,14 +143,14 @@ extern "C" size_t fil_profile_end(char* buf, size_t cap) {
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
     Agg* a = nullptr;
     for (auto& x : aggs) if (x.name == r.name) { a = &x; break; }
-    if (!a) { aggs.push_back(Agg{r.name, 0, 0.0, r.work}); a = &aggs.back(); }
+    if (!a) { aggs.push_back(Agg{r.name, 0, 0.0, r.work, r.executed}); a = &aggs.back(); }
     a->count += 1;
     a->ms += ms;
   }
   std::string out;
   char line[256];
   for (auto& a : aggs) {
-    snprintf(line, sizeof(line), "%s %ld %.6f %.6e\n", a.name.c_str(), a.count, a.ms, a.work);
+    snprintf(line, sizeof(line), "%s %ld %.6f %.6e %.6e\n", a.name.c_str(), a.count, a.ms, a.work, a.executed);
     out += line;
   }
   fil::g_prof.clear();

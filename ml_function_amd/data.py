@@ -134,7 +134,14 @@ class data_pipeline:
                     raise item
                 out, ev = item
                 if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev)
+                    # The batch was allocated on the producer's side stream: tell the caching allocator that the consumer's
+                    # stream uses it too, otherwise a dropped batch's block goes back to the side-stream pool at once and the
+                    # producer's next non_blocking copy may overwrite memory that queued consumer kernels still read.
+                    for t in _leaves(out):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
                 yield out
         finally:
             stop.set()

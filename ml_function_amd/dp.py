@@ -73,8 +73,12 @@ class LayerwiseAllReduce:
     Sums are over ranks in the backend's fixed order, segment boundaries never split a reduction, so the result is the
     same as one all-reduce of the whole bucket."""
 
-    def __init__(self, flat, segments, group=None):
+    def __init__(self, flat, segments, group=None, force=False):
+        """force=True: issue the collectives even in a one-rank group (an all-reduce over one rank leaves the data unchanged but
+        runs the whole path -- side stream, event waits, the backend's kernels: how the overlap machinery is exercised and timed
+        on a single GPU, bench.py --force-collective)."""
         self.flat, self.segments, self.group = flat, [(int(a), int(b)) for a, b in segments], group
+        self.force = bool(force)
         assert all(0 <= a <= b <= flat.numel() for a, b in self.segments)
         self.cuda = flat.is_cuda
         self.events = [torch.cuda.Event() for _ in self.segments] if self.cuda else [None] * len(self.segments)
@@ -82,7 +86,7 @@ class LayerwiseAllReduce:
         self._works = []
 
     def active(self):
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
 
     def launch(self):
         if not self.active():
@@ -92,17 +96,23 @@ class LayerwiseAllReduce:
                 if hi > lo:
                     dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
             return
-        for ev, (lo, hi) in zip(self.events, self.segments):
-            if hi <= lo:
-                continue
-            with torch.cuda.stream(self.side):
+        # Every cross-stream dependency is a barrier packet plus a signal round trip on the waiting queue (~15 us each on this
+        # stack): the per-collective joins go to the SIDE stream (work.wait() there makes it wait for the backend's internal
+        # stream), the compute stream joins the side stream once, in wait().
+        with torch.cuda.stream(self.side):
+            for ev, (lo, hi) in zip(self.events, self.segments):
+                if hi <= lo:
+                    continue
                 self.side.wait_event(ev)
-                self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w.wait()
+                self._works.append(w)
 
     def wait(self):
         """Make the current stream wait for every segment's collective (call before anything reads the gradients)."""
-        for w in self._works:
-            w.wait()
+        if not self.cuda:
+            for w in self._works:
+                w.wait()
         self._works = []
         if self.cuda and self.active():
             torch.cuda.current_stream().wait_stream(self.side)
@@ -176,3 +186,15 @@ def exchange_sparse_rows(grad, touched_rows, group=None):
     for r in range(world):  # rank order: identical summation order on every replica
         grad.index_add_(0, all_rows[r][:counts[r]], all_vals[r][:counts[r]])
     return torch.unique(torch.cat([all_rows[r][:counts[r]] for r in range(world)]))
+
+
+def add_table_l2_grad_(grad, table, ranges):
+    """grad[lo:hi] += 2 * reg * table[lo:hi] for every (lo, hi, reg): the gradient of Keras' l2(reg) = reg * sum(w^2) on those rows
+    (SparseEmbed.table_l2_ranges()).  Called by the data-parallel trainer AFTER exchange_sparse_rows, with the same table on
+    every replica: the term is then added exactly once, identically everywhere, and the exchanged gradient stayed sparse.
+    (Through autograd on a loss divided by the world size it would reach a row touched by one rank as reg/w there but 2*reg/w
+    on a rank that did not touch it: replicas drift apart.)"""
+    with torch.no_grad():
+        for lo, hi, reg in ranges:
+            grad[lo:hi].add_(table[lo:hi], alpha=2.0 * float(reg))
+    return grad

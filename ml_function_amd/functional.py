@@ -218,18 +218,20 @@ class _CinFn(torch.autograd.Function):
         dense_w = _f32c(dense_w)
         dense_b = _f32c(dense_b)
         out, pooled, saved = cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim, mode, xt=xt)
-        ctx.save_for_backward(x, dense_w, pooled, saved, *Ws, *bs)
-        ctx.xt = xt          # (not a graph tensor: the gather's second output, same values as x)
-        ctx.cfg = (L, output_dim, mode)
+        # xt (the gather's second output, same values as x) goes through save_for_backward too: an in-place edit between the
+        # forward and the backward then trips autograd's version check instead of silently feeding stale rows to the kernels
+        ctx.save_for_backward(x, dense_w, pooled, saved, *Ws, *bs, *([xt] if xt is not None else []))
+        ctx.cfg = (L, output_dim, mode, xt is not None)
         return out if output_dim == 1 else pooled
 
     @staticmethod
     def backward(ctx, g):
-        L, output_dim, mode = ctx.cfg
+        L, output_dim, mode, has_xt = ctx.cfg
         x, dense_w, pooled, saved = ctx.saved_tensors[:4]
         Ws = list(ctx.saved_tensors[4:4 + L])
-        bs = list(ctx.saved_tensors[4 + L:])
-        gr = cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, _f32c(g), output_dim, mode, xt=ctx.xt)
+        bs = list(ctx.saved_tensors[4 + L:4 + 2 * L])
+        xt = ctx.saved_tensors[4 + 2 * L] if has_xt else None
+        gr = cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, _f32c(g), output_dim, mode, xt=xt)
         return (gr["dx"], gr["ddw"], gr["ddb"], None, None, None, *gr["dW"], *gr["db"])
 
 
@@ -464,9 +466,12 @@ def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None):
     values = torch.zeros((rows.numel(), K), dtype=torch.float32, device=g.device)
     check(lib.fil_embed_segment_sum(ptr(g), ptr(perm), ptr(starts), ptr(rows), ptr(values), None, rows.numel(), K, stream_ptr()),
           "fil_embed_segment_sum")
-    # the skipped bucket (id -1: out-of-range ids / frozen fields) sorts first; dropping it without reading it back:
-    # its value row is never written (zeros), its row index is clamped to 0
-    return rows.clamp(min=0), values
+    # the skipped bucket (id -1: out-of-range ids / frozen fields) sorts first and its value row is never written: drop it, so
+    # that `rows` really are the unique touched rows (a lazy / sparse optimizer must not see a spurious row 0 every step).
+    # Only possible with a range check or frozen fields; unique_consecutive above has synchronised already.
+    if (sizes is not None or frozen is not None) and rows.numel() > 0 and bool(rows[0] < 0):
+        rows, values = rows[1:], values[1:]
+    return rows, values
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -532,4 +537,5 @@ def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False
     xt = torch.empty((B * table.shape[1], F), dtype=torch.float32, device=table.device)
     out = _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key, xt)
     out._fil_xt = xt
+    out._fil_xt_version = out._version      # a consumer ignores xt once the block has been modified in place
     return out

@@ -139,12 +139,17 @@ class Layer(torch.nn.Module):
         return []
 
 
-def collect_regularization_loss(module):
+def collect_regularization_loss(module, skip_tables=False):
     """Sum of the regularisation terms of every Layer below `module` (what Keras adds to the compiled loss as
-    sum(model.losses)); a zero scalar when nothing is regularised."""
+    sum(model.losses)); a zero scalar when nothing is regularised.  skip_tables=True leaves out the l2 terms of embedding
+    tables (layers with `table_l2_ranges`): a data-parallel trainer adds their gradient analytically AFTER the sparse row
+    exchange (dp.add_table_l2_grad_), because an autograd term over a whole table makes its gradient dense and breaks the
+    exchange's "zero outside the touched rows" contract."""
     terms = []
     for m in module.modules():
         if isinstance(m, Layer):
+            if skip_tables and hasattr(m, "table_l2_ranges"):
+                continue
             terms += list(m.regularization_losses())
     if not terms:
         p = next(module.parameters(), None)

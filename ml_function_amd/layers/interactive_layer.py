@@ -216,8 +216,9 @@ class CIN(Layer):
         x = pack_fields(inputs)
         # SparseEmbed(emit_xt=True) leaves the block's [B*K, F] transpose on it: the kernels then read that in place
         xt = getattr(x, "_fil_xt", None)
-        if xt is not None and (x.dim() != 3 or tuple(xt.shape) != (x.shape[0] * x.shape[2], x.shape[1]) or xt.device != x.device):
-            xt = None
+        if xt is not None and (x.dim() != 3 or tuple(xt.shape) != (x.shape[0] * x.shape[2], x.shape[1]) or xt.device != x.device
+                               or getattr(x, "_fil_xt_version", None) != x._version):
+            xt = None       # (version: the block was edited in place after the gather -- mask multiply, dropout_ -- xt is stale)
         Ws = [w[0] for w in self.conv_kernels]
         if self.output_dim == 1:
             return Fn.cin(x, Ws, self.conv_biases, self.logit_kernel, self.logit_bias, output_dim=1, mode=self.mode, xt=xt)
@@ -303,6 +304,10 @@ class SparseEmbed(Layer):
         if not self.built:
             return []
         return [reg * self.embeddings[lo:hi].square().sum() for lo, hi, reg in self._reg]
+
+    def table_l2_ranges(self):
+        """[(row_lo, row_hi, emb_reg)] of the regularised fields of the concatenated table (for dp.add_table_l2_grad_)."""
+        return list(self._reg) if self.built else []
 
     def call(self, inputs, **kwargs):
         idx = torch.cat([t.reshape(t.shape[0], 1) for t in inputs], dim=1) if isinstance(inputs, (list, tuple)) else inputs

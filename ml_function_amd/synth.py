@@ -69,15 +69,24 @@ def attn_case(B, F, K, H, A, seed=SEED, dist="uniform"):
                 dy=rng.standard_normal((H, B, F, A)).astype(np.float32))
 
 
-def attn_stack_case(B, F, K, H, A, L, seed=SEED, dist="uniform"):
+def attn_stack_case(B, F, K, H, A, L, seed=SEED, dist="uniform", beta_shift=0.0, center_upper=False):
     """L stacked interacting layers (BASELINE config 5: L=3): layer 0 reads [B,F,K], layers l > 0 the head-concat
-    [B,F,H*A] of the layer below.  Returns x, layers = [(Wq, Wk, Wr, gamma, beta)], dy [H,B,F,A]."""
+    [B,F,H*A] of the layer below.  Returns x, layers = [(Wq, Wk, Wr, gamma, beta)], dy [H,B,F,A].
+    beta_shift > 0 moves every layer's LayerNorm offset up so that no output sits near the ReLU kink ("kink-free" inputs of
+    the f16 gradient tests: an element that lands on the other side of zero in reduced precision flips its whole upstream
+    gradient, which says nothing about the kernels).  center_upper=True makes the projection weights of layers l > 0 zero-sum
+    over their input features, so the shifted outputs of the layer below (~beta_shift + noise) do not saturate the sigmoid
+    scores: x W == (x - shift) W, the scores stay O(1) and the upper layers' weight gradients stay well conditioned."""
     rng = np.random.default_rng(seed)
     x = embeddings(rng, B, F, K, dist)
     layers, kin = [], K
     for _ in range(L):
-        mk = lambda: glorot_uniform(rng, (kin, H, A), fan_in=H * kin, fan_out=A * kin)
+        def mk():
+            w = glorot_uniform(rng, (kin, H, A), fan_in=H * kin, fan_out=A * kin)
+            if center_upper and layers:
+                w = (w - w.mean(0, keepdims=True)).astype(np.float32)
+            return w
         layers.append((mk(), mk(), mk(), (1.0 + 0.1 * rng.standard_normal(A)).astype(np.float32),
-                       (0.1 * rng.standard_normal(A)).astype(np.float32)))
+                       (0.1 * rng.standard_normal(A) + beta_shift).astype(np.float32)))
         kin = H * A
     return dict(x=x, layers=layers, dy=rng.standard_normal((H, B, F, A)).astype(np.float32))

@@ -78,10 +78,11 @@ def attn(tag, B, F, K, H, A):
     save("attn_%s.npz" % tag, **arrays)
 
 
-def attn_stack(tag, B, F, K, H, A, L):
+def attn_stack(tag, B, F, K, H, A, L, beta_shift=0.0):
     """BASELINE config 5 as written (3 stacked interacting layers; the stacking rule is the documented extension of
-    oracle/graph.py:autoint_stack -- head-concat per the reference's ESULayer, behavior_layer.py:973)."""
-    c = synth.attn_stack_case(B, F, K, H, A, L, dist="normal")
+    oracle/graph.py:autoint_stack -- head-concat per the reference's ESULayer, behavior_layer.py:973).
+    beta_shift: the kink-free variant (synth.attn_stack_case) the f16 gradient bars are held on."""
+    c = synth.attn_stack_case(B, F, K, H, A, L, dist="normal", beta_shift=beta_shift, center_upper=beta_shift > 0)
     x = T(c["x"])
     layers = [tuple(T(p) for p in lay) for lay in c["layers"]]
     y = graph.autoint_stack(x, layers)
@@ -127,4 +128,5 @@ if __name__ == "__main__":
     attn("c5_small", 2, 200, 16, 4, 16)       # config 5 layer shape, small batch
     attn("default", 2, 39, 16, 3, 8)          # reference defaults: attention_dim=8, 3 heads
     attn_stack("c5_small", 2, 200, 16, 4, 16, 3)   # config 5: 3 layers, 4 heads, F=200, K=16, A=16, small batch
+    attn_stack("c5_nokink", 2, 200, 16, 4, 16, 3, beta_shift=4.0)   # ... with every output away from the ReLU kink
     label_encode()

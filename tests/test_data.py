@@ -60,3 +60,28 @@ def test_static_batch_is_a_bootstrap_resample():
     assert len(np.unique(out["a"])) < len(out["a"])                  # with replacement, like np.random.choice's default
     arr = data.static_batch(list(range(100)), batch_size=30, use_shuffle=False, rng=rng)
     assert arr.shape == (90,)
+
+
+@pytest.mark.gpu
+def test_prefetched_batches_survive_queued_consumer_work():
+    """Batches are allocated and filled on the producer's side stream.  The consumer queues a long kernel, then reads the batch
+    on its own stream and drops it at once (the training loop's pattern): without record_stream on the consumer's stream the
+    caching allocator may hand the block back to the producer, whose next copy overwrites data the queued reads still need."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, bs = 64 * 4096, 4096
+    x = np.arange(n, dtype=np.int64)
+    pipe = data.data_pipeline((x, (x * 3).astype(np.float32)), batch_size=bs, shuffle_buffer=0, repeat=1, prefetch=2, device=dev)
+    busy = torch.randn(4096, 4096, device=dev)
+    sums, fsums = [], []
+    for ids, vals in pipe:
+        for _ in range(6):                      # ~ms of queued work in front of every read of the batch
+            busy = torch.tanh(busy @ busy * 1e-3)
+        sums.append(ids.sum())
+        fsums.append((vals.double() - 3.0 * ids.double()).abs().max())
+        del ids, vals                           # block returns to the allocator while the reads are still queued
+    torch.cuda.synchronize()
+    got = torch.stack(sums).cpu().numpy()
+    want = x.reshape(-1, bs).sum(1)
+    assert np.array_equal(got, want)
+    assert float(torch.stack(fsums).max()) == 0.0

@@ -210,3 +210,41 @@ def test_sparse_row_exchange_single_process_is_a_noop():
     keep = grad.clone()
     rows = dp.exchange_sparse_rows(grad, torch.tensor([4, 1, 4]))
     assert torch.equal(grad, keep) and rows.tolist() == [1, 4]
+
+
+def _sparse_reg_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, K, B, reg = 50, 4, 12, 0.25
+        rng = np.random.default_rng(6)
+        table = torch.tensor(rng.normal(size=(V, K)), dtype=torch.float32)
+        idx = torch.tensor(rng.integers(0, V // 2, B))        # rows >= V/2 are touched by nobody
+        g = torch.tensor(rng.normal(size=(B, K)), dtype=torch.float32)
+        lo, hi = dp.shard_bounds(B, rank, world)
+        grad = torch.zeros(V, K)
+        grad.index_add_(0, idx[lo:hi], g[lo:hi] / world)      # the shard's part of the mean loss
+        dp.exchange_sparse_rows(grad, idx[lo:hi])
+        dp.add_table_l2_grad_(grad, table, [(0, 30, reg), (40, 50, 2 * reg)])
+        np.save(os.path.join(out_dir, "g%d.npy" % rank), grad.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_row_exchange_with_table_regulariser(tmp_path):
+    """emb_reg > 0: the l2 term of a table is added after the exchange, once, identically on every replica --
+    replicas stay bit-identical and rows nobody touched get exactly 2*reg*w (not reg/world)."""
+    world = 2
+    mp.spawn(_sparse_reg_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    V, K, B, reg = 50, 4, 12, 0.25
+    rng = np.random.default_rng(6)
+    table = torch.tensor(rng.normal(size=(V, K)), dtype=torch.float32, requires_grad=True)
+    idx = torch.tensor(rng.integers(0, V // 2, B))
+    g = torch.tensor(rng.normal(size=(B, K)), dtype=torch.float32)
+    loss = (table[idx] * g).sum() / world + reg * table[0:30].square().sum() + 2 * reg * table[40:50].square().sum()
+    loss.backward()
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(g0, g1)
+    assert np.abs(g0 - table.grad.numpy()).max() < 1e-6
+    assert np.abs(g0[45] - 4 * reg * table.detach().numpy()[45]).max() < 1e-7 and not g0[30:40].any()

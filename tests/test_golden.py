@@ -187,26 +187,61 @@ def test_gpu_autoint(name):
     assert rel(torch.relu(av + res), g["y"]) < 1e-5
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol_y,tol_g", [("f32", 1e-5, 5e-5), ("f16_mfma", 5e-3, 0.25)])  # dWq of upper layers: x10
-def test_gpu_autoint_stack(precision, tol_y, tol_g):
-    """BASELINE config 5 as written: 3 stacked interacting layers, 4 heads, F=200, K=16, A=16; layers 2 and 3 read the
-    head-major output of the layer below in place (no head-concat copy).  fp32 mode at the 1e-5 bar on the output (5e-5
-    on gradients: three ReLU/LN kinks deep); the labelled f16-MFMA mode at 5e-3 / 0.25 (kink flips, see
-    test_attn_f16_mfma_mode).  dWq of the upper layers is ill-conditioned (its terms cancel to ~1e-3 of their size: the
-    oracle graph itself evaluated in fp32 by torch-CPU is off by 1.6e-4 on dWq of layer 3 of this fixture), bar x10."""
+def _run_stack_fixture(name, precision):
     from ml_function_amd import functional as Fn
-    g = load("attn_stack_c5_small.npz")
+    g = load(name)
     L = int(g["L"])
     x = dev(g["x"]).requires_grad_()
     layers = [tuple(dev(g["%s%d" % (n, l)]).requires_grad_() for n in ["Wq", "Wk", "Wr", "gamma", "beta"]) for l in range(L)]
     y = Fn.autoint_stack(x, layers, precision=precision)
-    assert y.shape == g["y"].shape and rel(y, g["y"]) < tol_y
     y.backward(dev(g["dy"]))
+    return g, L, x, layers, y
+
+
+@pytest.mark.gpu
+def test_gpu_autoint_stack():
+    """BASELINE config 5 as written: 3 stacked interacting layers, 4 heads, F=200, K=16, A=16; layers 2 and 3 read the
+    head-major output of the layer below in place (no head-concat copy).  fp32 mode at the 1e-5 bar on the output (5e-5
+    on gradients: three ReLU/LN kinks deep).  dWq of the upper layers is ill-conditioned on this fixture (its terms cancel
+    to ~1e-3 of their size: the oracle graph itself evaluated in fp32 by torch-CPU is off by 1.6e-4 on dWq of layer 3), bar x10."""
+    g, L, x, layers, y = _run_stack_fixture("attn_stack_c5_small.npz", "f32")
+    assert y.shape == g["y"].shape and rel(y, g["y"]) < 1e-5
+    assert rel(x.grad, g["dx"]) < 5e-5
+    for l in range(L):
+        for p, n in zip(layers[l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
+            assert rel(p.grad, g["%s%d" % (n, l)]) < (5e-4 if (n == "dWq" and l > 0) else 5e-5), (l, n)
+
+
+@pytest.mark.gpu
+def test_gpu_autoint_stack_f16_kinked_smoke():
+    """The same fixture in the labelled f16-MFMA mode: outputs at 5e-3.  Its GRADIENTS are a smoke check only (finite, within
+    0.25): outputs that sit within ~1e-3 of the ReLU kink land on the other side of zero in reduced precision and flip their
+    whole upstream gradient -- a property of the inputs, not of the kernels.  The bar that bites is the kink-free fixture below."""
+    g, L, x, layers, y = _run_stack_fixture("attn_stack_c5_small.npz", "f16_mfma")
+    assert rel(y, g["y"]) < 5e-3
+    assert torch.isfinite(x.grad).all() and rel(x.grad, g["dx"]) < 0.25
+    for l in range(L):
+        for p, n in zip(layers[l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
+            assert torch.isfinite(p.grad).all(), (l, n)
+            if not (n == "dWq" and l > 0):      # (ill-conditioned on this fixture, see test_gpu_autoint_stack)
+                assert rel(p.grad, g["%s%d" % (n, l)]) < 0.25, (l, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol_y,tol_g", [("f32", 1e-5, 5e-5), ("f16_mfma", 5e-3, 2e-2)])
+def test_gpu_autoint_stack_kink_free(precision, tol_y, tol_g):
+    """Config 5's 3-layer stack on the kink-free fixture (synth.attn_stack_case(beta_shift=4, center_upper=True): every
+    pre-activation >= 0.6, sigmoid scores unsaturated, all weight gradients O(0.3..10)): EVERY gradient of EVERY layer
+    is held to the mode's bar -- fp32 1e-5 / 5e-5, f16-MFMA 5e-3 / 2e-2.  dWq of the layers above the
+    first is ill-conditioned in any precision (tests/test_gpu_parity.py::test_attn_at_the_benchmark_shape; measured on this
+    fixture: fp32 5e-5 against 3e-7 for the other gradients, f16 4.7e-2 against 1e-3): bar x5 there."""
+    g, L, x, layers, y = _run_stack_fixture("attn_stack_c5_nokink.npz", precision)
+    assert float(g["y"].min()) > 0.5
+    assert rel(y, g["y"]) < tol_y
     assert rel(x.grad, g["dx"]) < tol_g
     for l in range(L):
         for p, n in zip(layers[l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
-            assert rel(p.grad, g["%s%d" % (n, l)]) < (10 * tol_g if (n == "dWq" and l > 0) else tol_g), (l, n)
+            assert rel(p.grad, g["%s%d" % (n, l)]) < (5 * tol_g if (n == "dWq" and l > 0) else tol_g), (l, n)
 
 
 @pytest.mark.gpu
