@@ -58,11 +58,11 @@ static int env_int(const char* name, int dflt) {
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -219,7 +219,7 @@ static size_t saved_bytes(const CinShape& s) {
   if (g.on) {
     size_t u = align_up((size_t)s.M() * s.F * sizeof(float), 256);
     for (int l = 0; l < g.p; ++l) u += align_up((size_t)s.M() * s.HS(l) * sizeof(float), 256);
-    u += align_up((size_t)s.M() * g.JP * sizeof(float), 256) + align_up(g.uz_floats * sizeof(float), 256) +
+    u += align_up((size_t)s.M() * g.JP * sizeof(float), 256) + align_up((g.uz_floats + g.uf_floats) * sizeof(float), 256) +
          align_up((size_t)g.Hq * s.F * sizeof(float), 256);
     t = std::max(t, u);
   }
@@ -233,7 +233,7 @@ static size_t wf_floats(const CinShape& s) {
   }
   w = std::max(w, cin_wb_sym_floats(s.F, cin_jt_sym(s.F), chunks_of(s.H[0])));   // ... of the pair-symmetric first layer
   w += (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
-  return std::max(w, tail_geom(s).uf_floats);   // fused tail: Uf | consts
+  return w;
 }
 static int dz_periods(const CinShape& s, int l) { return cdiv(s.Hp(l), cin_dz_h_per_period(s.JT())); }
 static size_t wz_floats(const CinShape& s) {
@@ -366,18 +366,18 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       const int lL = L - 1;
       FIL_CHECK_ARG(W[lL] && bias[lL]);
       float* Y = sv.take<float>((size_t)M * tg.JP);
-      float* Uz = sv.take<float>(tg.uz_floats);
-      float* wsumL = sv.take<float>((size_t)tg.Hq * F);
-      float* Uf = Wf;
-      float* consts = Wf + (size_t)tg.Hpp * tg.JT4 * 64 * tg.NCB;
+      float* Uz = sv.take<float>(tg.uz_floats + tg.uf_floats);   // Uz | Uf | consts: one buffer, one clear
+      float* bmT = sv.take<float>((size_t)tg.Hq * F);
+      float* Uf = Uz + tg.uz_floats;
+      float* consts = Uf + (size_t)tg.Hpp * tg.JT4 * 64 * tg.NCB;
       {
         ProfScope ps("cin_tail_prep", st);
-        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(tg.Hq * F, 8)), dim3(256), 0, st, W[lL], wsumL, tg.Hq * F, tg.HL);
-        (void)hipMemsetAsync(Uf, 0, tg.uf_floats * sizeof(float), st);   // padding of the operand layouts (f >= F, j > F, spare slots)
-        (void)hipMemsetAsync(Uz, 0, tg.uz_floats * sizeof(float), st);
+        hipLaunchKernelGGL(cin_tail_wsum_kernel, dim3(cdiv(tg.Hq * F, 8)), dim3(256), 0, st, W[lL], bmT, tg.Hq, F, tg.HL);
+        // (padding of the operand layouts -- f >= F, j > F, spare slots -- must be zero)
+        (void)hipMemsetAsync(Uz, 0, (tg.uz_floats + tg.uf_floats) * sizeof(float), st);
         const size_t sh = (size_t)(F + 1) * (tg.Hq + 1) * sizeof(float);
         allow_lds(cin_tail_ueff_kernel, sh);
-        hipLaunchKernelGGL(cin_tail_ueff_kernel, dim3(cdiv(tg.C1, 4)), dim3(256), sh, st, W[l], bias[l], wsumL, bias[lL], tg.HL, Uf, Uz, consts,
+        hipLaunchKernelGGL(cin_tail_ueff_kernel, dim3(cdiv(tg.C1, kTailUc)), dim3(256), sh, st, W[l], bias[l], bmT, bias[lL], tg.HL, Uf, Uz, consts,
                            tg.Hpp, F, tg.Hq, tg.JT4, tg.JP, JT, tg.JHp);
       }
       FIL_CHECK_LAUNCH();
@@ -530,8 +530,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   if (tail) {   // saved layout of the fused tail: xT | maps 0..L-3 | Y | Uz | wsum_L
     for (int l = 0; l < tg.p; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
     tailY = sv.take<float>((size_t)M * tg.JP);
-    tailUz = sv.take<float>(tg.uz_floats);
-    tailWsum = sv.take<float>((size_t)tg.Hq * F);
+    tailUz = sv.take<float>(tg.uz_floats + tg.uf_floats);
+    tailWsum = sv.take<float>((size_t)tg.Hq * F);   // (bmT layout: [f][n])
   } else {
     for (int l = 0; l + 1 < L; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
   }
@@ -578,7 +578,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const long nQ = (long)tg.C1 * tg.JP;
       hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nQ + 63) / 64)), dim3(256), 0, st, part, Q, nQ, tp.splits);
       const int nblk_p = cdiv(tg.Cp, kTailPc);
-      const size_t sh = ((size_t)(F + 1) * (tg.Hq + 1) + (size_t)(kTailPc + 1) * tg.JP) * sizeof(float);
+      const size_t sh = ((size_t)(F + 1) * ((tg.Hq + 3) & ~3) + (size_t)tg.JP * (kTailPc + 4)) * sizeof(float);
       allow_lds(cin_tail_params_kernel, sh);
       // (the Q partials have been reduced: `part` now takes the dwsum_L partials)
       hipLaunchKernelGGL(cin_tail_params_kernel, dim3(nblk_p), dim3(256), sh, st, Q, W[p], tailWsum, dW[p], dbias[p], part, tg.Cp, F, tg.Hq, tg.JP);
@@ -590,7 +590,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ready(p);
     {
       ProfScope ps("cin_bwd_dz_tail", st, algo, 2.0 * (double)M * tg.Cp * (F + 1));
-      TailDzArgs a{tailUz, xT, xpT, xps, tailY, tg.JP, dPsrc, (int)LK, K, p, lL, Gbuf[cur], s.HS(p - 1), dxT, (int)M, F, tg.Hpp, tg.periods};
+      TailDzArgs a{tailUz, xT, xpT, xps, tailY, tg.JP, dPsrc, (int)LK, K, p, lL, Gbuf[cur], s.HS(p - 1), dxT, (int)M, F, tg.Hpp, tg.periods, knobs().tail_dz_mode};
       cin_launch_tail_dz(st, JT, tg.NQ, a);
     }
     FIL_CHECK_LAUNCH();

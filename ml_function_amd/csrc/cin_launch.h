@@ -87,6 +87,7 @@ struct TailDzArgs {
   int HSp;
   float* dxT;
   int M, F, Hp, periods;
+  int smode;
 };
 void cin_launch_tail_dz(hipStream_t st, int JT, int NQ, const TailDzArgs& a);
 

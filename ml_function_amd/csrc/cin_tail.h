@@ -25,6 +25,8 @@
 #pragma once
 #include "cin_kernels.h"
 
+#include <type_traits>
+
 namespace fil {
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -86,54 +88,81 @@ __device__ __forceinline__ void settle_any(T& v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Ueff and its operand layouts.  One thread per (channel row c, column j <= F); 4 rows per workgroup, Bm staged in LDS.
+// bmT[f][n] = wsum_L[(n,f)] = sum_n' W_L[(n*F + f), n']: the pooled weights of the last layer, stored so that Bm[1+f][.] is a
+// contiguous row (the staging loops below are coalesced).  One half wave per row of W_L.
+static __global__ __launch_bounds__(256) void cin_tail_wsum_kernel(const float* __restrict__ WL, float* __restrict__ bmT, int Hq, int F, int HL) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  const int C = Hq * F;
+  float t = 0.f;
+  if (row < C)
+    for (int n = l; n < HL; n += 32) t += WL[(long)row * HL + n];
+  t = half_wave_sum(t);
+  if (row < C && l == 0) {
+    const int n = row / F, f = row - n * F;
+    bmT[f * Hq + n] = t;
+  }
+}
+
+// stages Bm [F+1][ld] (row 0 = ones, row 1+f = bmT[f]) into LDS
+__device__ __forceinline__ void tail_stage_bm(const float* __restrict__ bmT, float* bm, int F, int Hq, int ld) {
+  for (int idx = threadIdx.x; idx < (F + 1) * Hq; idx += blockDim.x) {
+    const int j = idx / Hq, n = idx - j * Hq;
+    bm[j * ld + n] = j == 0 ? 1.f : bmT[idx - Hq];
+  }
+}
+
+// Ueff and its operand layouts.  kTailUc channel rows per workgroup; thread (row cl = tid/16, column group jg = tid%16) computes
+// the columns j = jg, jg+16, ... of its row, so a W_p row is read once per 16 lanes (broadcast) and Bm comes from LDS.
 //   Uf  (forward, B operand of 16x16x4):  [step s = h*JT4 + f/4][lane = (f&3)<<4 | (j&15)][component j>>4 < NCB]
 //   Uz  (dZ, A operand of 32x32x2):       [tile][slot row i][wave half][JHp]: column j = half*JHp + s; slot row as in cin_pack_wz_kernel
 //   consts: [0, JP) beff[j] = sum_n bias_p[n] Bm[j][n];  [JP] = sum_n' bias_L[n']
 // Padding (f >= F, j > F, slots past the last channel) must be zero: the caller clears the buffers first.
+constexpr int kTailUc = 16;
 static __global__ __launch_bounds__(256) void cin_tail_ueff_kernel(const float* __restrict__ Wp, const float* __restrict__ biasp,
-                                                            const float* __restrict__ wsumL, const float* __restrict__ biasL, int HL,
+                                                            const float* __restrict__ bmT, const float* __restrict__ biasL, int HL,
                                                             float* __restrict__ Uf, float* __restrict__ Uz, float* __restrict__ consts,
                                                             int Hpp, int F, int Hq, int JT4, int JP, int JT, int JHp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][Hq+1]
   const int NCB = JP >> 4;
   const int J1 = F + 1, ld = Hq + 1;
-  for (int idx = threadIdx.x; idx < J1 * Hq; idx += 256) {
-    const int j = idx / Hq, n = idx - j * Hq;
-    smem[j * ld + n] = j == 0 ? 1.f : wsumL[n * F + (j - 1)];
-  }
+  tail_stage_bm(bmT, smem, F, Hq, ld);
   __syncthreads();
   const int Cp = Hpp * F;
-  const int cl = threadIdx.x >> 6, j = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + cl;  // row Cp = the bias row (-> consts)
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     float t = 0.f;
     for (int n = threadIdx.x; n < HL; n += 64) t += biasL[n];
     t = wave_sum(t);
     if (threadIdx.x == 0) consts[JP] = t;
   }
-  if (c > Cp || j >= J1) return;
+  const int cl = threadIdx.x >> 4, jg = threadIdx.x & 15;
+  const int c = blockIdx.x * kTailUc + cl;  // row Cp = the bias row (-> consts)
+  if (c > Cp) return;
   const float* wrow = c < Cp ? Wp + (long)c * Hq : biasp;
-  const float* brow = smem + j * ld;
-  float t0 = 0.f, t1 = 0.f;
-  int n = 0;
-  for (; n + 1 < Hq; n += 2) {
-    t0 = fmaf(wrow[n], brow[n], t0);
-    t1 = fmaf(wrow[n + 1], brow[n + 1], t1);
-  }
-  if (n < Hq) t0 = fmaf(wrow[n], brow[n], t0);
-  const float t = t0 + t1;
-  if (c == Cp) {
-    consts[j] = t;
-    return;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < Hq; ++n) {
+    const float w = wrow[n];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int j = 16 * cb + jg;
+      if (cb < NCB) t[cb] = fmaf(w, smem[min(j, F) * ld + n], t[cb]);
+    }
   }
   const int h = c / F, f = c - h * F;
-  Uf[((long)(h * JT4 + (f >> 2)) * 64 + (((f & 3) << 4) | (j & 15))) * NCB + (j >> 4)] = t;
   const int slot = h * JT + (f >> 1), hf = f & 1;
   const int tile = slot >> 4, rr = slot & 15;
   const int i = (rr & 3) + 8 * (rr >> 2) + 4 * hf;
-  const int half = j >= JHp ? 1 : 0, s = j - half * JHp;
-  Uz[((long)(tile * 32 + i) * 2 + half) * JHp + s] = t;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int j = 16 * cb + jg;
+    if (cb >= NCB || j >= J1) continue;
+    if (c == Cp) {
+      consts[j] = t[cb];
+      continue;
+    }
+    Uf[((long)(h * JT4 + (f >> 2)) * 64 + (((f & 3) << 4) | jg)) * NCB + cb] = t[cb];
+    const int half = j >= JHp ? 1 : 0, s2 = j - half * JHp;
+    Uz[((long)(tile * 32 + i) * 2 + half) * JHp + s2] = t[cb];
+  }
 }
 
 // queue depth of the forward's B-operand stream: a divisor of the steps per h (slot j4 % DEPTH must mean the same step in every h)
@@ -199,6 +228,12 @@ __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __res
   for (int d = 0; d < DEPTH; ++d) settle_any(q[d]);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) settle(xpv[rb]);
+  // The A operands of step s+1 are computed as ONE block of RB multiplies in front of step s's MFMAs and consumed a step later:
+  // a v_mul whose result feeds the very next MFMA costs ~14 cycles of matrix time (VALU -> MFMA operand wait states; 128 instead
+  // of 145 TFLOP/s in tools/probe_mfma16.hip at this 4 x 3 shape), a block of independent ones ~1.5 each (143).
+  float an[RB], ac[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) ac[rb] = xpv[rb] * xr[rb][0];
 #pragma unroll 1
   for (int h = 0; h < Hp; ++h) {
     const bool more = h + 1 < Hp;
@@ -210,15 +245,18 @@ __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __res
     for (int j4 = 0; j4 < JT4; ++j4) {
       const typename BV::T w = q[j4 % DEPTH];
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const float a = xpv[rb] * xr[rb][j4];
+      for (int rb = 0; rb < RB; ++rb) an[rb] = (j4 + 1 < JT4 ? xpv[rb] : xpn[rb]) * xr[rb][(j4 + 1) % JT4];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma16(a, BV::get(w, cb), acc[rb][cb]);
-      }
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma16(ac[rb], BV::get(w, cb), acc[rb][cb]);
       __builtin_amdgcn_sched_barrier(0);
       const int jn = j4 + DEPTH;   // refill AFTER the step's MFMAs: the load may land in the registers it replaces
       q[j4 % DEPTH] = jn < JT4 ? BV::load(ru, uo, sh + jn * kStepBytes) : BV::load(ru, uo, shn + (jn - JT4) * kStepBytes);
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) ac[rb] = an[rb];
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) xpv[rb] = xpn[rb];
@@ -283,7 +321,8 @@ template <int NCB, bool SETTLE = false, int CBW = kTailCbw, int DEPTH = kTailDwD
 __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __restrict__ Apk, const float* __restrict__ xT,
                                                               const float* __restrict__ xpT, int xps, float* __restrict__ part, int M,
                                                               int F, int Hp, int JP, int rows_per_split, int blocks_x, int items) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
   const int Cp = Hp * F, C1 = Cp + 1;
   const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, as in cin_dw3_kernel
@@ -294,20 +333,21 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
   if (c0 >= C1) return;
   const int m_lo = split * rows_per_split;
   const int m_hi = min(M, m_lo + rows_per_split);
-  const long mrem = (long)M - m_lo;
+  // the three descriptors cover exactly the split's rows [m_lo, m_hi): anything past them -- the last step's spare rows, the
+  // prefetch beyond the end -- reads as zero, so the loop needs no row masks at all (0 * 0 products; 1 * A = 0 in the ones row)
+  const long mrem = (long)m_hi - m_lo;
   typedef DwordVec<NCB> BV;
   constexpr int kRowBytes = 16 * NCB * 4;
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(Apk + (long)m_lo * 16 * NCB, mrem * kRowBytes);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(xT + (long)m_lo * F, mrem * F * 4);
   const __amdgpu_buffer_rsrc_t rp = make_rsrc(xpT + (long)m_lo * xps, mrem * xps * 4);
   int fo[CBW], ho[CBW];
-  bool cv[CBW], ones[CBW];
+  bool ones[CBW];
 #pragma unroll
   for (int cbk = 0; cbk < CBW; ++cbk) {
     const int c = c0 + 16 * cbk + i;
-    cv[cbk] = c < C1;
     ones[cbk] = c == Cp;
-    const int cc = min(c, Cp - 1);
+    const int cc = min(c, Cp - 1);   // (channels past the end compute finite values that are never stored)
     const int hh = cc / F, ff = cc - hh * F;
     ho[cbk] = (kq * xps + hh) * 4;   // byte offsets of the lane's column inside row (m_lo + kq)
     fo[cbk] = (kq * F + ff) * 4;
@@ -315,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
   const int ao = (kq * 16 + i) * NCB * 4;
   const int steps = (m_hi - m_lo + 3) >> 2;
   const int groups = (steps + DEPTH - 1) / DEPTH;
-  const int mlane = m_lo + kq;
 
   f32x4 acc[CBW][NCB];
 #pragma unroll
@@ -349,28 +388,41 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
       }
     }
   }
-#pragma unroll 1
-  for (int g = 0; g < groups; ++g) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int s = g * DEPTH + d;
-      const typename BV::T a4 = qa[d];
-      const bool live = mlane + 4 * s < m_hi;
-      float a[CBW];
+  // Main loop.  The generated operands of step s+1 are computed as one block in front of step s's MFMAs (see cin_tail_fwd_kernel);
+  // only the wave that owns the all-ones channel row C_p pays for the select (a wave-uniform choice of the loop body).
+  auto run = [&](auto ones_tag) {
+    constexpr bool ONES = decltype(ones_tag)::value;
+    auto make_a = [&](int d, float (&a)[CBW]) {
 #pragma unroll
       for (int cbk = 0; cbk < CBW; ++cbk) {
-        const float z = ones[cbk] ? 1.f : qx[d][cbk] * qp[d][cbk];
-        a[cbk] = (live && cv[cbk]) ? z : 0.f;
+        const float z = qx[d][cbk] * qp[d][cbk];
+        a[cbk] = (ONES && ones[cbk]) ? 1.f : z;
       }
+    };
+    float ac[CBW], an[CBW];
+    make_a(0, ac);
+#pragma unroll 1
+    for (int g = 0; g < groups; ++g) {
 #pragma unroll
-      for (int cbk = 0; cbk < CBW; ++cbk)
+      for (int d = 0; d < DEPTH; ++d) {
+        const int s = g * DEPTH + d;
+        const typename BV::T a4 = qa[d];
+        make_a((d + 1) % DEPTH, an);   // (slot 0 was refilled with the next group's first step at d == 0)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[cbk][cb] = mfma16(a[cbk], BV::get(a4, cb), acc[cbk][cb]);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(s + DEPTH, qa[d], qx[d], qp[d]);   // refill after the step's MFMAs (lands in place, see cin_dw3_kernel)
-      __builtin_amdgcn_sched_barrier(0);
+        for (int cbk = 0; cbk < CBW; ++cbk)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc[cbk][cb] = mfma16(ac[cbk], BV::get(a4, cb), acc[cbk][cb]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(s + DEPTH, qa[d], qx[d], qp[d]);   // refill after the step's MFMAs (lands in place, see cin_dw3_kernel)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cbk = 0; cbk < CBW; ++cbk) ac[cbk] = an[cbk];
+      }
     }
-  }
+  };
+  if (c0 + 16 * CBW > Cp) run(std::true_type{});
+  else run(std::false_type{});
   // D[row = 4*kq + reg (channel of the block)][col = i]
   float* pout = part + (long)split * C1 * JP;
 #pragma unroll
@@ -386,52 +438,107 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Parameter gradients from Q [C_p + 1][JP].  One workgroup per kTailPc channel rows:
-//   dW_p[c][n]  = sum_{j <= F} Q[c][j] Bm[j][n]
-//   partB[blk][(n,f)] = sum_{c in blk} Q[c][1+f] W_p[c][n]           (-> dwsum_L, reduced by cin_tail_fill_kernel)
+// Parameter gradients from Q [C_p + 1][JP].  One workgroup per kTailPc channel rows, two small register-tiled products:
+//   dW_p[c][n]        = sum_{j <= F} Q[c][j] Bm[j][n]                 thread tile 4 rows x 4 columns (16-byte LDS reads of both)
+//   partB[blk][(n,f)] = sum_{c in blk} Q[c][1+f] W_p[c][n]            thread tile 4 columns n x kTailFt fields (-> dwsum_L, reduced
+//                                                                     by cin_tail_fill_kernel)
 //   workgroup 0: dbias_p[n] = sum_j Q[C_p][j] Bm[j][n]
 constexpr int kTailPc = 32;
 static __global__ __launch_bounds__(256) void cin_tail_params_kernel(const float* __restrict__ Q, const float* __restrict__ Wp,
-                                                              const float* __restrict__ wsumL, float* __restrict__ dWp,
+                                                              const float* __restrict__ bmT, float* __restrict__ dWp,
                                                               float* __restrict__ dbiasp, float* __restrict__ partB, int Cp, int F, int Hq,
                                                               int JP) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][Hq+1] | Q rows [kTailPc + 1][JP]
-  const int J1 = F + 1, ld = Hq + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][ldb] | Q^T [JP][kTailPc + 4]
+  const int J1 = F + 1;
+  const int ldb = (Hq + 3) & ~3;            // 16-byte aligned rows
+  constexpr int ldq = kTailPc + 4;
   float* bm = smem;
-  float* qs = smem + J1 * ld;
+  float* qt = smem + (size_t)J1 * ldb;      // qt[j][cl]: the workgroup's rows of Q, transposed; column kTailPc.. : the ones row
   const int c0 = blockIdx.x * kTailPc;
   const int nc = min(kTailPc, Cp - c0);
   for (int idx = threadIdx.x; idx < J1 * Hq; idx += 256) {
     const int j = idx / Hq, n = idx - j * Hq;
-    bm[j * ld + n] = j == 0 ? 1.f : wsumL[n * F + (j - 1)];
+    bm[j * ldb + n] = j == 0 ? 1.f : bmT[idx - Hq];
   }
   for (int idx = threadIdx.x; idx < (kTailPc + 1) * JP; idx += 256) {
     const int cl = idx / JP, j = idx - cl * JP;
     const int c = cl < kTailPc ? c0 + cl : Cp;   // last staged row: the ones channel
-    qs[idx] = (cl == kTailPc || cl < nc) ? Q[(long)c * JP + j] : 0.f;
+    qt[j * ldq + cl] = (cl == kTailPc || cl < nc) ? Q[(long)c * JP + j] : 0.f;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < nc * Hq; idx += 256) {
-    const int cl = idx / Hq, n = idx - cl * Hq;
-    const float* qrow = qs + cl * JP;
-    float t = 0.f;
-    for (int j = 0; j < J1; ++j) t = fmaf(qrow[j], bm[j * ld + n], t);
-    dWp[(long)(c0 + cl) * Hq + n] = t;
+  // dW_p: tiles of 4 rows x 4 columns
+  const int nq = ldb >> 2;                  // column quads
+  for (int tile = threadIdx.x; tile < (kTailPc / 4) * nq; tile += 256) {
+    const int cq = tile / nq, n4 = tile - cq * nq;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int j = 0; j < J1; ++j) {
+      const float4 qv = *reinterpret_cast<const float4*>(qt + j * ldq + 4 * cq);
+      const float4 bv = *reinterpret_cast<const float4*>(bm + j * ldb + 4 * n4);
+      const float qa[4] = {qv.x, qv.y, qv.z, qv.w}, ba[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(qa[a], ba[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int cl = 4 * cq + a;
+      if (cl < nc) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (4 * n4 + b < Hq) dWp[(long)(c0 + cl) * Hq + 4 * n4 + b] = acc[a][b];
+      }
+    }
   }
   if (blockIdx.x == 0) {
-    const float* qrow = qs + kTailPc * JP;
     for (int n = threadIdx.x; n < Hq; n += 256) {
       float t = 0.f;
-      for (int j = 0; j < J1; ++j) t = fmaf(qrow[j], bm[j * ld + n], t);
+      for (int j = 0; j < J1; ++j) t = fmaf(qt[j * ldq + kTailPc], bm[j * ldb + n], t);
       dbiasp[n] = t;
     }
   }
+  // partB: tiles of 4 columns n x kTailFt fields
+  constexpr int kTailFt = 4;
+  const int nfg = (F + kTailFt - 1) / kTailFt;
   float* pb = partB + (long)blockIdx.x * Hq * F;
-  for (int idx = threadIdx.x; idx < Hq * F; idx += 256) {
-    const int n = idx / F, f = idx - n * F;
-    float t = 0.f;
-    for (int cl = 0; cl < nc; ++cl) t = fmaf(qs[cl * JP + 1 + f], Wp[(long)(c0 + cl) * Hq + n], t);
-    pb[idx] = t;
+  for (int tile = threadIdx.x; tile < nq * nfg; tile += 256) {
+    const int fg = tile / nq, n4 = tile - fg * nq;
+    float acc[kTailFt][4];
+#pragma unroll
+    for (int a = 0; a < kTailFt; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    const bool vec = (Hq & 3) == 0;
+    for (int cl = 0; cl < nc; ++cl) {
+      const float* wr = Wp + (long)(c0 + cl) * Hq + 4 * n4;
+      float wv[4];
+      if (vec) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wr);
+        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wv[b] = 4 * n4 + b < Hq ? wr[b] : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < kTailFt; ++a) {
+        const float qv = qt[min(1 + kTailFt * fg + a, F) * ldq + cl];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(qv, wv[b], acc[a][b]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < kTailFt; ++a) {
+      const int f = kTailFt * fg + a;
+      if (f < F) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (4 * n4 + b < Hq) pb[(4 * n4 + b) * F + f] = acc[a][b];
+      }
+    }
   }
 }
 
@@ -481,7 +588,7 @@ static __global__ __launch_bounds__(256) void cin_tail_fill_kernel(const float* 
 // With 4*NQ MFMA steps per tile instead of 64 the register contraction (2 FMAs per dZ element) is no longer a side show: the x
 // fragment and the dX accumulators live in REGISTERS here (the lane's A row is 20 registers instead of 64), so a slot costs its
 // two FMAs and nothing else; 32 rows per wave, two waves per SIMD.
-template <int JT, int NQ>
+template <int JT, int NQ, int SMODE = 0>
 __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __restrict__ Uz, const float* __restrict__ xT,
                                                               const float* __restrict__ xpT, int xps, const float* __restrict__ Y, int JP,
                                                               const float* __restrict__ dP, int ldp, int K, int lp, int lL,
@@ -546,6 +653,12 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
 #pragma unroll
   for (int hl = 0; hl < HPP; ++hl) xprev[hl] = xcur[hl] = gout[hl] = 0.f;
   int hprev = -HPP;
+  // (the prologue's loads are waited for once, here: merged with them the wait count at the top of the period loop collapses
+  // to vmcnt(0), i.e. the A-operand prefetch of the next tile is drained at every period -- see cin_fwd3_kernel)
+#pragma unroll
+  for (int s4 = 0; s4 < NQ; ++s4) settle(q[s4].x);
+#pragma unroll
+  for (int sx = 0; sx < JHp; ++sx) settle(areg[sx]);
 
   // contraction of slot rr of tile tpp (period base hb): compile-time (hl, j) after unrolling
   auto slot_apply = [&](const f32x16& d, const float (&xpv)[HPP], int hb, int tpp, int rr) {
@@ -602,16 +715,31 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
       for (int s4 = 0; s4 < NQ; ++s4) {
         const float4 w = q[s4];
         q[s4] = wnext[s4];
-        d = mfma32(w.x, areg[4 * s4 + 0], d);
-        d = mfma32(w.y, areg[4 * s4 + 1], d);
-        d = mfma32(w.z, areg[4 * s4 + 2], d);
-        d = mfma32(w.w, areg[4 * s4 + 3], d);
-        // the previous tile's 16 slots, spread over this tile's NQ step groups
+        auto slots = [&](int lo, int hi) {
 #pragma unroll
-        for (int sl = (16 * s4) / NQ; sl < (16 * (s4 + 1)) / NQ; ++sl) {
-          if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, sl);
-          else slot_apply(dprev, xcur, hbase, tp - 1, sl);
+          for (int sl = lo; sl < hi; ++sl) {
+            if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, sl);
+            else slot_apply(dprev, xcur, hbase, tp - 1, sl);
+          }
+        };
+        // the previous tile's 16 slots: SMODE 0 spread over this tile's NQ step groups (behind each group's 4 MFMAs);
+        // 1 all behind the first group; 2 all in front of the tile's first MFMA; 3 one slot behind each of the first 16 MFMAs
+        if (SMODE == 2 && s4 == 0) {
+          slots(0, 16);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d = mfma32(wv[e], areg[4 * s4 + e], d);
+          if (SMODE == 3 && 4 * s4 + e < 16) {
+            __builtin_amdgcn_sched_barrier(0);
+            slots(4 * s4 + e, 4 * s4 + e + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (SMODE == 0) slots((16 * s4) / NQ, (16 * (s4 + 1)) / NQ);
+        if (SMODE == 1 && s4 == 0) slots(0, 16);
         __builtin_amdgcn_sched_barrier(0);
       }
       dprev = d;

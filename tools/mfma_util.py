@@ -46,12 +46,19 @@ def main():
     for kind, prefix in (("fwd", "cin_fwd3_kernel"), ("bwd_dz", "cin_dz3_kernel"), ("bwd_dw", "cin_dw3_kernel<1,false")):
         # (instantiations whose last template argument is SPLIT = true belong to the split-bf16 experiment)
         hits = sorted((v["first_dispatch"], k) for k, v in res.items() if k.startswith(prefix) and not k.split(" grid=")[0].endswith(",true>"))
-        if len(hits) == 2:   # the two MFMA layers l = 1, 2: the forward visits l1 first, the backward l2 first
-            order = (1, 2) if kind == "fwd" else (2, 1)
-            for (_, k), l in zip(hits, order):
-                by_scope["cin_%s_l%d" % (kind, l)] = {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
-                                                     "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
-                                                     "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
+        order = ((1, 2) if kind == "fwd" else (2, 1)) if len(hits) == 2 else ((1,) if len(hits) == 1 else ())
+        # two general MFMA layers (l = 1, 2): the forward visits l1 first, the backward l2 first; with the fused tail only l1 is left
+        for (_, k), l in zip(hits, order):
+            by_scope["cin_%s_l%d" % (kind, l)] = {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
+                                                 "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
+                                                 "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
+    for scope, prefix in (("cin_fwd_tail", "cin_tail_fwd_kernel"), ("cin_bwd_dw_tail", "cin_tail_dw_kernel"), ("cin_bwd_dz_tail", "cin_tail_dz_kernel")):
+        hits = [k for k in res if k.startswith(prefix)]
+        if len(hits) == 1:
+            k = hits[0]
+            by_scope[scope] = {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
+                               "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
+                               "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
     with open(out, "w") as fh:
         json.dump({"definition": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "by_scope": by_scope,
                    "per_launch": res}, fh, indent=1, sort_keys=True)
