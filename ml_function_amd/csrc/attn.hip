@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 // nothing is computed twice (each wave runs the whole prologue + all key tiles of its own blocks and keeps its own partial dk /
 // dW / dgamma sums, merged after the loop), and a workgroup has twice the waves -- for the shapes whose LDS footprint lets only
 // one workgroup onto a CU (K = 64 layers of a stack, the f32 mode at large F) that is the second wave per SIMD.
-template <int NC, bool F16, int NB, int WPH>
+template <int NC, bool F16, int NB, int WPH, bool DXL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BWD_WPE(NC, F16)))) void attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
@@ -601,6 +601,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   } else {
     wt.init(Wq, Wk, Wr, d);
   }
+  // dx of the sample being processed, fp32 [NC][FP][16] (chunk-major like the head-major global layout), when the footprint
+  // allows (dx_lds): the heads' dq / dres parts are summed into it block by block, the dk part is added after the block loop,
+  // and it leaves once, as whole 1-KB rows.  Without it the dq part goes to global memory and is read back for the dk part
+  // ("second visit": +2 x |dx| of HBM traffic per launch -- 420 MB at K = 64, F = 200, B = 4096 -- in 64-byte pieces).
+  // (DXL: a compile-time choice -- this kernel sits at its register limit, a run-time branch costs it 100 more spilled registers)
+  float* dxs = nullptr;
+  if constexpr (DXL) dxs = reinterpret_cast<float*>(sp + (F16 ? (size_t)3 * NH * NC * 256 * sizeof(_Float16) : 0));
   row_write<F16>(kimg, d.FP + c, g, to_op<F16>(f32x4{0.f, 0.f, 0.f, 0.f}));   // the zero tile (never written again)
   __shared__ __attribute__((aligned(16))) float gamma_s[16];      // re-read per block: 4 registers less than keeping it
   if (threadIdx.x < 16) gamma_s[threadIdx.x] = (use_ln && (int)threadIdx.x < d.A) ? gamma[threadIdx.x] : 0.f;
@@ -829,10 +836,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
             if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), wt.arole(2, hh, cc, lane), px);
           }
           const int kin = 16 * cc + c;
+          if constexpr (DXL) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int f = 16 * bi + 4 * g + r;
-            buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);      // [query 4g+r][kin c]
+            for (int r = 0; r < 4; ++r) dxs[(cc * d.FP + 16 * bi + 4 * g + r) * 16 + c] = px[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int f = 16 * bi + 4 * g + r;
+              buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);      // [query 4g+r][kin c]
+            }
           }
         }
       }
@@ -871,6 +883,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     // (job (block j = WPH step + sub', chunk cc) belongs to wave (sub' NC + cc + step) % nw, as in the block loop: the same
     // lanes revisit the same elements; this wave's job of step `st` in round m is q = ((w - st) mod nw) + m nw)
     for (int m = 0; m * nw < WPH * NC; ++m) {
+      if constexpr (DXL) {
+        // (the dq part is in the LDS image: read, add the dk part, write back -- no batch of global read-backs to keep in registers)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int q = (w + nw - (j / WPH) % nw) % nw + m * nw, cc = q - (j % WPH) * NC;
+          if (j < d.nblk && cc >= 0 && cc < NC) {
+            float* pe = dxs + (cc * d.FP + 16 * j + 4 * g) * 16 + c;
+            f32x4 px = {pe[0], pe[16], pe[32], pe[48]};
+            for (int hh = 0; hh < NH; ++hh)
+              px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pe[16 * r] = px[r];
+          }
+        }
+      } else {
       f32x4 old[NB];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -893,6 +920,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
             const int f = 16 * j + 4 * g + r;
             buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);
           }
+        }
+      }
+      }
+    }
+    if constexpr (DXL) {
+      // the finished dx image leaves as 16-byte pieces, 1 KiB contiguous per wave instruction (the barrier at the top of the
+      // next sample keeps the image from being overwritten before every wave has stored its share)
+      lds_barrier();
+      const bool vec = (d.xcw & 3) == 0 && (d.K & 3) == 0;
+      const int per_ch = d.FP * 4, total = d.NC * per_ch;
+      for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int ch = idx / per_ch, rem = idx - ch * per_ch;
+        const int f = rem >> 2, k0 = 16 * ch + 4 * (rem & 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dxs + (ch * d.FP + f) * 16 + 4 * (rem & 3));
+        if (vec) {
+          buf_store4(r_dx, (f < d.F && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB, v);
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) buf_store1(r_dx, (f < d.F && k0 + s4 < d.K) ? 4 * x_off(d, b, f, k0 + s4) : kOOB, v[s4]);
         }
       }
     }
@@ -994,13 +1040,15 @@ static int make_dims(const char* fn, int B, int F, int K, int H, int A, int x_ch
 static size_t fwd_lds(const AttnDims& d, bool f16) {
   return f16 ? ((size_t)d.NC * d.FP * 16 + (size_t)d.H * d.FP * 16) * sizeof(_Float16) : (size_t)d.H * d.FP * 20 * sizeof(float);
 }
-static size_t bwd_lds(const AttnDims& d, bool f16, int wph = 1) {
+static size_t bwd_dx_lds(const AttnDims& d) { return (size_t)d.NC * d.FP * 16 * sizeof(float); }   // the sample's dx image
+static size_t bwd_lds(const AttnDims& d, bool f16, int wph = 1, bool dx_img = false) {
   const size_t tiles = (size_t)d.H * wph * 6 + 3 * (size_t)d.H * d.NC;   // per-wave tiles + the weight table
+  const size_t dxb = dx_img ? bwd_dx_lds(d) : 0;
   if (f16) {
     const size_t ximg = d.NC <= FIL_ATTN_XL_MAXNC ? (size_t)d.NC * d.FP * 16 : 0;
-    return (ximg + (size_t)d.H * (d.FP + 16) * 16 + tiles * 256) * sizeof(_Float16);
+    return (ximg + (size_t)d.H * (d.FP + 16) * 16 + tiles * 256) * sizeof(_Float16) + dxb;
   }
-  return ((size_t)d.H * (d.FP + 16) * 20 + (size_t)d.H * wph * 6 * 320) * sizeof(float);   // no weight table in the f32 mode
+  return ((size_t)d.H * (d.FP + 16) * 20 + (size_t)d.H * wph * 6 * 320) * sizeof(float) + dxb;   // no weight table in the f32 mode
 }
 constexpr size_t kLdsCap = 160 * 1024;
 constexpr int kMaxBwdGrid = 1024;   // persistent workgroups (the workspace holds this many partial sums)
@@ -1165,6 +1213,19 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   if (wph_knob == 1 || wph_knob == 2) wph = d.nblk > 8 ? wph_knob : 1;
   if (wph == 2 && (H > 4 || bwd_lds(d, f16, 2) > kLdsCap || d.nblk < 2)) wph = 1;
   sh = bwd_lds(d, f16, wph);
+  // dx image in LDS when it fits without costing a resident workgroup (FIL_ATTN_DX_LDS=0 keeps the global second visit)
+  static const int dxl_knob = [] {
+    const char* e = getenv("FIL_ATTN_DX_LDS");
+    return e != nullptr ? atoi(e) : 1;
+  }();
+  int dx_lds = 0;
+  if (dxl_knob != 0) {
+    const size_t sh2 = bwd_lds(d, f16, wph, true);
+    if (sh2 <= kLdsCap && kLdsCap / sh2 >= std::min<size_t>(kLdsCap / sh, 2)) {   // (at most two workgroups per CU run anyway: registers)
+      dx_lds = 1;
+      sh = sh2;
+    }
+  }
   const long Gws = std::min<long>(kMaxBwdGrid, 2L * B);
   Carver ws(workspace);
   float* wpart = ws.take<float>((size_t)Gws * 3 * K * H * A);
@@ -1185,13 +1246,15 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     ProfScope ps("attn_bwd", st, (double)B * H * (10.0 * F * (double)F * A + 2.0 * F * K * A * (has_res ? 9 : 7)));
     const dim3 block(64 * H * wph);
     int lrc = FIL_OK;
-#define CALL_BWD_NB(N, P, NBV, WV)                                                                                          \
-  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV, WV>, sh);                                                                 \
-  if (lrc == FIL_OK) {                                                                                                      \
-    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV, WV>, 64 * H * WV, sh), WV);                                  \
-    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV, WV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, \
-                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                             \
+#define CALL_BWD_NBD(N, P, NBV, WV, DX)                                                                                         \
+  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV, WV, DX>, sh);                                                                 \
+  if (lrc == FIL_OK) {                                                                                                          \
+    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV, WV, DX>, 64 * H * WV, sh), WV);                                  \
+    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV, WV, DX>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, \
+                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                                 \
   }
+#define CALL_BWD_NB(N, P, NBV, WV) \
+  if (dx_lds) { CALL_BWD_NBD(N, P, NBV, WV, true); } else { CALL_BWD_NBD(N, P, NBV, WV, false); }
   // (the two-waves-per-head form exists for the large-F instantiations only: smaller shapes fit two workgroups per CU)
 #define CALL_BWD(N, P)                                                                     \
   if (d.nblk <= 4) { CALL_BWD_NB(N, P, 4, 1); }                                            \
@@ -1201,6 +1264,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     FIL_ATTN_NC(d.NC, CALL_BWD)
 #undef CALL_BWD
 #undef CALL_BWD_NB
+#undef CALL_BWD_NBD
     if (lrc != FIL_OK) return fail(lrc, "fil_attn_bwd: cannot reserve %zu bytes of LDS", sh);
     FIL_CHECK_LAUNCH();
   }
