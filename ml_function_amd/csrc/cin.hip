@@ -197,11 +197,11 @@ struct TailDwPlan {
 };
 static TailDwPlan tail_dw_plan(long M, int C1) {
   TailDwPlan p;
-  p.blocks_x = cdiv(cdiv(C1, 16 * kTailCbw), 4);
-  const long unit = 4L * kTailDwDepth;
+  p.blocks_x = cdiv(C1, 16 * kTailCbw);           // one workgroup per channel block and row split (its 4 waves quarter the split)
+  const long unit = 4L * 4 * kTailDwDepth;        // a quarter of a split is a whole number of DEPTH-step groups
   // two workgroups per CU (two waves per SIMD: the second covers the first one's operand waits), all resident at once
   long want = knobs().tail_splits > 0 ? knobs().tail_splits : std::max<long>(1, 2L * cu_count() / p.blocks_x);
-  want = std::max<long>(want, (M + (1L << 22) - 1) >> 22);   // byte offsets of a split (rows * 256) stay below 2^31
+  want = std::max<long>(want, (M + (1L << 22) - 1) >> 22);   // byte offsets inside a split (rows * 256) stay below 2^31
   const long rows = std::max(unit, ((M + want - 1) / want + unit - 1) / unit * unit);
   p.rows_per_split = (int)rows;
   p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
@@ -243,7 +243,7 @@ static size_t wz_floats(const CinShape& s) {
   for (int l = 0; l < s.L; ++l) w = std::max(w, ((size_t)dz_periods(s, l) * cin_dz_tiles_per_period(s.JT()) + 1) * 32 * s.HS(l));
   w = w + w / 2;   // the split-bf16 planes (mode bit 1) take 6 bytes per weight instead of 4
   const TailGeom g = tail_geom(s);
-  if (g.on) w = std::max(w, (size_t)g.C1 * g.JP);   // fused tail: the reduced Q [C_p + 1][JP] sits here until the first pack
+  (void)g;
   return w;
 }
 // column chunks a layer's pooled partials may come in: its own, or (last layer pooled by the epilogue of the layer
@@ -267,8 +267,7 @@ static size_t dw_part_floats(const CinShape& s) {
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
   const TailGeom g = tail_geom(s);
   if (g.on) {   // fused tail: Q partials, then the dwsum_L partials of cin_tail_params_kernel
-    pmax = std::max(pmax, (size_t)tail_dw_plan(s.M(), g.C1).splits * g.C1 * g.JP);
-    pmax = std::max(pmax, (size_t)cdiv(g.Cp, kTailPc) * g.Hq * s.F);
+    pmax = std::max(pmax, (size_t)tail_dw_plan(s.M(), g.C1).splits * g.C1 * g.JP + (size_t)cdiv(g.Cp, kTailPc) * g.Hq * s.F);
   }
   return pmax;
 }
@@ -352,7 +351,31 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
   const float* xT = xt_in ? x : xT_own;
-  if (!xt_in) {
+  // fused tail: its slices of `saved` (behind xT and the maps of the layers below it)
+  float *tailY = nullptr, *tailUz = nullptr, *tailBmT = nullptr;
+  if (tail) {
+    Carver pv(saved);
+    (void)pv.take<float>((size_t)M * F);
+    for (int l = 0; l < tg.p; ++l) (void)pv.take<float>((size_t)M * s.HS(l));
+    tailY = pv.take<float>((size_t)M * tg.JP);
+    tailUz = pv.take<float>(tg.uz_floats + tg.uf_floats);   // Uz | Uf | consts: one buffer, one clear
+    tailBmT = pv.take<float>((size_t)tg.Hq * F);
+  }
+  // the exact pair-symmetric first layer + fused tail (the north-star path): every preparation job that depends on the inputs
+  // alone -- x transpose, first-layer weight pack, pooled weights of the last layer, clearing the tail's operand buffers -- in ONE
+  // launch instead of four
+  const bool prep_fused = tail && tune.sym && !split;
+  if (prep_fused) {
+    FIL_CHECK_ARG(W[0] && W[L - 1]);
+    ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
+    const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
+    const long npack = (long)chunks0 * F * 2 * JTs * 128;
+    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = cdiv(tg.Hq * F, 8), nz = 64;
+    const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
+    allow_lds(cin_fwd_prep_kernel, sh);
+    hipLaunchKernelGGL(cin_fwd_prep_kernel, dim3(nt + npk + nws + nz), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0,
+                       npk, W[L - 1], tailBmT, tg.Hq, tg.HL, nws, reinterpret_cast<float4*>(tailUz), (long)((tg.uz_floats + tg.uf_floats) / 4));
+  } else if (!xt_in) {
     ProfScope ps("cin_transpose_in", st, 2.0 * M * F * sizeof(float));
     hipLaunchKernelGGL(cin_transpose_in_kernel, dim3(B), dim3(256), (size_t)F * (K + 1) * sizeof(float), st, x, xT_own, F, K);
   }
@@ -365,17 +388,19 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       // ---- fused tail: layers p = L-2 and L-1 through Ueff = W_p [1 | wsum_L]: F+1 output columns instead of H_p
       const int lL = L - 1;
       FIL_CHECK_ARG(W[lL] && bias[lL]);
-      float* Y = sv.take<float>((size_t)M * tg.JP);
-      float* Uz = sv.take<float>(tg.uz_floats + tg.uf_floats);   // Uz | Uf | consts: one buffer, one clear
-      float* bmT = sv.take<float>((size_t)tg.Hq * F);
+      float* Y = tailY;
+      float* Uz = tailUz;
+      float* bmT = tailBmT;
       float* Uf = Uz + tg.uz_floats;
       float* consts = Uf + (size_t)tg.Hpp * tg.JT4 * 64 * tg.NCB;
       {
         ProfScope ps("cin_tail_prep", st);
-        hipLaunchKernelGGL(cin_tail_wsum_kernel, dim3(cdiv(tg.Hq * F, 8)), dim3(256), 0, st, W[lL], bmT, tg.Hq, F, tg.HL);
-        // (padding of the operand layouts -- f >= F, j > F, spare slots -- must be zero)
-        (void)hipMemsetAsync(Uz, 0, (tg.uz_floats + tg.uf_floats) * sizeof(float), st);
-        const size_t sh = (size_t)(F + 1) * (tg.Hq + 1) * sizeof(float);
+        if (!prep_fused) {
+          hipLaunchKernelGGL(cin_tail_wsum_kernel, dim3(cdiv(tg.Hq * F, 8)), dim3(256), 0, st, W[lL], bmT, tg.Hq, F, tg.HL);
+          // (padding of the operand layouts -- f >= F, j > F, spare slots -- must be zero)
+          (void)hipMemsetAsync(Uz, 0, (tg.uz_floats + tg.uf_floats) * sizeof(float), st);
+        }
+        const size_t sh = (size_t)(F + 1) * (((tg.Hq + 3) & ~3) + 4) * sizeof(float);
         allow_lds(cin_tail_ueff_kernel, sh);
         hipLaunchKernelGGL(cin_tail_ueff_kernel, dim3(cdiv(tg.C1, kTailUc)), dim3(256), sh, st, W[l], bias[l], bmT, bias[lL], tg.HL, Uf, Uz, consts,
                            tg.Hpp, F, tg.Hq, tg.JT4, tg.JP, JT, tg.JHp);
@@ -419,7 +444,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
                              reinterpret_cast<bf16x8*>(Wf), F, F, Hl, JTs, (F + hps - 1) / hps, chunks, 1, hps);
         } else {
           const long npack = (long)chunks * F * 2 * JTs * 128;
-          hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
+          if (!prep_fused)
+            hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
         }
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));   // (executed: unordered pairs)
         cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl, split);
@@ -541,16 +567,18 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   if (output_dim == 1) {
     ProfScope ps("cin_head_bwd", st);
     hipLaunchKernelGGL(cin_head_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, dense_w, pooled, dP, small, B, (int)LK, kHeadChunk);
-    hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
+    // (fused tail: the fixed-order sum of the head's partials rides in the tail's first launch, below)
+    if (!tail) hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
     FIL_CHECK_LAUNCH();
     dPsrc = dP;
   }
-  ready(L);
+  if (!tail) ready(L);
 
   int cur = 0;
   int ltop = L - 1;          // first layer handled by the general kernels
   bool dx_started = false;   // has dxT been initialised yet
   bool have_gx0 = false;     // did a general layer-1 kernel produce Gx^0
+  bool wz_prepacked = false; // fused tail with L == 3: layer 0's dZ weights were packed by the tail's first launch
   if (tail) {
     // ---- fused tail: both top layers' parameter gradients from Q = Z_p^T A (F+2 columns), data gradients from A Ueff^T
     const int p = tg.p, lL = L - 1;
@@ -559,12 +587,25 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const int xps = s.xps(p);
     const double algo = gemm_flops(M, tg.Hpp, F, tg.Hq) + gemm_flops(M, tg.Hq, F, tg.HL);   // the two layers of the reference graph
     float* Apk = Gbuf[1];
+    // the first general layer below the tail is the pair-symmetric layer 0 (L == 3): its slot-ordered weights can be packed now
+    // (nothing else uses the packed-W buffer any more), together with A and the head's partial sums -- one launch for the three
+    wz_prepacked = p == 1 && tune.sym && F >= 2 && !split;
     {
       ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
-      hipLaunchKernelGGL(cin_tail_a_kernel, dim3((int)std::min<long>((M * 16 * tg.NCB + 255) / 256, 8192)), dim3(256), 0, st, xT, dPsrc, (int)LK, K,
-                         p, lL, Apk, (int)M, F, tg.NCB);
+      const int na = (int)std::min<long>((M * 16 * tg.NCB + 255) / 256, 4096);
+      const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;
+      int np = 0, JTs = 0, tiles0 = 0;
+      if (wz_prepacked) {
+        FIL_CHECK_ARG(W[0]);
+        JTs = cin_jt_sym(F);
+        tiles0 = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
+        np = (int)std::min<long>(((long)tiles0 * 32 * s.HS(0) + 255) / 256, 1024);
+      }
+      hipLaunchKernelGGL(cin_tail_pre_kernel, dim3(na + nh + np), dim3(256), 0, st, xT, dPsrc, (int)LK, K, p, lL, Apk, (int)M, F, tg.NCB, na, small,
+                         ddense_w, ddense_b, (int)LK, nblk, nh, W[0], Wz, H[0], JTs, s.HS(0), tiles0);
     }
     FIL_CHECK_LAUNCH();
+    ready(L);
     const TailDwPlan tp = tail_dw_plan(M, tg.C1);
     {
       ProfScope ps("cin_bwd_dw_tail", st, algo, 2.0 * (double)M * tg.C1 * (F + 2));
@@ -572,18 +613,19 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       cin_launch_tail_dw(st, tg.NCB, a);
     }
     FIL_CHECK_LAUNCH();
-    float* Q = Wz;   // (the dZ kernels' packed-W buffer is idle until the first general layer packs into it)
     {
       ProfScope ps("cin_tail_params", st);
-      const long nQ = (long)tg.C1 * tg.JP;
-      hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nQ + 63) / 64)), dim3(256), 0, st, part, Q, nQ, tp.splits);
       const int nblk_p = cdiv(tg.Cp, kTailPc);
-      const size_t sh = ((size_t)(F + 1) * ((tg.Hq + 3) & ~3) + (size_t)tg.JP * (kTailPc + 4)) * sizeof(float);
+      const int ldb = (tg.Hq + 3) & ~3;
+      const size_t sh = ((size_t)(F + 1) * ldb + (size_t)tg.JP * (kTailPc + 4) + (size_t)kTailPc * ldb) * sizeof(float);
       allow_lds(cin_tail_params_kernel, sh);
-      // (the Q partials have been reduced: `part` now takes the dwsum_L partials)
-      hipLaunchKernelGGL(cin_tail_params_kernel, dim3(nblk_p), dim3(256), sh, st, Q, W[p], tailWsum, dW[p], dbias[p], part, tg.Cp, F, tg.Hq, tg.JP);
-      hipLaunchKernelGGL(cin_tail_fill_kernel, dim3(cdiv(tg.Hq * F, 64)), dim3(256), 0, st, part, nblk_p, Q, bias[p], dW[lL], dbias[lL], tg.Cp, F,
-                         tg.Hq, tg.HL, tg.JP);
+      // the dwsum_L partials go behind the Q partials in `part`; the reduced ones row of Q into the (idle) v buffer of the last-layer shortcut
+      float* partB = part + (size_t)tp.splits * tg.C1 * tg.JP;
+      float* qones = vlast;
+      hipLaunchKernelGGL(cin_tail_params_kernel, dim3(2 * nblk_p), dim3(256), sh, st, part, tp.splits, W[p], tailWsum, dW[p], dbias[p], partB, qones,
+                         tg.Cp, F, tg.Hq, tg.JP);
+      hipLaunchKernelGGL(cin_tail_fill_kernel, dim3(cdiv(tg.Hq * F, 64)), dim3(256), 0, st, partB, nblk_p, qones, bias[p], dW[lL], dbias[lL], F,
+                         tg.Hq, tg.HL);
     }
     FIL_CHECK_LAUNCH();
     ready(lL);
@@ -686,12 +728,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const long nW = (long)Cl * Hl;
     {
       ProfScope ps("cin_reduce_dw", st, (double)(parts + 1) * nW * sizeof(float));
-      // (the packed-W buffer of the dZ kernel is idle until this layer's pack below: scratch for the pair-indexed sum)
-      hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, symD > 0 ? Wz : dW[l], nW, parts);
-      if (symD > 0) {
-        const long full = (long)F * F * Hl;
-        hipLaunchKernelGGL(cin_expand_sym_kernel, dim3((int)std::min<long>((full + 255) / 256, 2048)), dim3(256), 0, st, Wz, dW[l], F, symD, Hl);
-      }
+      // (pair-indexed first layer: the fixed-order sum is written straight to both dW rows of each pair)
+      if (symD > 0) hipLaunchKernelGGL(cin_reduce_expand_sym_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, dW[l], F, symD, Hl, parts);
+      else hipLaunchKernelGGL(cin_reduce_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, dW[l], nW, parts);
     }
     FIL_CHECK_LAUNCH();
     ready(l);   // dW[l], dbias[l] final: the dZ kernel of this layer and everything below can overlap their all-reduce
@@ -714,7 +753,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
           const long nvec = (long)tiles * (HSl / 16) * 3 * 64;
           hipLaunchKernelGGL(cin_pack_wzb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
                              reinterpret_cast<bf16x8*>(Wz), F, F, Hl, JTs, HSl, tiles, 1);
-        } else {
+        } else if (!wz_prepacked) {
           hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
         }
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));

@@ -49,14 +49,16 @@ __device__ __forceinline__ void settle(f32x4s& v) { asm volatile("" : "+v"(v)); 
 constexpr int kQDepthMax = 10;
 
 // x [B,F,K] -> xT [M][F]   (one workgroup per sample, transposed through LDS)
-static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [F][K+1]
-  const long b = blockIdx.x;
+__device__ __forceinline__ void cin_transpose_in_body(const float* __restrict__ x, float* __restrict__ xT, int F, int K, long b, float* smem) {
   const float* src = x + b * F * K;
   for (int i = threadIdx.x; i < F * K; i += 256) smem[(i / K) * (K + 1) + (i % K)] = src[i];
   __syncthreads();
   float* dst = xT + b * K * F;
   for (int i = threadIdx.x; i < F * K; i += 256) dst[i] = smem[(i % F) * (K + 1) + (i / F)];
+}
+static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [F][K+1]
+  cin_transpose_in_body(x, xT, F, K, blockIdx.x, smem);
 }
 
 // dx [B,F,K] = dxT [M][F] (+ addT [M][F])
@@ -102,10 +104,10 @@ static __global__ __launch_bounds__(256) void cin_expand_sym_kernel(const float*
 
 // Symmetric first layer: Wf[chunk][h][d < JT2][128] = pair weight of (h, f = (h+d) mod F): W[(h,h)] for d = 0,
 // W[(h,f)] + W[(f,h)] for 0 < d <= F/2 (halved at d = F/2 when F is even: that pair is met from both ends), else 0.
-static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float* __restrict__ W, float* __restrict__ Wf, int F, int H, int JT2,
-                                                              int chunks) {
+__device__ __forceinline__ void cin_pack_wf_sym_body(const float* __restrict__ W, float* __restrict__ Wf, int F, int H, int JT2, int chunks,
+                                                     int bid, int nblocks) {
   const long total = (long)chunks * F * JT2 * 128;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)bid * 256 + threadIdx.x; i < total; i += (long)nblocks * 256) {
     const int col = (int)(i & 127);
     long t = i >> 7;
     const int d = (int)(t % JT2);
@@ -123,6 +125,10 @@ static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float
     }
     Wf[i] = v;
   }
+}
+static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float* __restrict__ W, float* __restrict__ Wf, int F, int H, int JT2,
+                                                              int chunks) {
+  cin_pack_wf_sym_body(W, Wf, F, H, JT2, chunks, blockIdx.x, gridDim.x);
 }
 
 // ---- split-bf16 ("bf16x3") operands -------------------------------------------------------------------------------
@@ -622,10 +628,10 @@ static __global__ __launch_bounds__(256) void cin_pack_wz_kernel(const float* __
 
 // Symmetric first layer: slot (h, j), parity hf <-> pair (h, f = (h + d) mod F), d = 2j + hf; weights as in
 // cin_pack_wf_sym_kernel.
-static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float* __restrict__ W, float* __restrict__ Wz, int F, int H, int JT,
-                                                              int NCOL, int tiles) {
+__device__ __forceinline__ void cin_pack_wz_sym_body(const float* __restrict__ W, float* __restrict__ Wz, int F, int H, int JT, int NCOL,
+                                                     int tiles, int bid, int nblocks) {
   const long total = (long)tiles * 32 * NCOL;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblocks * 256) {
     const int col = (int)(idx % NCOL);
     const long row = idx / NCOL;
     const int i = (int)(row & 31);
@@ -645,6 +651,10 @@ static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float
     }
     Wz[idx] = v;
   }
+}
+static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float* __restrict__ W, float* __restrict__ Wz, int F, int H, int JT,
+                                                              int NCOL, int tiles) {
+  cin_pack_wz_sym_body(W, Wz, F, H, JT, NCOL, tiles, blockIdx.x, gridDim.x);
 }
 
 // Split-bf16 form of Wz: [(tile*NT + t)*3 + plane][lane 64][8 bf16], NT = NCOL/16.  Element e of lane (r, half) is the
@@ -1389,11 +1399,11 @@ static __global__ __launch_bounds__(256) void cin_scale_rows3_kernel(const float
 // out[i] = sum_{p < parts} part[p*n + i]   (fixed order).  One workgroup per 64 outputs; the 4 waves take every 4th
 // partial (coalesced over i), then the 4 wave sums are added in wave order -> many loads in flight, fixed order.
 // out2 != nullptr: outputs i >= n1 go to out2[i - n1] (the dense head: ddense_w | ddense_b from one partial buffer, no copies).
-static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
-                                                         int parts, float* __restrict__ out2 = nullptr, long n1 = 0) {
+__device__ __forceinline__ void cin_reduce_body(const float* __restrict__ part, float* __restrict__ out, long n, int parts,
+                                                float* __restrict__ out2, long n1, int bid) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + lane;
+  const long i = (long)bid * 64 + lane;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   if (i < n) {
     int p = wave;
@@ -1411,6 +1421,44 @@ static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __r
     const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     if (out2 != nullptr && i >= n1) out2[i - n1] = v;
     else out[i] = v;
+  }
+}
+static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+                                                         int parts, float* __restrict__ out2 = nullptr, long n1 = 0) {
+  cin_reduce_body(part, out, n, parts, out2, n1, blockIdx.x);
+}
+
+// Pair-indexed first-layer weight gradient: fixed-order sum of the row-split partials (as cin_reduce_kernel: 64 outputs per
+// workgroup, the 4 waves take every 4th partial) written straight to BOTH dW rows of the pair (cin_expand_sym_kernel's map):
+// slot (h, d) <-> f = (h + d) mod F gives dW[(h,f)] and, unless d == 0 or 2d == F (that pair's other end has its own slot),
+// dW[(f,h)].
+static __global__ __launch_bounds__(256) void cin_reduce_expand_sym_kernel(const float* __restrict__ part, float* __restrict__ dW, int F, int D,
+                                                                    int H, int parts) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long n = (long)F * D * H;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (i < n) {
+    int p = wave;
+    for (; p + 12 < parts; p += 16) {
+      t0 += part[(long)p * n + i];
+      t1 += part[(long)(p + 4) * n + i];
+      t2 += part[(long)(p + 8) * n + i];
+      t3 += part[(long)(p + 12) * n + i];
+    }
+    for (; p < parts; p += 4) t0 += part[(long)p * n + i];
+  }
+  red[wave][lane] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int col = (int)(i % H);
+    const int pair = (int)(i / H);
+    const int h = pair / D, d = pair - h * D;
+    const int f = (h + d) % F;
+    dW[((long)h * F + f) * H + col] = v;
+    if (d != 0 && 2 * d != F) dW[((long)f * F + h) * H + col] = v;
   }
 }
 

@@ -90,8 +90,8 @@ __device__ __forceinline__ void settle_any(T& v) {
 // ---------------------------------------------------------------------------------------------------------------------
 // bmT[f][n] = wsum_L[(n,f)] = sum_n' W_L[(n*F + f), n']: the pooled weights of the last layer, stored so that Bm[1+f][.] is a
 // contiguous row (the staging loops below are coalesced).  One half wave per row of W_L.
-static __global__ __launch_bounds__(256) void cin_tail_wsum_kernel(const float* __restrict__ WL, float* __restrict__ bmT, int Hq, int F, int HL) {
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+__device__ __forceinline__ void cin_tail_wsum_body(const float* __restrict__ WL, float* __restrict__ bmT, int Hq, int F, int HL, int bid) {
+  const int row = bid * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   const int C = Hq * F;
   float t = 0.f;
   if (row < C)
@@ -100,6 +100,31 @@ static __global__ __launch_bounds__(256) void cin_tail_wsum_kernel(const float* 
   if (row < C && l == 0) {
     const int n = row / F, f = row - n * F;
     bmT[f * Hq + n] = t;
+  }
+}
+static __global__ __launch_bounds__(256) void cin_tail_wsum_kernel(const float* __restrict__ WL, float* __restrict__ bmT, int Hq, int F, int HL) {
+  cin_tail_wsum_body(WL, bmT, Hq, F, HL, blockIdx.x);
+}
+
+// One launch for the forward's independent preparation jobs (each ~4-9 us as a launch of its own, none of them busy for more
+// than a fraction of that): [0, nt) x -> xT transposes (one sample per workgroup); [nt, nt+npk) the pair-symmetric first
+// layer's packed weights; then the pooled weights of the last layer (bmT, 8 rows per workgroup); the rest clears the fused
+// tail's operand buffers.
+static __global__ __launch_bounds__(256) void cin_fwd_prep_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K, int nt,
+                                                           const float* __restrict__ W0, float* __restrict__ Wf, int H0, int JT2,
+                                                           int chunks, int npk, const float* __restrict__ WL, float* __restrict__ bmT,
+                                                           int Hq, int HL, int nws, float4* __restrict__ zero, long nzero4) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < nt) {
+    cin_transpose_in_body(x, xT, F, K, b, smem);
+  } else if (b < nt + npk) {
+    cin_pack_wf_sym_body(W0, Wf, F, H0, JT2, chunks, b - nt, npk);
+  } else if (b < nt + npk + nws) {
+    cin_tail_wsum_body(WL, bmT, Hq, F, HL, b - nt - npk);
+  } else {
+    const int nz = gridDim.x - (nt + npk + nws);
+    for (long i = (long)(b - nt - npk - nws) * 256 + threadIdx.x; i < nzero4; i += (long)nz * 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -122,10 +147,13 @@ static __global__ __launch_bounds__(256) void cin_tail_ueff_kernel(const float* 
                                                             const float* __restrict__ bmT, const float* __restrict__ biasL, int HL,
                                                             float* __restrict__ Uf, float* __restrict__ Uz, float* __restrict__ consts,
                                                             int Hpp, int F, int Hq, int JT4, int JP, int JT, int JHp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][Hq+1]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][ld], ld = Hq rounded up to 4, + 4: 16-byte aligned rows
   const int NCB = JP >> 4;
-  const int J1 = F + 1, ld = Hq + 1;
-  tail_stage_bm(bmT, smem, F, Hq, ld);
+  const int J1 = F + 1, ld = ((Hq + 3) & ~3) + 4;
+  for (int idx = threadIdx.x; idx < J1 * ld; idx += 256) {
+    const int j = idx / ld, n = idx - j * ld;
+    smem[idx] = n < Hq ? (j == 0 ? 1.f : bmT[(j - 1) * Hq + n]) : 0.f;   // (zero pad: the 4-wide loop below runs over it)
+  }
   __syncthreads();
   const int Cp = Hpp * F;
   if (blockIdx.x == 0 && threadIdx.x < 64) {
@@ -138,13 +166,29 @@ static __global__ __launch_bounds__(256) void cin_tail_ueff_kernel(const float* 
   const int c = blockIdx.x * kTailUc + cl;  // row Cp = the bias row (-> consts)
   if (c > Cp) return;
   const float* wrow = c < Cp ? Wp + (long)c * Hq : biasp;
+  const bool vec = (Hq & 3) == 0;
   float t[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int n = 0; n < Hq; ++n) {
-    const float w = wrow[n];
+  const float* brow[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) brow[cb] = smem + min(16 * cb + jg, F) * ld;
+  for (int n = 0; n < Hq; n += 4) {
+    float w[4];
+    if (vec) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wrow + n);
+      w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = n + e < Hq ? wrow[n + e] : 0.f;
+    }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const int j = 16 * cb + jg;
-      if (cb < NCB) t[cb] = fmaf(w, smem[min(j, F) * ld + n], t[cb]);
+      if (cb < NCB) {
+        const float4 b4 = *reinterpret_cast<const float4*>(brow[cb] + n);
+        t[cb] = fmaf(w[0], b4.x, t[cb]);
+        t[cb] = fmaf(w[1], b4.y, t[cb]);
+        t[cb] = fmaf(w[2], b4.z, t[cb]);
+        t[cb] = fmaf(w[3], b4.w, t[cb]);
+      }
     }
   }
   const int h = c / F, f = c - h * F;
@@ -293,10 +337,10 @@ __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------------------
 // A = dLoss/dY as the weight-gradient kernel's B operand: Apk[m][jj < 16][cb < NCB] = A[m][16cb + jj]
 //   A[m][0] = dP_p[m];  A[m][1+f] = dP_L[m] x[m,f];  A[m][F+1] = dP_L[m] (its column sum is dbias_L);  zero beyond.
-static __global__ __launch_bounds__(256) void cin_tail_a_kernel(const float* __restrict__ xT, const float* __restrict__ dP, int ldp, int K,
-                                                         int lp, int lL, float* __restrict__ Apk, int M, int F, int NCB) {
+__device__ __forceinline__ void cin_tail_a_body(const float* __restrict__ xT, const float* __restrict__ dP, int ldp, int K, int lp, int lL,
+                                                float* __restrict__ Apk, int M, int F, int NCB, int bid, int nblocks) {
   const long total = (long)M * 16 * NCB;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblocks * 256) {
     const int cb = (int)(idx % NCB);
     const long t = idx / NCB;
     const long m = t >> 4;
@@ -307,11 +351,25 @@ static __global__ __launch_bounds__(256) void cin_tail_a_kernel(const float* __r
     Apk[idx] = j == 0 ? dP[b * ldp + lp * K + k] : (j <= F ? dpl * xT[m * F + (j - 1)] : (j == F + 1 ? dpl : 0.f));
   }
 }
+// One launch for three independent jobs at the start of the backward: [0, na) A = dLoss/dY; [na, na+nh) the fixed-order sum of
+// the dense head's gradient partials; the rest (if any) the slot-ordered pair weights of the first layer's dZ kernel.
+static __global__ __launch_bounds__(256) void cin_tail_pre_kernel(const float* __restrict__ xT, const float* __restrict__ dP, int ldp, int K,
+                                                           int lp, int lL, float* __restrict__ Apk, int M, int F, int NCB, int na,
+                                                           const float* __restrict__ hpart, float* __restrict__ ddense_w,
+                                                           float* __restrict__ ddense_b, int LK, int hparts, int nh,
+                                                           const float* __restrict__ W0, float* __restrict__ Wz, int H0, int JTs, int HS0,
+                                                           int tiles) {
+  const int b = blockIdx.x;
+  if (b < na) cin_tail_a_body(xT, dP, ldp, K, lp, lL, Apk, M, F, NCB, b, na);
+  else if (b < na + nh) cin_reduce_body(hpart, ddense_w, (long)LK + 1, hparts, ddense_b, (long)LK, b - na);
+  else cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles, b - na - nh, gridDim.x - na - nh);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM of the fused tail: Q[c][j] = sum_m Z_p[m,c] A[m][j]  (c <= C_p: row C_p is an all-ones channel, whose
 // sums are dbeff / dbias_L), one row split per workgroup item, partials reduced in fixed order by cin_reduce_kernel.
-// Wave = CBW blocks of 16 channel rows x NCB blocks of 16 columns; step = 4 rows of m (reduction element kq = lane>>4).
+// Wave = CBW blocks of 16 channel rows x NCB blocks of 16 columns over a quarter of the workgroup's row split; step = 4 rows of m
+// (reduction element kq = lane>>4).
 //   A operand: x^{p-1}[m,h_c] * x[m,f_c]  (two dword gathers per channel block, raw buffer loads with scalar row offsets)
 //   B operand: Apk[m][i][0..NCB)          (one load of exactly NCB dwords)
 constexpr int kTailDwDepth = 8;
@@ -327,12 +385,15 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
   const int Cp = Hp * F, C1 = Cp + 1;
   const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, as in cin_dw3_kernel
   if (item >= items) return;
+  // Workgroup = one block of 16*CBW channel rows x one row split; its four waves take the four quarters of the split and their
+  // accumulators are folded through LDS (fixed order) into ONE partial per workgroup: a quarter of the partial sums to write and
+  // to reduce afterwards for the same number of waves in flight.
   const int bx = item % blocks_x;
   const int split = item / blocks_x;
-  const int c0 = (bx * 4 + wave) * (16 * CBW);
-  if (c0 >= C1) return;
-  const int m_lo = split * rows_per_split;
-  const int m_hi = min(M, m_lo + rows_per_split);
+  const int c0 = bx * (16 * CBW);
+  const int quarter = rows_per_split >> 2;             // (a multiple of 4 * DEPTH rows: the host rounds the split to that)
+  const int m_lo = min(M, split * rows_per_split + wave * quarter);
+  const int m_hi = min(M, min(m_lo + quarter, (split + 1) * rows_per_split));
   // the three descriptors cover exactly the split's rows [m_lo, m_hi): anything past them -- the last step's spare rows, the
   // prefetch beyond the end -- reads as zero, so the loop needs no row masks at all (0 * 0 products; 1 * A = 0 in the ones row)
   const long mrem = (long)m_hi - m_lo;
@@ -423,6 +484,26 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
   };
   if (c0 + 16 * CBW > Cp) run(std::true_type{});
   else run(std::false_type{});
+  // fold the four waves' sums: waves 1..3 park theirs in LDS, wave 0 adds them in wave order and stores
+  __shared__ float fold[3][CBW * NCB * 4][64];
+  if (wave > 0) {
+#pragma unroll
+    for (int cbk = 0; cbk < CBW; ++cbk)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fold[wave - 1][(cbk * NCB + cb) * 4 + e][lane] = acc[cbk][cb][e];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int cbk = 0; cbk < CBW; ++cbk)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[cbk][cb][e] += fold[w][(cbk * NCB + cb) * 4 + e][lane];
   // D[row = 4*kq + reg (channel of the block)][col = i]
   float* pout = part + (long)split * C1 * JP;
 #pragma unroll
@@ -438,36 +519,61 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dw_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Parameter gradients from Q [C_p + 1][JP].  One workgroup per kTailPc channel rows, two small register-tiled products:
+// Parameter gradients from the row-split partials of Q [splits][C_p + 1][JP].  One workgroup per kTailPc channel rows: it sums
+// its rows' partials in split order (the fixed-order reduction, no separate pass), stages them (transposed) next to Bm and its
+// rows of W_p in LDS, then two small register-tiled products:
 //   dW_p[c][n]        = sum_{j <= F} Q[c][j] Bm[j][n]                 thread tile 4 rows x 4 columns (16-byte LDS reads of both)
-//   partB[blk][(n,f)] = sum_{c in blk} Q[c][1+f] W_p[c][n]            thread tile 4 columns n x kTailFt fields (-> dwsum_L, reduced
-//                                                                     by cin_tail_fill_kernel)
-//   workgroup 0: dbias_p[n] = sum_j Q[C_p][j] Bm[j][n]
+//   partB[blk][(n,f)] = sum_{c in blk} Q[c][1+f] W_p[c][n]            thread tile 4 columns n x 4 fields (-> dwsum_L, reduced by
+//                                                                     cin_tail_fill_kernel)
+//   workgroup 0: dbias_p[n] = sum_j Q[C_p][j] Bm[j][n], and the reduced ones row Q[C_p][.] -> qones (cin_tail_fill_kernel)
 constexpr int kTailPc = 32;
-static __global__ __launch_bounds__(256) void cin_tail_params_kernel(const float* __restrict__ Q, const float* __restrict__ Wp,
+static __global__ __launch_bounds__(256) void cin_tail_params_kernel(const float* __restrict__ Qpart, int splits, const float* __restrict__ Wp,
                                                               const float* __restrict__ bmT, float* __restrict__ dWp,
-                                                              float* __restrict__ dbiasp, float* __restrict__ partB, int Cp, int F, int Hq,
-                                                              int JP) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][ldb] | Q^T [JP][kTailPc + 4]
+                                                              float* __restrict__ dbiasp, float* __restrict__ partB,
+                                                              float* __restrict__ qones, int Cp, int F, int Hq, int JP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // Bm [F+1][ldb] | Q^T [JP][kTailPc + 4] | W_p rows [kTailPc][ldb]
   const int J1 = F + 1;
   const int ldb = (Hq + 3) & ~3;            // 16-byte aligned rows
   constexpr int ldq = kTailPc + 4;
   float* bm = smem;
-  float* qt = smem + (size_t)J1 * ldb;      // qt[j][cl]: the workgroup's rows of Q, transposed; column kTailPc.. : the ones row
-  const int c0 = blockIdx.x * kTailPc;
+  float* qt = smem + (size_t)J1 * ldb;      // qt[j][cl]: the workgroup's rows of Q, transposed; column kTailPc: the ones row
+  float* wps = qt + (size_t)JP * ldq;
+  // (two workgroups per block of rows: the even one computes dW_p / dbias_p, the odd one the dwsum_L partials -- twice the
+  // workgroups in flight for a kernel whose ~150 workgroups would otherwise leave 100 CUs idle)
+  const int phase = blockIdx.x & 1, blk = blockIdx.x >> 1;
+  const int c0 = blk * kTailPc;
   const int nc = min(kTailPc, Cp - c0);
-  for (int idx = threadIdx.x; idx < J1 * Hq; idx += 256) {
-    const int j = idx / Hq, n = idx - j * Hq;
-    bm[j * ldb + n] = j == 0 ? 1.f : bmT[idx - Hq];
-  }
+  const long qstride = (long)(Cp + 1) * JP;
   for (int idx = threadIdx.x; idx < (kTailPc + 1) * JP; idx += 256) {
     const int cl = idx / JP, j = idx - cl * JP;
     const int c = cl < kTailPc ? c0 + cl : Cp;   // last staged row: the ones channel
-    qt[j * ldq + cl] = (cl == kTailPc || cl < nc) ? Q[(long)c * JP + j] : 0.f;
+    float t0 = 0.f, t1 = 0.f;
+    if (cl == kTailPc || cl < nc) {
+      const float* src = Qpart + (long)c * JP + j;
+      int sp = 0;
+      for (; sp + 1 < splits; sp += 2) {
+        t0 += src[(long)sp * qstride];
+        t1 += src[(long)(sp + 1) * qstride];
+      }
+      if (sp < splits) t0 += src[(long)sp * qstride];
+    }
+    qt[j * ldq + cl] = t0 + t1;
+  }
+  if (phase == 0) {
+    for (int idx = threadIdx.x; idx < J1 * ldb; idx += 256) {
+      const int j = idx / ldb, n = idx - j * ldb;
+      bm[idx] = n < Hq ? (j == 0 ? 1.f : bmT[(j - 1) * Hq + n]) : 0.f;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < kTailPc * ldb; idx += 256) {
+      const int cl = idx / ldb, n = idx - cl * ldb;
+      wps[idx] = (cl < nc && n < Hq) ? Wp[(long)(c0 + cl) * Hq + n] : 0.f;
+    }
   }
   __syncthreads();
   // dW_p: tiles of 4 rows x 4 columns
   const int nq = ldb >> 2;                  // column quads
+  if (phase == 0)
   for (int tile = threadIdx.x; tile < (kTailPc / 4) * nq; tile += 256) {
     const int cq = tile / nq, n4 = tile - cq * nq;
     float acc[4][4];
@@ -500,11 +606,13 @@ static __global__ __launch_bounds__(256) void cin_tail_params_kernel(const float
       for (int j = 0; j < J1; ++j) t = fmaf(qt[j * ldq + kTailPc], bm[j * ldb + n], t);
       dbiasp[n] = t;
     }
+    for (int j = threadIdx.x; j < JP; j += 256) qones[j] = qt[j * ldq + kTailPc];
   }
-  // partB: tiles of 4 columns n x kTailFt fields
+  if (phase == 0) return;
+  // partB: tiles of 4 columns n x 4 fields, both operands from LDS
   constexpr int kTailFt = 4;
   const int nfg = (F + kTailFt - 1) / kTailFt;
-  float* pb = partB + (long)blockIdx.x * Hq * F;
+  float* pb = partB + (long)blk * Hq * F;
   for (int tile = threadIdx.x; tile < nq * nfg; tile += 256) {
     const int fg = tile / nq, n4 = tile - fg * nq;
     float acc[kTailFt][4];
@@ -512,20 +620,16 @@ static __global__ __launch_bounds__(256) void cin_tail_params_kernel(const float
     for (int a = 0; a < kTailFt; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    const bool vec = (Hq & 3) == 0;
-    for (int cl = 0; cl < nc; ++cl) {
-      const float* wr = Wp + (long)(c0 + cl) * Hq + 4 * n4;
-      float wv[4];
-      if (vec) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wr);
-        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
-      } else {
+    const float* qrow[kTailFt];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) wv[b] = 4 * n4 + b < Hq ? wr[b] : 0.f;
-      }
+    for (int a = 0; a < kTailFt; ++a) qrow[a] = qt + min(1 + kTailFt * fg + a, F) * ldq;
+#pragma unroll 4
+    for (int cl = 0; cl < kTailPc; ++cl) {   // (rows past nc are zero in both images)
+      const float4 w4 = *reinterpret_cast<const float4*>(wps + cl * ldb + 4 * n4);
+      const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
       for (int a = 0; a < kTailFt; ++a) {
-        const float qv = qt[min(1 + kTailFt * fg + a, F) * ldq + cl];
+        const float qv = qrow[a][cl];
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(qv, wv[b], acc[a][b]);
       }
@@ -543,10 +647,10 @@ static __global__ __launch_bounds__(256) void cin_tail_params_kernel(const float
 }
 
 // dwsum_L[(n,f)] = sum_blk partB[blk][(n,f)] + Q[C_p][1+f] bias_p[n];  dW_L[(n,f)][n'] = dwsum_L[(n,f)] for every n';
-// workgroup 0: dbias_L[n'] = Q[C_p][F+1] (= sum_m dP_L[m]).  64 rows per workgroup, partial sums folded through LDS in fixed order.
-static __global__ __launch_bounds__(256) void cin_tail_fill_kernel(const float* __restrict__ partB, int parts, const float* __restrict__ Q,
+// workgroup 0: dbias_L[n'] = Q[C_p][F+1] (= sum_m dP_L[m]).  qones = the reduced ones row Q[C_p][.] (cin_tail_params_kernel).  64 rows per workgroup, partial sums folded through LDS in fixed order.
+static __global__ __launch_bounds__(256) void cin_tail_fill_kernel(const float* __restrict__ partB, int parts, const float* __restrict__ qones,
                                                             const float* __restrict__ biasp, float* __restrict__ dWL,
-                                                            float* __restrict__ dbiasL, int Cp, int F, int Hq, int HL, int JP) {
+                                                            float* __restrict__ dbiasL, int F, int Hq, int HL) {
   __shared__ float red[4][64];
   __shared__ float val[64];
   const int rows = Hq * F;
@@ -566,7 +670,7 @@ static __global__ __launch_bounds__(256) void cin_tail_fill_kernel(const float* 
   __syncthreads();
   if (g == 0 && row < rows) {
     const int n = row / F, f = row - n * F;
-    val[rl] = ((red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl])) + Q[(long)Cp * JP + 1 + f] * biasp[n];
+    val[rl] = ((red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl])) + qones[1 + f] * biasp[n];
   }
   __syncthreads();
   const int nrow = min(64, rows - r0);
@@ -575,7 +679,7 @@ static __global__ __launch_bounds__(256) void cin_tail_fill_kernel(const float* 
     dWL[(long)r0 * HL + idx] = val[r];
   }
   if (blockIdx.x == 0) {
-    const float s = Q[(long)Cp * JP + F + 1];
+    const float s = qones[F + 1];
     for (int n = threadIdx.x; n < HL; n += 256) dbiasL[n] = s;
   }
 }

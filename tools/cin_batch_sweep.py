@@ -29,7 +29,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        print("B=%5d  %.3f ms/step  %.3f M samples/s  (%.2f us/sample)" % (B, ms, B / ms / 1e3, ms * 1e3 / B))
+        from ml_function_amd import _lib
+        _lib.profile_begin("cin_fwd_,cin_bwd_dw_,cin_bwd_dz_")
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        pr = _lib.profile_end()
+        print("B=%5d  %.3f ms/step  %.3f M samples/s  (%.2f us/sample)   " % (B, ms, B / ms / 1e3, ms * 1e3 / B)
+              + "  ".join("%s %.3f" % (k.replace("cin_", ""), v["avg_ms"]) for k, v in sorted(pr.items())))
 
 if __name__ == "__main__":
     main()
