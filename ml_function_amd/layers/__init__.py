@@ -1,9 +1,11 @@
 from .base import Layer
 from .behavior_layer import MultHeadAttentionLayer, ProductAttentionLayer
-from .core_layer import Dense, DnnLayer, HiddenLayer, MergeScoreLayer, ResActivateLayer, ScoreLayer, StackLayer
-from .interactive_layer import (CIN, AttentionBaseLayer, CrossLayer, FmLayer, InnerLayer, IPnnLayer, LinearLayer, OPnnLayer,
-                                SparseEmbed)
+from .core_layer import (AlignLayer, Dense, DnnLayer, HiddenLayer, IntraViewPoolingLayer, MergeScoreLayer, ResActivateLayer, ScoreLayer,
+                         StackLayer)
+from .interactive_layer import (CIN, AttentionBaseLayer, CrossLayer, ExtractLayer, FmLayer, InnerLayer, IPnnLayer, LinearLayer,
+                                OPnnLayer, SparseEmbed)
 
 __all__ = ["Layer", "InnerLayer", "FmLayer", "CrossLayer", "CIN", "SparseEmbed", "ProductAttentionLayer",
            "MultHeadAttentionLayer", "StackLayer", "ScoreLayer", "MergeScoreLayer", "HiddenLayer", "ResActivateLayer",
-           "DnnLayer", "Dense", "IPnnLayer", "OPnnLayer", "LinearLayer", "AttentionBaseLayer"]
+           "DnnLayer", "Dense", "IPnnLayer", "OPnnLayer", "LinearLayer", "AttentionBaseLayer", "ExtractLayer",
+           "IntraViewPoolingLayer", "AlignLayer"]

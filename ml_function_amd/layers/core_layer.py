@@ -246,3 +246,34 @@ class DnnLayer(Layer):
         if self.output_dim != -1:
             x = self.logit_layer(x)
         return x
+
+
+class IntraViewPoolingLayer(Layer):
+    """IntraViewPoolingLayer (core_layer.py:228-238): mean over axis 1, kept as a size-1 axis -- [B,N,...] -> [B,1,...]."""
+
+    def __init__(self):
+        super().__init__()
+
+    def call(self, inputs, **kwargs):
+        return torch.mean(inputs, dim=1).unsqueeze(1)
+
+
+class AlignLayer(Layer):
+    """AlignLayer (core_layer.py:240-258): a list of tensors whose last dims differ is brought to the LARGEST last dim -- every
+    narrower input goes through its own Dense(max_dim) (no activation, glorot kernel, zero bias), the widest ones pass through
+    untouched.  build() creates `format_dense` = [Dense or None per input], like the reference."""
+
+    def __init__(self):
+        super().__init__()
+
+    def build(self, input_shape):
+        dim_list = [int(sh[-1]) for sh in input_shape]
+        max_dim = max(dim_list)
+        self.format_dense = [Dense(units=max_dim) if d < max_dim else None for d in dim_list]
+        for i, fd in enumerate(self.format_dense):
+            if fd is not None:
+                self.add_module("format_dense_%d" % i, fd)
+        super().build(input_shape)
+
+    def call(self, inputs, **kwargs):
+        return [fd(x) if fd is not None else x for x, fd in zip(inputs, self.format_dense)]

@@ -72,6 +72,42 @@ class IPnnLayer(Layer):
         return self.inner(inputs)
 
 
+class ExtractLayer(Layer):
+    """ExtractLayer (interactive_layer.py:82-109): picks, out of a list of per-feature tensors, the ones whose input is named in
+    `need_fea`.  `need_inputs` are the model's input descriptors, parallel to the list given to call(); the reference matches
+    Keras Input names with their ":0" suffix cut off (`input_.name[:-2]`), so both an object with such a `.name` and a plain
+    feature-name string are accepted here.  need_remove=True returns [picked, rest] instead of the picked list.
+    compute_mask: None unless mask_zero, then the picked inputs' masks."""
+
+    def __init__(self, need_fea, need_inputs, supports_masking=True, mask_zero=False, need_remove=False):
+        super().__init__()
+        self.need_fea = need_fea
+        self.need_inputs = need_inputs
+        self.supports_masking = supports_masking
+        self.mask_zero = mask_zero
+        self.need_remove = need_remove
+
+    @staticmethod
+    def _name(inp):
+        if isinstance(inp, str):
+            return inp
+        n = inp.name
+        return n[:-2] if n.endswith(":0") else n
+
+    def call(self, inputs, **kwargs):
+        self.need_idx = [i for i, inp in enumerate(self.need_inputs) if self._name(inp) in self.need_fea]
+        need_inputs = [inputs[i] for i in self.need_idx]
+        if self.need_remove:
+            picked = set(self.need_idx)
+            return [need_inputs, [t for i, t in enumerate(inputs) if i not in picked]]
+        return need_inputs
+
+    def compute_mask(self, inputs, mask=None):
+        if not self.mask_zero:
+            return None
+        return [mask[i] for i in self.need_idx]
+
+
 class OPnnLayer(Layer):
     """OPnnLayer (interactive_layer.py:111-143).  Its InnerLayer(use_inner=False, ...) reads the attribute the
     reference never defines, so calling it raises AttributeError there; the same here (kept for constructor parity)."""

@@ -276,3 +276,30 @@ def test_pmc_traffic_summary_and_bench_lookup(tmp_path, monkeypatch):
     assert bench.pmc_traffic("cin_bwd_dz_l2")[0] == (2 * 30.0 + 3.0) * 1024   # backward visits layer 2 first
     assert bench.pmc_traffic("cin_bwd_dz_l1")[0] == (2 * 40.0 + 4.0) * 1024
     assert bench.pmc_traffic("cin_head_fwd") == (None, None)
+
+
+def test_extract_pool_align_layers():
+    """The list / pooling glue of SURVEY section 2 rows 1-2 (interactive_layer.py:82-109, core_layer.py:228-258): pure torch, CPU."""
+    from collections import namedtuple
+    from ml_function_amd.layers import AlignLayer, ExtractLayer, IntraViewPoolingLayer
+    Inp = namedtuple("Inp", ["name"])
+    descr = [Inp("C1:0"), Inp("C2:0"), "I3", Inp("C4:0")]
+    ts = [torch.full((2, 1, 3), float(i)) for i in range(4)]
+    ex = ExtractLayer(need_fea=["C2", "I3"], need_inputs=descr)
+    out = ex(ts)
+    assert [float(t[0, 0, 0]) for t in out] == [1.0, 2.0] and ex.need_idx == [1, 2]
+    assert ex.compute_mask(ts, mask=["m0", "m1", "m2", "m3"]) is None
+    ex2 = ExtractLayer(need_fea=["C4"], need_inputs=descr, mask_zero=True, need_remove=True)
+    picked, rest = ex2(ts)
+    assert [float(t[0, 0, 0]) for t in picked] == [3.0] and [float(t[0, 0, 0]) for t in rest] == [0.0, 1.0, 2.0]
+    assert ex2.compute_mask(ts, mask=["m0", "m1", "m2", "m3"]) == ["m3"]
+    x = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
+    p = IntraViewPoolingLayer()(x)
+    assert p.shape == (2, 1, 4) and torch.allclose(p[:, 0], x.mean(1))
+    al = AlignLayer()
+    ins = [torch.randn(5, 4), torch.randn(5, 7), torch.randn(5, 2, 7), torch.randn(5, 3)]
+    outs = al(ins)
+    assert [o.shape[-1] for o in outs] == [7, 7, 7, 7] and outs[1] is ins[1] and outs[2] is ins[2]
+    assert [fd is None for fd in al.format_dense] == [False, True, True, False]
+    assert torch.allclose(outs[0], ins[0] @ al.format_dense[0].kernel + al.format_dense[0].bias)
+    assert float(al.format_dense[3].bias.abs().sum()) == 0.0 and len(list(al.parameters())) == 4
