@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 205
+#define FIL_ABI_VERSION 206
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -104,6 +104,9 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *         + FIL_CIN_NOTAIL (32): mode 0 without the fused tail (last layer through wsum_L only: the round-2 path);
  *           FIL_CIN_TAIL_ALWAYS (64): the fused tail whenever it is defined (L >= 3, F <= 62), also where it saves nothing
  *           (by default it is used when F+2 columns padded to 16 are at most 3/4 of H_{L-1}); both exist for tests / comparison.
+ *         + FIL_CIN_NOKSPLIT (128): small batches (B*K <= 16,384 rows) give each block of 32 rows to the FOUR waves of a workgroup,
+ *           which split the reduction between them (strong-scaling shards: without it the row-parallel kernels stop getting faster
+ *           below one row block per SIMD); this bit keeps one wave per row block.  Same function up to summation order.
  *         + FIL_CIN_MB2 (4) / FIL_CIN_NOSYM (8): per-call launch-shape overrides (64-row waves in the row-parallel kernels,
  *             i.e. the launch configuration large batches get by themselves; symmetric first-layer kernels off).  Same
  *             function up to summation order; they exist so that tests can reach every instantiation at small sizes.
@@ -153,7 +156,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
 enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
-                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64 };
+                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);

@@ -55,24 +55,36 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_SYM=0         symmetric first-layer kernels off
 //   FIL_CIN_DW_MB, FIL_CIN_DW_SPLITS, FIL_CIN_DZ_MB   launch shape of the dW / dZ kernels
 //   FIL_CIN_TAIL_SPLITS   row splits of the fused tail's weight-gradient kernel
+//   FIL_CIN_KSPLIT=0|4    reduction split of the row-parallel kernels over the 4 waves of a workgroup (default: by M)
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
 struct CinTune {
   int mb_forced;
-  bool sym;
-  explicit CinTune(int mode) : mb_forced((mode & FIL_CIN_MB2) ? 2 : knobs().mb), sym(knobs().sym != 0 && !(mode & FIL_CIN_NOSYM)) {}
+  bool sym, no_ksplit;
+  explicit CinTune(int mode)
+      : mb_forced((mode & FIL_CIN_MB2) ? 2 : knobs().mb), sym(knobs().sym != 0 && !(mode & FIL_CIN_NOSYM)), no_ksplit((mode & FIL_CIN_NOKSPLIT) != 0) {}
   int mb_rows(long M) const {
     if (mb_forced == 1 || mb_forced == 2) return mb_forced;
     return cdiv((int)std::min<long>(M, 1L << 30), 64) >= 768 ? 2 : 1;
+  }
+  // Small M (a strong-scaling shard: 512 samples x K = 16 is 256 blocks of 32 rows for 1024 SIMDs): a wave reduces over ALL
+  // channels of its rows, so below one row block per SIMD the row-parallel kernels stop getting faster.  ks = 4 gives a row
+  // block to the four waves of a workgroup, which split the reduction (h range / periods) and fold their partial sums through
+  // LDS.  Used when that still leaves at most two waves per SIMD; exact kernels with 32-row blocks only.
+  int ksplit(long M) const {
+    if (knobs().ksplit == 0 || no_ksplit) return 1;
+    if (mb_rows(M) != 1) return 1;
+    if (knobs().ksplit == 4) return 4;
+    return cdiv((int)std::min<long>(M, 1L << 30), 32) <= 512 ? 4 : 1;
   }
 };
 
@@ -324,8 +336,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 127)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS)", mode);
+  if (mode < 0 || mode > 255)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
@@ -410,7 +422,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         const double algo = gemm_flops(M, tg.Hpp, F, tg.Hq) + gemm_flops(M, tg.Hq, F, tg.HL);   // the two layers of the reference graph
         ProfScope ps("cin_fwd_tail", st, algo, 2.0 * (double)M * tg.Cp * (F + 1));
         const int RB = tune.mb_rows(M) == 2 ? 4 : 2;
-        TailFwdArgs a{xT, xpT, s.xps(l), Uf, consts, Y, tg.JP, const_cast<float*>(pa.part[l]), const_cast<float*>(pa.part[lL]), (int)M, F, tg.Hpp};
+        TailFwdArgs a{xT, xpT, s.xps(l), Uf, consts, Y, tg.JP, const_cast<float*>(pa.part[l]), const_cast<float*>(pa.part[lL]), (int)M, F, tg.Hpp,
+                      tune.ksplit(M)};
         cin_launch_tail_fwd(st, RB, tg.JT4, tg.NCB, a);
         pa.chunks[l] = pa.chunks[lL] = 1;
       }
@@ -448,7 +461,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
             hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
         }
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));   // (executed: unordered pairs)
-        cin_launch_fwd3_sym(st, MB, JTs, dim3(cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hl, split);
+        const int ks = split ? 1 : tune.ksplit(M);
+        cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part,
+                            (int)M, F, Hl, split, ks);
       } else {
         long npack = (long)chunks * Hp * 2 * JT * 128;
         if (split) {
@@ -495,8 +510,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 127)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS)", mode);
+  if (mode < 0 || mode > 255)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
@@ -632,7 +647,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ready(p);
     {
       ProfScope ps("cin_bwd_dz_tail", st, algo, 2.0 * (double)M * tg.Cp * (F + 1));
-      TailDzArgs a{tailUz, xT, xpT, xps, tailY, tg.JP, dPsrc, (int)LK, K, p, lL, Gbuf[cur], s.HS(p - 1), dxT, (int)M, F, tg.Hpp, tg.periods, knobs().tail_dz_mode};
+      TailDzArgs a{tailUz, xT, xpT, xps, tailY, tg.JP, dPsrc, (int)LK, K, p, lL, Gbuf[cur], s.HS(p - 1), dxT, (int)M, F, tg.Hpp, tg.periods, knobs().tail_dz_mode,
+                   tune.ksplit(M)};
       cin_launch_tail_dz(st, JT, tg.NQ, a);
     }
     FIL_CHECK_LAUNCH();
@@ -757,7 +773,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
           hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
         }
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));
-        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(cdiv((int)M, 128 * MBs)), G, HSl, Wz, xT, gx0T, dxT, dx_started ? 1 : 0, (int)M, F, Hl, periods, split);
+        const int ks = (split || NHMAX != 64 || MBs != 1) ? 1 : tune.ksplit(M);
+        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), G, HSl, Wz, xT, gx0T, dxT,
+                           dx_started ? 1 : 0, (int)M, F, Hl, periods, split, ks);
       } else {
         const int periods = dz_periods(s, l);
         const int tiles = periods * cin_dz_tiles_per_period(JT) + 1;

@@ -232,7 +232,11 @@ static __global__ __launch_bounds__(256) void cin_pack_wb_kernel(const float* __
 //
 // SPLIT (opt-in, general layers): the main loop runs on split-bf16 operands (see above); Wf then points to the
 // cin_pack_wb_kernel layout.  Prologue, epilogue and the fused next-layer pooling are shared with the fp32 form.
-template <int MB, int JT, bool SYM = false, bool SPLIT = false>
+//
+// KS > 1 (exact kernels only; small M: fewer row blocks than SIMDs): KS waves of the workgroup share one row block and split the
+// reduction over h between them; the partial accumulators are folded through LDS in wave order and the group's first wave runs
+// the epilogue (see cin_tail_fwd_kernel).
+template <int MB, int JT, bool SYM = false, bool SPLIT = false, int KS = 1>
 __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                           const float* __restrict__ Wf, const float* __restrict__ bias,
                                                           float* __restrict__ xoutT, int HS, float* __restrict__ pool_part, int M,
@@ -242,11 +246,17 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   // queue depth: the largest divisor of JT not above kQDepthMax (slot j % DEPTH must mean the same step in every h)
   constexpr int DEPTH = JT <= kQDepthMax ? JT : (JT % 10 == 0 ? 10 : (JT % 8 == 0 ? 8 : (JT % 7 == 0 ? 7 : (JT % 6 == 0 ? 6 : 4))));
   static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(KS == 1 || !SPLIT, "the h split exists for the exact kernels");
+  const int tid = threadIdx.x, lane = tid & 63, wave = KS == 1 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
   const int chunk = blockIdx.y;
-  const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
-  if (wrow0 >= M) return;  // whole wave past the end (no barriers in this kernel)
+  const int kpart = wave % KS;
+  const int wrow0 = ((blockIdx.x * 4 + wave) / KS) * (32 * MB);
+  if (KS == 1 && wrow0 >= M) return;  // whole wave past the end (no barriers in this kernel unless KS > 1)
+  const int hq_ = (Hp + KS - 1) / KS;
+  const int h_lo = KS == 1 ? 0 : min(Hp, kpart * hq_);
+  const int h_hi = KS == 1 ? Hp : (wrow0 < M ? min(Hp, h_lo + hq_) : h_lo);
+  const int hs = min(h_lo, Hp - 1);
   long mq[MB];
   bool vq[MB];
   float xr[MB][JT];   // (unused by the SYM + SPLIT form: it keeps a sliding window instead)
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     }
   }
   if constexpr (SYM && !SPLIT) {
-    load_x(0, xn);
+    load_x(hs, xn);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -478,13 +488,13 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   const float4* wbase = reinterpret_cast<const float4*>(Wf + (long)chunk * Hp * (2 * JT) * 128) + (half * 32 + r);
     float4 q[DEPTH];
   #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) q[d] = wbase[(long)(2 * d) * 32];
+    for (int d = 0; d < DEPTH; ++d) q[d] = wbase[(long)hs * (2 * JT) * 32 + (long)(2 * d) * 32];
     const float* xprow[MB];
     float xpv[MB], xpn[MB];
   #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       xprow[mb] = xpT + mq[mb] * xps;
-      xpv[mb] = xprow[mb][0];
+      xpv[mb] = xprow[mb][hs];
       xpn[mb] = 0.f;
     }
     // Every prologue load is waited for HERE, once.  The compiler orders the prologue's loads as it likes; when the operand of
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   #pragma unroll
     for (int mb = 0; mb < MB; ++mb) settle(xpv[mb]);
   #pragma unroll 1
-    for (int h = 0; h < Hp; ++h) {
+    for (int h = h_lo; h < h_hi; ++h) {
       const bool more = h + 1 < Hp;
       // (branch-free: a conditional load makes the compiler's wait-count bookkeeping fall back to vmcnt(0) at the top of
       // every h, which drains the whole operand queue once per h -- ~1,500 idle cycles against 10,240 of MFMA work)
@@ -537,6 +547,27 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     }
   }
 
+  if constexpr (KS > 1) {
+    __shared__ float fold[3][MB * 64][64];   // (wave 0 never parks)
+    if (kpart > 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) fold[wave - 1][(mb * 4 + nb) * 16 + e][lane] = acc[mb][nb][e];
+    }
+    __syncthreads();
+    if (kpart > 0 || wrow0 >= M) return;
+#pragma unroll
+    for (int k = 1; k < KS; ++k)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mb][nb][e] += fold[wave + k - 1][(mb * 4 + nb) * 16 + e][lane];
+  }
   // ---- epilogue: + bias, store [M][HS] (lane r owns columns 4r..4r+3 of the chunk), sum-pool over columns
   float bv[4];
 #pragma unroll
@@ -733,7 +764,10 @@ constexpr int kGlStride = 36;    // floats per buffered row: 16-byte aligned, ro
 // of 6 bf16 MFMAs per row block (accumulator layout, slot order and the register contraction are unchanged).
 // (exact general kernel at 32 rows per wave, H <= 128: two waves per SIMD are part of the design -- the register budget is held
 // to 256; the split forms sit just below it on their own and schedule better without the cap)
-template <int MB, int JT, int NHMAX, bool SYM = false, bool SPLIT = false>
+// KS > 1 (pair-symmetric exact kernel only; small M): KS waves of the workgroup share one block of rows and split the periods
+// (values of h) between them; each writes the Gx columns of its own h range, the dX partial sums meet in the LDS scratch
+// (see cin_tail_dz_kernel).
+template <int MB, int JT, int NHMAX, bool SYM = false, bool SPLIT = false, int KS = 1>
 __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2 : 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
                                                          const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                          const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
@@ -746,10 +780,15 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
   constexpr int NQ = NHMAX / 4;
   constexpr int P = JT / gcd_c(16, JT);
   constexpr int HPP = 16 * P / JT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(KS == 1 || (SYM && !SPLIT), "the period split exists for the exact pair-symmetric kernel");
+  const int tid = threadIdx.x, lane = tid & 63, wave = KS == 1 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
-  const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
-  if (wrow0 >= M) return;
+  const int kpart = wave % KS;
+  const int wrow0 = ((blockIdx.x * 4 + wave) / KS) * (32 * MB);
+  if (KS == 1 && wrow0 >= M) return;
+  const int pq_ = (periods + KS - 1) / KS;
+  const int per_lo = KS == 1 ? 0 : min(periods, kpart * pq_);
+  const int per_hi = KS == 1 ? periods : (wrow0 < M ? min(periods, per_lo + pq_) : per_lo);
   float* xs = SYM ? smem + wave * 32 + r : smem + tid;                                    // xs[(mb*JT + j)*256]   | SYM: xs[(mb*FR + f)*kSymStride]
   float* dxs = SYM ? xs + MB * FR * kSymStride : smem + MB * JT * 256 + tid;              // dxs[(mb*JT + j)*256]  | SYM: same shape as xs
   constexpr bool GLINE = !SYM;                                                             // (the first layer has no G^{l-1})
@@ -830,7 +869,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
     for (int t = 0; t < QD; ++t) fetch_a(t, aq[t]);
   } else {
 #pragma unroll
-    for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[s4];
+    for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[(long)per_lo * P * kTileStride + s4];
   }
   float gx[MB];
 #pragma unroll
@@ -937,7 +976,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
   slot_fetch(hprev, P - 1, 0);
 
 #pragma unroll 1
-  for (int per = 0; per < periods; ++per) {
+  for (int per = per_lo; per < per_hi; ++per) {
     const int hbase = per * HPP;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -1034,7 +1073,12 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
   // dX rows of the wave are contiguous in dxT ([32*MB rows][F]): written cooperatively from the LDS scratch so that
   // every store instruction covers whole lines (one lane per row element = a 156-byte stride = 8-16x write
   // amplification in WRITE_SIZE)
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (KS > 1) {
+    __syncthreads();
+    if (kpart > 0 || wrow0 >= M) return;
+  } else {
+    __builtin_amdgcn_wave_barrier();
+  }
   const float* dsc = smem + (SYM ? MB * FR * kSymStride + wave * 32 : MB * JT * 256 + wave * 64);
 #pragma unroll 1
   for (int mb = 0; mb < MB; ++mb) {
@@ -1043,7 +1087,11 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2
     float* dst = dxT + (long)row0 * F;
     for (int idx = lane; idx < nrow * F; idx += 64) {
       const int rr = idx / F, f = idx - rr * F;
-      const float v = SYM ? dsc[(mb * FR + f) * kSymStride + rr] : dsc[(mb * JT + (f >> 1)) * 256 + (f & 1) * 32 + rr];
+      float v = SYM ? dsc[(mb * FR + f) * kSymStride + rr] : dsc[(mb * JT + (f >> 1)) * 256 + (f & 1) * 32 + rr];
+      if constexpr (KS > 1) {   // (SYM only) the group's partial sums, in wave order
+#pragma unroll
+        for (int k = 1; k < KS; ++k) v += dsc[(mb * FR + f) * kSymStride + rr + 32 * k];
+      }
       dst[idx] = accumulate ? dst[idx] + v : v;
     }
   }

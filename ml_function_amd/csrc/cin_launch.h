@@ -10,8 +10,10 @@ inline int cin_jt_of(int F) { return ((F + 1) / 2 + 3) / 4 * 4; }
 // steps per h of the symmetric first-layer kernels: d = 0..F/2 in pairs, rounded up to an even count (menu 2..18)
 inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
 
+// ks = 4: four waves share a block of 32 rows and split the reduction over h (small M; exact kernels, MB = 1 only; the grid must
+// then be cdiv(M, 32) workgroups in x)
 void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT,
-                         int HS, float* pool_part, int M, int F, int H, bool split = false);
+                         int HS, float* pool_part, int M, int F, int H, bool split = false, int ks = 1);
 
 // split-bf16 form of the symmetric first layer: h per super-period, and floats of its packed weight planes
 inline int cin_sym_hps(int JTs) { return JTs % 4 == 0 ? 4 : 8; }
@@ -39,7 +41,7 @@ void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* 
 
 // symmetric first layer (x^{l-1} = x); FR = field rows of the LDS scratch (see cin_dz_sym_rows)
 void cin_launch_dz3_sym(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
-                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods, bool split = false);
+                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods, bool split = false, int ks = 1);
 
 // tiles per period / h per period of the dZ kernel for a given JT (mirrors the constexprs in cin_dz3_kernel)
 inline int cin_gcd(int a, int b) { return b == 0 ? a : cin_gcd(b, a % b); }
@@ -66,6 +68,7 @@ struct TailFwdArgs {
   int JP;
   float *pool_p, *pool_L;
   int M, F, Hp;
+  int ks;   // 4: four waves share a row block and split the reduction over h (RB = 2 only)
 };
 void cin_launch_tail_fwd(hipStream_t st, int RB, int JT4, int NCB, const TailFwdArgs& a);
 struct TailDwArgs {
@@ -88,6 +91,7 @@ struct TailDzArgs {
   float* dxT;
   int M, F, Hp, periods;
   int smode;
+  int ks;   // 4: four waves share a block of 32 rows and split the periods
 };
 void cin_launch_tail_dz(hipStream_t st, int JT, int NQ, const TailDzArgs& a);
 

@@ -219,17 +219,26 @@ constexpr int tail_depth(int JT4) {
 // Wave = RB blocks of 16 rows x NCB blocks of 16 columns.  Lane (i = lane&15, kq = lane>>4): A operand = row 16rb+i, reduction
 // element kq of the step <-> field f = 4*j4 + kq;  B operand = Uf (one 16-byte load per step and lane: its NCB columns 16cb+i).
 // The x fragment x[m, 4*j4 + kq] lives in registers (JT4 per row block), x^{p-1}[m,h] is one dword per h and row block.
-template <int RB, int JT4, int NCB>
+//
+// KS > 1 (small M: fewer row blocks than SIMDs): KS waves of the workgroup share one row block and split the reduction over h
+// between them (wave kpart takes h in [kpart*ceil(Hp/KS), ...)); the partial accumulators are folded through LDS in wave order
+// and the first wave of the group runs the epilogue.  A wave reduces over ALL channels of its rows whatever M is, so without the
+// split the kernel's time stops shrinking below one row block per SIMD (DESIGN.md section 6, strong scaling).
+template <int RB, int JT4, int NCB, int KS = 1>
 __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                               const float* __restrict__ Uf, const float* __restrict__ consts,
                                                               float* __restrict__ Y, int JP, float* __restrict__ pool_p,
                                                               float* __restrict__ pool_L, int M, int F, int Hp) {
   constexpr int DEPTH = tail_depth(JT4);
   static_assert(JT4 % DEPTH == 0, "queue depth must divide the steps per h");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4;
-  const int wrow0 = (blockIdx.x * 4 + wave) * (16 * RB);
-  if (wrow0 >= M) return;
+  const int kpart = wave % KS;
+  const int wrow0 = ((blockIdx.x * 4 + wave) / KS) * (16 * RB);
+  const int hq = (Hp + KS - 1) / KS;
+  const int h_lo = KS == 1 ? 0 : min(Hp, kpart * hq);
+  const int h_hi = KS == 1 ? Hp : (wrow0 < M ? min(Hp, h_lo + hq) : h_lo);   // (row blocks past M: no work, but the barrier below is met)
+  if (KS == 1 && wrow0 >= M) return;
   long mq[RB];
   float xr[RB][JT4];
 #pragma unroll
@@ -255,14 +264,15 @@ __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __res
   const __amdgpu_buffer_rsrc_t ru = make_rsrc(Uf, (long)Hp * JT4 * kStepBytes);
   const int uo = lane * NCB * 4;
   typename BV::T q[DEPTH];
+  const int hs = min(h_lo, Hp - 1);   // first h of this wave (clamped: an empty range still issues its in-range prologue loads)
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) q[d] = BV::load(ru, uo, d * kStepBytes);
+  for (int d = 0; d < DEPTH; ++d) q[d] = BV::load(ru, uo, (hs * JT4 + d) * kStepBytes);
   const float* xprow[RB];
   float xpv[RB], xpn[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     xprow[rb] = xpT + mq[rb] * xps;
-    xpv[rb] = xprow[rb][0];
+    xpv[rb] = xprow[rb][hs];
     xpn[rb] = 0.f;
   }
   // every prologue load is waited for once, HERE: the wait count at the top of the h loop then comes from the back edge alone
@@ -279,8 +289,8 @@ __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __res
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) ac[rb] = xpv[rb] * xr[rb][0];
 #pragma unroll 1
-  for (int h = 0; h < Hp; ++h) {
-    const bool more = h + 1 < Hp;
+  for (int h = h_lo; h < h_hi; ++h) {
+    const bool more = h + 1 < Hp;   // (the prefetch may run into the next wave's h range: in range, never used)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) xpn[rb] = xprow[rb][more ? h + 1 : h];
     const int sh = h * JT4 * kStepBytes;                            // (scalar byte offsets: no per-load address arithmetic)
@@ -304,6 +314,27 @@ __global__ __launch_bounds__(256, 1) void cin_tail_fwd_kernel(const float* __res
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) xpv[rb] = xpn[rb];
+  }
+  if constexpr (KS > 1) {
+    __shared__ float fold[4][RB * NCB * 4][64];
+    if (kpart > 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fold[wave][(rb * NCB + cb) * 4 + e][lane] = acc[rb][cb][e];
+    }
+    __syncthreads();
+    if (kpart > 0 || wrow0 >= M) return;
+#pragma unroll
+    for (int k = 1; k < KS; ++k)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[rb][cb][e] += fold[wave + k][(rb * NCB + cb) * 4 + e][lane];
   }
   // ---- epilogue: + beff, store Y [M][JP] (16 consecutive columns per row and store), the two pools
   float be[NCB];
@@ -692,7 +723,9 @@ static __global__ __launch_bounds__(256) void cin_tail_fill_kernel(const float* 
 // With 4*NQ MFMA steps per tile instead of 64 the register contraction (2 FMAs per dZ element) is no longer a side show: the x
 // fragment and the dX accumulators live in REGISTERS here (the lane's A row is 20 registers instead of 64), so a slot costs its
 // two FMAs and nothing else; 32 rows per wave, two waves per SIMD.
-template <int JT, int NQ, int SMODE = 0>
+// KS > 1 (small M): KS waves of the workgroup share one block of 32 rows and split the PERIODS (values of h) between them; each
+// writes the G^{p-1} columns of its own h range, the dX partial sums meet in the LDS staging area.
+template <int JT, int NQ, int SMODE = 0, int KS = 1>
 __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __restrict__ Uz, const float* __restrict__ xT,
                                                               const float* __restrict__ xpT, int xps, const float* __restrict__ Y, int JP,
                                                               const float* __restrict__ dP, int ldp, int K, int lp, int lL,
@@ -702,10 +735,16 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
   constexpr int JHp = 4 * NQ;
   constexpr int P = JT / gcd_c(16, JT);
   constexpr int HPP = 16 * P / JT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
-  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
-  if (wrow0 >= M) return;
+  const int kpart = wave % KS;
+  const int wrow0 = ((blockIdx.x * 4 + wave) / KS) * 32;
+  if (KS == 1 && wrow0 >= M) return;
+  // this wave's periods: [per_lo, per_hi); whole 32-column lines of G^{p-1} per wave (the line buffer is flushed line by line)
+  constexpr int kLinePer = HPP >= 32 ? 1 : 32 / HPP;
+  const int pq = ((periods + KS - 1) / KS + kLinePer - 1) / kLinePer * kLinePer;
+  const int per_lo = KS == 1 ? 0 : min(periods, kpart * pq);
+  const int per_hi = KS == 1 ? periods : (wrow0 < M ? min(periods, per_lo + pq) : per_lo);
   float* gl = smem + JT * 256 + wave * (32 * kGlStride);
   const int m = wrow0 + r;
   const bool vq = m < M;
@@ -729,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
     for (int j = 0; j < JT; ++j) {
       const int keep = (vq && 2 * j + half < F) ? -1 : 0;
       xr[j] = __builtin_bit_cast(float, __builtin_bit_cast(int, xt[j]) & keep);
-      dxa[j] = dpl * __builtin_bit_cast(float, __builtin_bit_cast(int, yt[j]) & keep);
+      dxa[j] = (KS == 1 || kpart == 0) ? dpl * __builtin_bit_cast(float, __builtin_bit_cast(int, yt[j]) & keep) : 0.f;   // (the direct term: once)
     }
     float at[JHp];
 #pragma unroll
@@ -748,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
   constexpr long kTileStride = 64L * NQ;  // float4 per tile
   float4 q[NQ];
 #pragma unroll
-  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[s4];
+  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[(long)per_lo * P * kTileStride + s4];
   float gx = 0.f;
   f32x16 dprev;
 #pragma unroll
@@ -801,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
   };
 
 #pragma unroll 1
-  for (int per = 0; per < periods; ++per) {
+  for (int per = per_lo; per < per_hi; ++per) {
     const int hbase = per * HPP;
 #pragma unroll
     for (int hl = 0; hl < HPP; ++hl) {
@@ -860,13 +899,21 @@ __global__ __launch_bounds__(256, 2) void cin_tail_dz_kernel(const float* __rest
   float* dxs = smem + tid;
 #pragma unroll
   for (int j = 0; j < JT; ++j) dxs[j * 256] = dxa[j];
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (KS > 1) {
+    __syncthreads();
+    if (kpart > 0 || wrow0 >= M) return;
+  } else {
+    __builtin_amdgcn_wave_barrier();
+  }
   const float* dsc = smem + wave * 64;
   const int nrow = min(32, M - wrow0);
   float* dst = dxT + (long)wrow0 * F;
   for (int idx = lane; idx < nrow * F; idx += 64) {
     const int rr = idx / F, f = idx - rr * F;
-    dst[idx] = dsc[(f >> 1) * 256 + (f & 1) * 32 + rr];
+    float v = dsc[(f >> 1) * 256 + (f & 1) * 32 + rr];
+#pragma unroll
+    for (int k = 1; k < KS; ++k) v += dsc[(f >> 1) * 256 + (f & 1) * 32 + rr + 64 * k];   // the group's partial sums, in wave order
+    dst[idx] = v;
   }
 }
 

@@ -6,6 +6,13 @@ namespace fil {
 
 template <int RB, int JT4, int NCB>
 static void tail_fwd(hipStream_t st, const TailFwdArgs& a) {
+  if constexpr (RB == 2) {
+    if (a.ks == 4) {   // one row block per workgroup, its four waves split the reduction over h
+      hipLaunchKernelGGL((cin_tail_fwd_kernel<2, JT4, NCB, 4>), dim3(cdiv(a.M, 32)), dim3(kCinThreads), 0, st, a.xT, a.xpT, a.xps, a.Uf, a.consts,
+                         a.Y, a.JP, a.pool_p, a.pool_L, a.M, a.F, a.Hp);
+      return;
+    }
+  }
   const dim3 grid(cdiv(a.M, 64 * RB));
   hipLaunchKernelGGL((cin_tail_fwd_kernel<RB, JT4, NCB>), grid, dim3(kCinThreads), 0, st, a.xT, a.xpT, a.xps, a.Uf, a.consts, a.Y, a.JP,
                      a.pool_p, a.pool_L, a.M, a.F, a.Hp);
@@ -47,13 +54,25 @@ static void tail_dz(hipStream_t st, const TailDzArgs& a) {
                      a.ldp, a.K, a.lp, a.lL, a.GprevT, a.HSp, a.dxT, a.M, a.F, a.Hp, a.periods);
 }
 
+template <int JT, int NQ>
+static void tail_dz_ks4(hipStream_t st, const TailDzArgs& a) {
+  const size_t sh = ((size_t)JT * 256 + (size_t)4 * 32 * kGlStride) * sizeof(float);
+  if (sh > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_tail_dz_kernel<JT, NQ, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL((cin_tail_dz_kernel<JT, NQ, 0, 4>), dim3(cdiv(a.M, 32)), dim3(kCinThreads), sh, st, a.Uz, a.xT, a.xpT, a.xps, a.Y, a.JP, a.dP,
+                     a.ldp, a.K, a.lp, a.lL, a.GprevT, a.HSp, a.dxT, a.M, a.F, a.Hp, a.periods);
+}
+
 void cin_launch_tail_dz(hipStream_t st, int JT, int NQ, const TailDzArgs& a) {
-#define FIL_TZ(J)                                        \
-  case J:                                                \
-    if (NQ == J / 4) tail_dz<J, J / 4, 0>(st, a);        \
-    else tail_dz<J, J / 4 + 1, 0>(st, a);                \
+#define FIL_TZ(J)                                                                   \
+  case J:                                                                           \
+    if (a.ks == 4) {                                                                \
+      if (NQ == J / 4) tail_dz_ks4<J, J / 4>(st, a);                                \
+      else tail_dz_ks4<J, J / 4 + 1>(st, a);                                        \
+    } else if (NQ == J / 4) tail_dz<J, J / 4, 0>(st, a);                            \
+    else tail_dz<J, J / 4 + 1, 0>(st, a);                                           \
     break;
-  if (a.smode != 0 && JT == 20 && NQ == 5) {   // (experiment: slot placement variants at the north-star shape only)
+  if (a.smode != 0 && a.ks != 4 && JT == 20 && NQ == 5) {   // (experiment: slot placement variants at the north-star shape only)
     if (a.smode == 1) tail_dz<20, 5, 1>(st, a);
     else if (a.smode == 2) tail_dz<20, 5, 2>(st, a);
     else tail_dz<20, 5, 3>(st, a);

@@ -193,15 +193,15 @@ def test_cin_large_batch_rows_beyond_2_pow_21():
     dw, db = dev(c["dense_w"]), dev(c["dense_b"])
     gout = torch.randn((B, 1), device="cuda", generator=g)
 
-    def run(xs, gs):
+    def run(xs, gs, mode=0):
         xs = xs.clone().requires_grad_()
         W2 = [w.clone().requires_grad_() for w in Ws]
-        out = Fn.cin(xs, W2, bs, dw, db)
+        out = Fn.cin(xs, W2, bs, dw, db, mode=mode)
         out.backward(gs)
         return out.detach(), xs.grad, [w.grad for w in W2]
 
     out, dx, dW = run(x, gout)
-    out_s, dx_s, _ = run(x[:64], gout[:64])
+    out_s, dx_s, _ = run(x[:64], gout[:64], mode=128)   # (128: one wave per row block, the summation order of the large batch)
     assert torch.equal(out[:64], out_s) and torch.equal(dx[:64], dx_s)
     h = B // 2
     _, _, dWa = run(x[:h], gout[:h])
@@ -318,8 +318,8 @@ CIN_SHAPES = [
 
 
 @pytest.mark.parametrize("B,F,K,conv", CIN_SHAPES)
-@pytest.mark.parametrize("output_dim", [1, 2])
-@pytest.mark.parametrize("mode", [0, 1])  # 0: last-layer shortcut, 1: every layer through the general GEMM kernels
+# mode 0: shortcuts (+ the reduction split of small batches), 1: general GEMM kernels, 128: shortcuts, one wave per row block
+@pytest.mark.parametrize("output_dim,mode", [(1, 0), (2, 0), (1, 1), (2, 1), (1, 128)])
 def test_cin(B, F, K, conv, output_dim, mode):
     from ml_function_amd import functional as Fn
     c = synth.cin_case(B, F, K, conv, dist="uniform", output_dim=output_dim)
@@ -365,8 +365,8 @@ TAIL_SHAPES = [
 
 
 @pytest.mark.parametrize("B,F,K,conv", TAIL_SHAPES)
-@pytest.mark.parametrize("output_dim", [1, 2])
-@pytest.mark.parametrize("mode", [64, 64 | 4])   # (| 4: the 64-row waves large batches get)
+# (| 4: the 64-row waves large batches get; | 128: one wave per row block instead of the small-batch reduction split)
+@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 4), (1, 64 | 128)])
 def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
     from ml_function_amd import functional as Fn
     c = synth.cin_case(B, F, K, conv, dist="uniform", output_dim=output_dim)
@@ -387,6 +387,32 @@ def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
     if output_dim == 1:
         check("tail ddense_w", dw.grad, ddw)
         check("tail ddense_b", db.grad, ddb)
+
+
+@pytest.mark.parametrize("B", [128, 512, 1024])
+@pytest.mark.parametrize("mode", [0, 128])
+def test_cin_small_batches_of_the_benchmark_shape(B, mode):
+    """A strong-scaling shard of the benchmark (global B = 4096 over 8 / 32 GPUs: 512 / 128 samples, and 1024): mode 0 splits the
+    reduction of every row-parallel kernel over the four waves of a workgroup (fil.h FIL_CIN_NOKSPLIT), mode 128
+    keeps one wave per row block -- both against the fp64 oracle, and against each other to fp32 reassociation."""
+    from ml_function_amd import functional as Fn
+    c = synth.cin_case(B, 39, 16, [128, 128, 128])
+    x = dev(c["x"]).requires_grad_()
+    Ws = [dev(w).requires_grad_() for w in c["Ws"]]
+    bs = [dev(b).requires_grad_() for b in c["bs"]]
+    dw, db = dev(c["dense_w"]).requires_grad_(), dev(c["dense_b"]).requires_grad_()
+    out = Fn.cin(x, Ws, bs, dw, db, mode=mode)
+    check("shard out", out, closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"]))
+    out.backward(dev(c["g"]))
+    dx, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"])
+    check("shard dx", x.grad, dx, tol=2e-5)
+    for l in range(3):
+        check("shard dW%d" % l, Ws[l].grad, dWs[l], tol=2e-5)
+        check("shard db%d" % l, bs[l].grad, dbs[l], tol=2e-5)
+    check("shard ddense_w", dw.grad, ddw, tol=2e-5)
+    if mode == 0:
+        other = Fn.cin(dev(c["x"]), [dev(w) for w in c["Ws"]], [dev(b) for b in c["bs"]], dev(c["dense_w"]), dev(c["dense_b"]), mode=128)
+        assert not torch.equal(out, other) and rel(out, other.detach().cpu().numpy()) < 1e-5      # other kernels ran, same function
 
 
 def test_cin_fused_tail_is_the_default_where_it_pays():
