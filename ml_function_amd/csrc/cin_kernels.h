@@ -507,6 +507,9 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     for (int d = 0; d < DEPTH; ++d) settle(q[d].x);
   #pragma unroll
     for (int mb = 0; mb < MB; ++mb) settle(xpv[mb]);
+    float ac[MB], an[MB];
+  #pragma unroll
+    for (int mb = 0; mb < MB; ++mb) ac[mb] = xpv[mb] * xr[mb][0];
   #pragma unroll 1
     for (int h = h_lo; h < h_hi; ++h) {
       const bool more = h + 1 < Hp;
@@ -520,14 +523,24 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   #pragma unroll
       for (int j = 0; j < JT; ++j) {
         const float4 w = q[j % DEPTH];
+        // the A operands of step j+1 as one block in front of step j's MFMAs: a v_mul whose result feeds the very next MFMA costs
+        // its VALU -> MFMA operand wait states on the matrix pipe (tools/probe_mfma16.hip)
   #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const float a = xpv[mb] * xr[mb][j];
+          if (j + 1 < JT) an[mb] = xpv[mb] * xr[mb][j + 1];
+          else an[mb] = xpn[mb] * (SYM ? xn[SYM ? mb : 0][0] : xr[mb][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float a = ac[mb];
           acc[mb][0] = mfma32(a, w.x, acc[mb][0]);
           acc[mb][1] = mfma32(a, w.y, acc[mb][1]);
           acc[mb][2] = mfma32(a, w.z, acc[mb][2]);
           acc[mb][3] = mfma32(a, w.w, acc[mb][3]);
         }
+  #pragma unroll
+        for (int mb = 0; mb < MB; ++mb) ac[mb] = an[mb];
         __builtin_amdgcn_sched_barrier(0);
         // refill this slot with the operand of step j + DEPTH (possibly in the next h) -- AFTER the step's MFMAs were issued,
         // so the load may land in the registers it replaces: when JT == DEPTH every slot is refilled once per h and a refill
@@ -1135,27 +1148,26 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   // descriptors start at the split's first row (offsets stay far below the 2 GiB descriptor range for any M) and end
   // with the tensor, so the prefetch past the last row reads zeros
   const int m_lo = split * rows_per_split;
-  const long mrem = (long)M - m_lo;
+  const int m_hi = min(M, m_lo + rows_per_split);
+  // the descriptors cover exactly the split's rows [m_lo, m_hi): the last step's spare row and the prefetch past the end read
+  // zeros, so the loop needs no row masks (0 * 0 products); channel rows past C compute finite values that are never stored
+  const long mrem = (long)m_hi - m_lo;
   const __amdgpu_buffer_rsrc_t rg = make_rsrc(gT + (long)m_lo * HS, mrem * HS * 4);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(XONES ? gT : xT + (long)m_lo * F, mrem * F * 4);
   const __amdgpu_buffer_rsrc_t rp = make_rsrc(xpT + (long)m_lo * xps, mrem * xps * 4);
   int fo[MB], ho[MB];
-  bool cv[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int c = c0 + mb * 32 + r;
-    cv[mb] = c < C;
-    const int cc = cv[mb] ? c : C - 1;
+    const int cc = c < C ? c : C - 1;
     const int hh = symD > 0 ? cc / symD : cc / F;
     const int ff = symD > 0 ? (hh + (cc - hh * symD)) % F : cc - hh * F;
     ho[mb] = (half * xps + hh) * 4;            // byte offsets of the lane's column inside row (m_lo + half)
     fo[mb] = (half * F + ff) * 4;
   }
   const int go = (half * HS + chunk * 128 + 4 * r) * 4;
-  const int m_hi = min(M, m_lo + rows_per_split);
   const int steps = (m_hi - m_lo + 1) >> 1;
   const int groups = (steps + DEPTH - 1) / DEPTH;
-  const int mlane = m_lo + half;
 
   f32x16 acc[MB][4];
 #pragma unroll
@@ -1180,23 +1192,29 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) fetch(d, qg[d], qx[d], qp[d]);
+  // the generated operand of step s+1 is computed in front of step s's MFMAs and consumed a step later (a v_mul feeding the very
+  // next MFMA costs its VALU -> MFMA operand wait states on the matrix pipe, tools/probe_mfma16.hip)
+  float ac[MB], an[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) ac[mb] = qx[0][mb] * qp[0][mb];
 #pragma unroll 1
   for (int g = 0; g < groups; ++g) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int s = g * DEPTH + d;
       const f32x4v g4 = qg[d];
-      float a[MB];
-      const bool live = mlane + 2 * s < m_hi;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = (live && cv[mb]) ? qx[d][mb] * qp[d][mb] : 0.f;
+      for (int mb = 0; mb < MB; ++mb) an[mb] = qx[(d + 1) % DEPTH][mb] * qp[(d + 1) % DEPTH][mb];   // (slot 0: refilled with the next group's first step)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        acc[mb][0] = mfma32(a[mb], g4[0], acc[mb][0]);
-        acc[mb][1] = mfma32(a[mb], g4[1], acc[mb][1]);
-        acc[mb][2] = mfma32(a[mb], g4[2], acc[mb][2]);
-        acc[mb][3] = mfma32(a[mb], g4[3], acc[mb][3]);
+        acc[mb][0] = mfma32(ac[mb], g4[0], acc[mb][0]);
+        acc[mb][1] = mfma32(ac[mb], g4[1], acc[mb][1]);
+        acc[mb][2] = mfma32(ac[mb], g4[2], acc[mb][2]);
+        acc[mb][3] = mfma32(ac[mb], g4[3], acc[mb][3]);
       }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) ac[mb] = an[mb];
       __builtin_amdgcn_sched_barrier(0);
       // the refill comes AFTER the step's MFMAs so that it may land in the registers it replaces: loaded into fresh registers,
       // the eight slots have to be copied back at the end of every group, and those copies wait for every load of the group
