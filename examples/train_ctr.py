@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--dense", type=int, default=13)
     ap.add_argument("--embed-dim", type=int, default=16)
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run every step eagerly (default on one GPU: the whole step -- forward, backward, Adam -- is captured once "
+                         "into a HIP graph and replayed; the C ABI neither allocates nor synchronises, so it is capture-safe)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -72,9 +75,12 @@ def main():
     # l2(emb_reg) of the tables: added analytically after the sparse exchange (see dp.add_table_l2_grad_), identically per replica
     table_l2 = {id(m.embeddings): m.table_l2_ranges() for m in model.modules() if hasattr(m, "table_l2_ranges") and m.built}
     others = [p for n, p in model.named_parameters() if not n.endswith("embeddings")]
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr, eps=1e-7)      # Keras 'adam' (un_seq.py:61)
+    use_graph = world == 1 and not args.no_graph
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, eps=1e-7, capturable=use_graph)      # Keras 'adam' (un_seq.py:61)
     pipe = data.data_pipeline(table, batch_size=args.batch, shuffle_buffer=2048, repeat=2, prefetch=2, seed=rank, device=device)
-    for step, (dense, idx, y) in enumerate(pipe):
+
+    def train_step(dense, idx, y):
+        """forward + loss + backward + (data-parallel exchange) + Adam; returns (bce, p) of the batch"""
         opt.zero_grad(set_to_none=True)
         out = model(dense if use_dense else None, idx)
         p = (out[:, 1] if out.shape[1] == 2 else out[:, 0]).clamp(1e-6, 1 - 1e-6)
@@ -95,8 +101,35 @@ def main():
             if t.grad is not None and table_l2.get(id(t)):
                 dp.add_table_l2_grad_(t.grad, t.detach(), table_l2[id(t)])
         opt.step()
+        return bce.detach(), p.detach()
+
+    graph, static = None, None
+    for step, (dense, idx, y) in enumerate(pipe):
+        full = idx.shape[0] == args.batch            # (the last batch of the pipeline can be short: it runs eagerly)
+        if use_graph and full:
+            if graph is None:
+                # static input buffers; three eager steps on a side stream (lazy initialisations, allocator warm-up), then capture
+                static = [torch.empty_like(dense), torch.empty_like(idx), torch.empty_like(y)]
+                for dst, src in zip(static, (dense, idx, y)):
+                    dst.copy_(src)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        train_step(*static)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                opt.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    static_out = train_step(*static)
+            for dst, src in zip(static, (dense, idx, y)):
+                dst.copy_(src)
+            graph.replay()
+            bce, p = static_out
+        else:
+            bce, p = train_step(dense, idx, y)
         if rank == 0 and (step % 20 == 0 or step == len(pipe) - 1):
-            print("step %4d  loss %.4f  auc %.4f" % (step, float(bce.detach()), metrics.auc(y, p.detach())), flush=True)
+            print("step %4d  loss %.4f  auc %.4f" % (step, float(bce), metrics.auc(y, p)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

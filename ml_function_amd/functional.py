@@ -430,7 +430,7 @@ def product_attention(q, k, v, use_scale=False, mask=None, mask_mod=1):
 _SORT_CACHE = []
 
 
-def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None):
+def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None):
     """layout_key: a hashable description of (offsets, sizes, frozen) -- two tables with the same field layout (SparseEmbed
     passes its word sizes / frozen flags) share the sort even though their offset tensors are different objects."""
     lib = _lib.load()
@@ -444,13 +444,18 @@ def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None):
     B, F = idx.shape
     row_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
     check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
-    out = torch.sort(row_ids, stable=True)
+    # (n_rows = rows of the concatenated table: when the global row ids fit 31 bits, 32-bit keys halve the radix passes of the sort)
+    if n_rows is not None and n_rows < 2 ** 31 and row_ids.numel() > 0:
+        s32, perm = torch.sort(row_ids.to(torch.int32), stable=True)
+        out = (s32.to(torch.int64), perm)
+    else:
+        out = torch.sort(row_ids, stable=True)
     _SORT_CACHE.insert(0, (key, (idx, offsets, sizes, frozen), out))
     del _SORT_CACHE[2:]
     return out
 
 
-def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None):
+def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None, n_rows=None):
     """Deterministic embedding-table gradient as (rows [U] int64, values [U,K]): the unique global table rows the batch
     touched (sorted) and the sum of their gradient rows, contributions added in a fixed order (no atomics).  Out-of-range
     ids and frozen fields (frozen [F] uint8) contribute nothing.  The sort is torch's (plumbing); the sums are the HIP
@@ -459,7 +464,7 @@ def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None):
     B, F = idx.shape
     K = g.shape[-1]
     g = _f32c(g)
-    sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key)
+    sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key, n_rows)
     rows, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
     starts = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=g.device)
     torch.cumsum(counts, 0, out=starts[1:])
@@ -513,11 +518,11 @@ class _EmbedFn(torch.autograd.Function):
             if frozen is not None:
                 raise FilError("embed_gather: frozen fields are not supported by the atomic scatter-add")
         elif sparse_grad:   # what Keras hands its optimizers (IndexedSlices): only the touched rows exist
-            rows, values = embed_grad_rows(offsets, sizes, idx, g, frozen, layout_key)
+            rows, values = embed_grad_rows(offsets, sizes, idx, g, frozen, layout_key, table_shape[0])
             dtable = torch.sparse_coo_tensor(rows.unsqueeze(0), values, table_shape)
         else:               # dense table, deterministic, no data-dependent shapes (HIP-graph capturable)
             lib = _lib.load()
-            sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key)
+            sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key, table_shape[0])
             dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
             check(lib.fil_embed_run_sum(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, stream_ptr()), "fil_embed_run_sum")
         return dtable, None, None, None, None, None, None, None, None, None

@@ -363,10 +363,9 @@ class SparseEmbed(Layer):
         if self.use_flatten:
             embed_list = [e.reshape(e.shape[0], -1) for e in embed_list]
         if self.use_add:
-            out = embed_list[0]
-            for e in embed_list[1:]:
-                out = out + e
-            embed_list = out
+            # Keras Add over the F per-field tensors (tf.add_n: order unspecified) as ONE reduction of the packed block -- the
+            # Python loop of F-1 additions was 2(F-1) tiny kernels per step (xDeepFM's linear terms: 165 us of a 2.3 ms step)
+            embed_list = block.sum(dim=1) if self.use_flatten else block.sum(dim=1, keepdim=True)
         if self.mask_zero:
             masks = [(idx[:, f:f + 1] != 0) for f in range(idx.shape[1])]
             return embed_list, masks
