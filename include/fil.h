@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 206
+#define FIL_ABI_VERSION 207
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -114,11 +114,15 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *       dW[l] and dbias[l] are final, [L] once the dense head's gradients are -- from the top layer down, each before the
  *       data-gradient kernel of its layer starts -- so a data-parallel caller can start the all-reduce of a layer's
  *       gradients on another stream while the rest of the backward is still running.
+ *       fil_cin_grad_ready_points(.., mode, point) tells WHERE in the backward each slot is recorded: point[l] (l = 0..L) = ordinal of
+ *       the recording point, 0 first; slots with the same ordinal are recorded together (fused tail: the two top layers), so a
+ *       caller reduces them with ONE collective.  Returns the number of distinct points, or a (negative) error code.
  *   Limits: F <= 64, H_l <= 256, L <= 8, B*K <= 2^28.
  */
 size_t fil_cin_saved_bytes(int B, int F, int K, int L, const int* H);
 size_t fil_cin_fwd_workspace_bytes(int B, int F, int K, int L, const int* H);
 size_t fil_cin_bwd_workspace_bytes(int B, int F, int K, int L, const int* H);
+int fil_cin_grad_ready_points(int B, int F, int K, int L, const int* H, int mode, int* point);
 int fil_cin_fwd(const float* x, const float* const* W, const float* const* bias, const float* dense_w,
                 const float* dense_b, float* out, float* pooled, float* saved, int B, int F, int K, int L,
                 const int* H, int output_dim, int mode, void* workspace, size_t workspace_bytes, void* stream);

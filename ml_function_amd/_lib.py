@@ -32,6 +32,7 @@ SIGNATURES = {
     "fil_cin_saved_bytes": (_Z, [_I, _I, _I, _I, _P]),
     "fil_cin_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _P]),
     "fil_cin_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _P]),
+    "fil_cin_grad_ready_points": (_I, [_I, _I, _I, _I, _P, _I, _P]),
     "fil_cin_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _Z, _P]),
     "fil_cin_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _Z, _P]),
     "fil_attn_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),

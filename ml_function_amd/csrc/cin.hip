@@ -330,6 +330,24 @@ extern "C" size_t fil_cin_bwd_workspace_bytes(int B, int F, int K, int L, const 
   return bwd_ws_bytes(s);
 }
 
+extern "C" int fil_cin_grad_ready_points(int B, int F, int K, int L, const int* H, int mode, int* point) {
+  CinShape s;
+  if (int rc = check_shape("fil_cin_grad_ready_points", B, F, K, L, H, s)) return rc;
+  if (point == nullptr || mode < 0 || mode > 255) return fail(FIL_ERR_ARG, "fil_cin_grad_ready_points: point == NULL or mode %d out of range", mode);
+  if (B == 0) {                                         // empty batch: zero gradients, every slot at once
+    for (int i = 0; i <= L; ++i) point[i] = 0;
+    return 1;
+  }
+  int pt = 0, l = L - 1;
+  point[L] = pt++;                                      // the dense head
+  if (tail_used(s, mode)) {                             // fused tail: the two top layers' gradients come out of one group of launches
+    point[L - 1] = point[L - 2] = pt++;
+    l = L - 3;
+  }
+  for (; l >= 0; --l) point[l] = pt++;
+  return pt;
+}
+
 extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* const* bias, const float* dense_w,
                            const float* dense_b, float* out, float* pooled, float* saved, int B, int F, int K, int L,
                            const int* H, int output_dim, int mode, void* workspace, size_t workspace_bytes, void* stream) {

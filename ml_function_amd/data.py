@@ -20,6 +20,8 @@ import threading
 import numpy as np
 import torch
 
+from .streams import independent_stream
+
 
 def _map_structure(fn, s):
     if isinstance(s, dict):
@@ -105,7 +107,8 @@ class data_pipeline:
             return
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
-        stream = torch.cuda.Stream(self.device) if self.device is not None and self.device.type == "cuda" else None
+        # (the copy stream must not share a hardware queue with the compute stream, or the copies queue up behind its kernels)
+        stream = independent_stream(self.device) if self.device is not None and self.device.type == "cuda" else None
 
         def produce():
             try:

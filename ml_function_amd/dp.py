@@ -10,6 +10,8 @@ The reference has no distributed code at all; this module is net-new.
 import torch
 import torch.distributed as dist
 
+from .streams import independent_stream
+
 
 def shard_bounds(n_rows, rank, world):
     """Contiguous, balanced row range of `rank`: sizes differ by at most one row."""
@@ -82,7 +84,8 @@ class LayerwiseAllReduce:
         assert all(0 <= a <= b <= flat.numel() for a, b in self.segments)
         self.cuda = flat.is_cuda
         self.events = [torch.cuda.Event() for _ in self.segments] if self.cuda else [None] * len(self.segments)
-        self.side = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        # (a stream that really runs beside the compute stream: one sharing its hardware queue would stall it at every wait)
+        self.side = independent_stream(flat.device) if self.cuda else None
         self._works = []
 
     def active(self):
@@ -140,6 +143,27 @@ def cin_bucket_layout(W_shapes, b_shapes, head_shapes):
         segments.append((lo, hi))
         lo = hi
     return sizes, segments, index
+
+
+def merge_segments_by_point(segments, points):
+    """Coalesce the per-layer segments of cin_bucket_layout whose gradients become final at the same point of the backward.
+
+    segments[i] belongs to layer L-1-i (segment 0 also holds the head); points = functional.cin_grad_ready_points(...) (L+1
+    ordinals, [l] per layer).  Returns (merged segments, layer_of_event): merged segment j is reduced behind the grad_ready slot
+    of layer layer_of_event[j] -- the lowest layer of its group, whose slot is recorded when the whole group is final.  Every
+    collective costs tens of microseconds of stream plumbing whatever its size: with the fused tail the two top layers finish
+    together and share one."""
+    L = len(segments)
+    merged, layer_of_event = [], []
+    for i, (lo, hi) in enumerate(segments):
+        l = L - 1 - i
+        if merged and points[l] == points[layer_of_event[-1]]:
+            merged[-1] = (merged[-1][0], hi)
+            layer_of_event[-1] = l
+        else:
+            merged.append((lo, hi))
+            layer_of_event.append(l)
+    return merged, layer_of_event
 
 
 def allreduce_module_grads(module, group=None):

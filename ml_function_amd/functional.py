@@ -146,6 +146,18 @@ def dcn_cross(x, w, b):
 CIN_X_TRANSPOSED = 16   # fil.h FIL_CIN_X_TRANSPOSED: x handed over as [B*K, F] (embed_gather(emit_xt=True))
 
 
+def cin_grad_ready_points(B, F, K, H, mode=0):
+    """Where in fil_cin_bwd each grad_ready slot is recorded (fil.h): list of L+1 ordinals, [l] for layer l and [L] for the dense
+    head; slots with equal ordinals become final together, so a data-parallel caller reduces them with one collective."""
+    lib = _lib.load()
+    L = len(H)
+    pts = (ctypes.c_int * (L + 1))()
+    n = lib.fil_cin_grad_ready_points(int(B), int(F), int(K), L, int_array(list(H)), int(mode), pts)
+    if n < 0:
+        raise FilError("fil_cin_grad_ready_points: %s" % lib.fil_last_error().decode())
+    return [int(v) for v in pts]
+
+
 def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0, xt=None):
     """Raw forward through the C ABI.  Returns (out [B,1] or None, pooled [B,L*K], saved uint8 buffer).
     xt (optional): x already transposed to [B*K, F] by the gather that produced it; the kernels then read it in place."""

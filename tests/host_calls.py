@@ -55,6 +55,12 @@ def run(lib):
         assert lib.fil_cin_fwd_workspace_bytes(B, 39, 16, 3, H3) >= 0
         assert lib.fil_cin_bwd_workspace_bytes(B, 39, 16, 3, H3) >= 0
     assert lib.fil_cin_saved_bytes(4096, 39, 16, 3, H3) == 65536 * 39 * 4 + 2 * 65536 * 128 * 4
+    pts = (ctypes.c_int * 4)()
+    assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 0, pts) == 3 and list(pts) == [2, 1, 1, 0]     # fused tail: layers 1, 2 together
+    assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 32, pts) == 4 and list(pts) == [3, 2, 1, 0]    # FIL_CIN_NOTAIL
+    assert lib.fil_cin_grad_ready_points(0, 39, 16, 3, H3, 0, pts) == 1 and list(pts) == [0, 0, 0, 0]
+    assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 0, None) == -1
+    assert lib.fil_cin_grad_ready_points(4096, 65, 16, 3, H3, 0, pts) == -4
     # attention
     nul9 = [None] * 9
     expect(lib.fil_attn_fwd(*nul9, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, 0, None, 0, None), -4)

@@ -115,6 +115,19 @@ def test_cin_bucket_layout_is_in_readiness_order():
     assert index[("W", 2)] == 2 and index[("b", 0)] == 7 and index[("head", 1)] == 1
 
 
+def test_segments_merge_where_gradients_finish_together():
+    sizes, segments, index = dp.cin_bucket_layout([(15, 6), (30, 7), (35, 3)], [(6,), (7,), (3,)], [(12, 1), (1,)])
+    # every layer at its own point (no fused tail): nothing merges, events in layer order L-1 .. 0
+    assert dp.merge_segments_by_point(segments, [3, 2, 1, 0]) == (segments, [2, 1, 0])
+    # fused tail: layers 2 and 1 become final together -> one collective behind layer 1's slot, then layer 0
+    assert dp.merge_segments_by_point(segments, [2, 1, 1, 0]) == ([(0, 338), (338, 434)], [1, 0])
+    # everything at once (empty batch)
+    assert dp.merge_segments_by_point(segments, [0, 0, 0, 0]) == ([(0, 434)], [0])
+    # four layers with the tail on top
+    segs4 = [(0, 10), (10, 30), (30, 60), (60, 100)]
+    assert dp.merge_segments_by_point(segs4, [3, 2, 1, 1, 0]) == ([(0, 30), (30, 60), (60, 100)], [2, 1, 0])
+
+
 def test_layerwise_allreduce_equals_full_batch(tmp_path):
     """The bucket reduced segment by segment (the order bench.py overlaps them in) == gradient of the full batch."""
     world = 2

@@ -60,6 +60,24 @@ def test_layerwise_allreduce_executes_on_one_rank():
             torch.cuda.synchronize()
             assert calls == [b - a for a, b in segments] * 3           # every segment really went through the backend
             assert torch.equal(flat, plain)
+            # (a') bench.py's default: one collective per point of the backward (fused tail: the two top layers together)
+            del calls[:]
+            H = [int(w.shape[1]) for w in inp["Ws"]]
+            points = Fn.cin_grad_ready_points(512, inp["x"].shape[1], inp["x"].shape[2], H, 0)
+            assert points == [2, 1, 1, 0]                   # layer 0 last; layers 1 and 2 (the fused tail) together; head first
+            assert Fn.cin_grad_ready_points(512, inp["x"].shape[1], inp["x"].shape[2], H, 32) == [3, 2, 1, 0]   # FIL_CIN_NOTAIL
+            merged, layer_of_event = dp.merge_segments_by_point(segments, points)
+            assert merged == [(segments[0][0], segments[1][1]), segments[2]] and layer_of_event == [1, 0]
+            redm = dp.LayerwiseAllReduce(flat, merged, force=True)
+            ready = [None] * (L + 1)
+            for ev, l in zip(redm.events, layer_of_event):
+                ready[l] = ev
+            for _ in range(2):
+                backward(ready)
+                redm.launch()
+                redm.wait()
+            torch.cuda.synchronize()
+            assert calls == [b - a for a, b in merged] * 2 and torch.equal(flat, plain)
             # (b) one all-reduce of the whole bucket after the backward (bench.py --no-overlap)
             del calls[:]
             red1 = dp.LayerwiseAllReduce(flat, [(0, flat.numel())], force=True)
@@ -73,3 +91,27 @@ def test_layerwise_allreduce_executes_on_one_rank():
             dist.all_reduce = real
     finally:
         dist.destroy_process_group()
+
+
+def test_independent_stream_runs_beside_the_compute_stream():
+    """torch's streams are multiplexed onto a few in-order hardware queues; the reducer's (and the input pipeline's) side stream
+    must be one whose work proceeds while the compute stream is busy."""
+    from ml_function_amd import streams
+    device = torch.device("cuda", 0)
+    side = streams.independent_stream(device)
+    assert not streams.shares_queue_with_current(side, device)
+    assert streams.shares_queue_with_current(torch.cuda.current_stream(device), device)     # the probe itself: same queue = True
+    t = torch.zeros(1 << 20, device=device)
+    with torch.cuda.stream(side):
+        t.add_(1.0)                                   # (first launch of this kernel: code-object load, not what is timed)
+    torch.cuda.synchronize()
+    start, busy, done = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    start.record()
+    torch.cuda._sleep(int(2e7))
+    busy.record()
+    with torch.cuda.stream(side):
+        t.add_(1.0)
+        done.record()
+    torch.cuda.synchronize()
+    assert start.elapsed_time(done) < 0.5 * start.elapsed_time(busy)      # the side work finished under the long compute kernel
+    assert float(t.sum()) == float(2 << 20)

@@ -18,6 +18,37 @@ COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "S
             "GRBM_GUI_ACTIVE"]
 
 
+def is_split_instance(key):
+    """True for the template instantiations of the split-bf16 experiment: SPLIT is the 4th argument of cin_fwd3_kernel<MB,JT,SYM,SPLIT,KS>,
+    the 5th of cin_dz3_kernel<MB,JT,WG,SYM,SPLIT,KS> and the 2nd of cin_dw3_kernel<MB,SPLIT,DEPTH>."""
+    name = key.split(" grid=")[0]
+    if "<" not in name:
+        return False
+    args = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",")
+    pos = 3 if name.startswith("cin_fwd3") else 4 if name.startswith("cin_dz3") else 1 if name.startswith("cin_dw3") else None
+    return pos is not None and len(args) > pos and args[pos] == "true"
+
+
+def scopes_of(res):
+    """bench.py's profiler scope -> the counters of the kernel instantiation behind it."""
+    def pick(k):
+        return {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
+                "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
+                "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
+    by_scope = {}
+    for kind, prefix in (("fwd", "cin_fwd3_kernel"), ("bwd_dz", "cin_dz3_kernel"), ("bwd_dw", "cin_dw3_kernel")):
+        hits = sorted((v["first_dispatch"], k) for k, v in res.items() if k.startswith(prefix) and not is_split_instance(k))
+        order = ((1, 2) if kind == "fwd" else (2, 1)) if len(hits) == 2 else ((1,) if len(hits) == 1 else ())
+        # two general MFMA layers (l = 1, 2): the forward visits l1 first, the backward l2 first; with the fused tail only l1 is left
+        for (_, k), l in zip(hits, order):
+            by_scope["cin_%s_l%d" % (kind, l)] = pick(k)
+    for scope, prefix in (("cin_fwd_tail", "cin_tail_fwd_kernel"), ("cin_bwd_dw_tail", "cin_tail_dw_kernel"), ("cin_bwd_dz_tail", "cin_tail_dz_kernel")):
+        hits = [k for k in res if k.startswith(prefix)]
+        if len(hits) == 1:
+            by_scope[scope] = pick(hits[0])
+    return by_scope
+
+
 def main():
     d, out, iters = sys.argv[1], sys.argv[2], int(sys.argv[3])
     data = {c: per_kernel(d, c) for c in COUNTERS}
@@ -42,23 +73,7 @@ def main():
                 e["wave_cycles_issue_stalled_frac"] = (e["SQ_WAIT_INST_ANY"] or 0.0) / wc
                 e["wave_cycles_issuing_frac"] = (e["SQ_ACTIVE_INST_ANY"] or 0.0) / wc
             res["%s grid=%d" % (name, grid) + (" #%d" % s if slots > 1 else "")] = e
-    by_scope = {}
-    for kind, prefix in (("fwd", "cin_fwd3_kernel"), ("bwd_dz", "cin_dz3_kernel"), ("bwd_dw", "cin_dw3_kernel<1,false")):
-        # (instantiations whose last template argument is SPLIT = true belong to the split-bf16 experiment)
-        hits = sorted((v["first_dispatch"], k) for k, v in res.items() if k.startswith(prefix) and not k.split(" grid=")[0].endswith(",true>"))
-        order = ((1, 2) if kind == "fwd" else (2, 1)) if len(hits) == 2 else ((1,) if len(hits) == 1 else ())
-        # two general MFMA layers (l = 1, 2): the forward visits l1 first, the backward l2 first; with the fused tail only l1 is left
-        for (_, k), l in zip(hits, order):
-            by_scope["cin_%s_l%d" % (kind, l)] = {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
-                                                 "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
-                                                 "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
-    for scope, prefix in (("cin_fwd_tail", "cin_tail_fwd_kernel"), ("cin_bwd_dw_tail", "cin_tail_dw_kernel"), ("cin_bwd_dz_tail", "cin_tail_dz_kernel")):
-        hits = [k for k in res if k.startswith(prefix)]
-        if len(hits) == 1:
-            k = hits[0]
-            by_scope[scope] = {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
-                               "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
-                               "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
+    by_scope = scopes_of(res)
     with open(out, "w") as fh:
         json.dump({"definition": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "by_scope": by_scope,
                    "per_launch": res}, fh, indent=1, sort_keys=True)
