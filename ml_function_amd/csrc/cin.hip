@@ -59,11 +59,11 @@ static int env_int(const char* name, int dflt) {
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -782,7 +782,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
         const int periods = cdiv(F, cin_dz_h_per_period(JTs));
         const int tiles = periods * cin_dz_tiles_per_period(JTs) + 1;
         const long npack = (long)tiles * 32 * HSl;
-        const int MBs = split ? MBg : MB;
+        // exact kernel, H <= 128: 32 rows per wave at TWO waves per SIMD where the instantiation fits 256 registers (the second wave
+        // covers the first one's prologue, epilogue and contraction issue: c4 0.154 -> 0.136 ms); FIL_CIN_MB2 / FIL_CIN_MB=2 /
+        // FIL_CIN_DZS_MB=2 keep 64 rows per wave
+        const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
+        const int MBs = split ? MBg : (two_waves ? 1 : MB);
         if (split) {
           const long nvec = (long)tiles * (HSl / 16) * 3 * 64;
           hipLaunchKernelGGL(cin_pack_wzb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],

@@ -780,8 +780,10 @@ constexpr int kGlStride = 36;    // floats per buffered row: 16-byte aligned, ro
 // KS > 1 (pair-symmetric exact kernel only; small M): KS waves of the workgroup share one block of rows and split the periods
 // (values of h) between them; each writes the Gx columns of its own h range, the dX partial sums meet in the LDS scratch
 // (see cin_tail_dz_kernel).
+// pair-symmetric exact kernel at 32 rows per wave: the slot counts whose instantiation fits 256 registers without spilling
+constexpr bool cin_dzs_two_waves(int JT) { return JT <= 12 || JT == 16; }
 template <int MB, int JT, int NHMAX, bool SYM = false, bool SPLIT = false, int KS = 1>
-__global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SYM && !SPLIT) ? 2 : 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
+__global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 && (!SYM || cin_dzs_two_waves(JT))) ? 2 : 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
                                                          const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                          const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
                                                          int HSp, float* __restrict__ gx0T, float* __restrict__ dxT, int accumulate,
