@@ -160,7 +160,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
 enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
-                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128 };
+                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128, FIL_CIN_NOQTAIL = 256 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);

@@ -10,6 +10,7 @@
 #include "cin_kernels.h"
 #include "cin_tail.h"
 #include "cin_launch.h"
+#include "cin_qtail.h"
 
 #include <stdlib.h>
 
@@ -59,11 +60,11 @@ static int env_int(const char* name, int dflt) {
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -204,6 +205,15 @@ static bool tail_used(const CinShape& s, int mode) {
   if (!g.on) return false;
   return (mode & FIL_CIN_TAIL_ALWAYS) != 0 || 4 * g.JP <= 3 * g.Hq;
 }
+// Quadratic tail (cin_qtail.h): three layers, pair-symmetric first-layer kernels available, one 128-column chunk below the tail.
+// The top two layers then cost F(F+1)/2 x H_1 products per row -- half of the fused tail's H_1 F (F+1), and no column padding.
+static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
+  return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.H[0] <= 128 && 3 * s.F <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
+         knobs().qtail != 0;   // (3 F: its three [M][F] scratch arrays share one gradient buffer)
+}
+static size_t qtail_saved_floats(const CinShape& s) {   // R | T | wsum_L | cvec, behind xT and the first layer's map
+  return (size_t)s.M() * s.HS(0) + (size_t)s.F * s.F * s.H[0] + (size_t)s.H[1] * s.F + 128;
+}
 struct TailDwPlan {
   int blocks_x, splits, rows_per_split;
 };
@@ -233,6 +243,11 @@ static size_t saved_bytes(const CinShape& s) {
     for (int l = 0; l < g.p; ++l) u += align_up((size_t)s.M() * s.HS(l) * sizeof(float), 256);
     u += align_up((size_t)s.M() * g.JP * sizeof(float), 256) + align_up((g.uz_floats + g.uf_floats) * sizeof(float), 256) +
          align_up((size_t)g.Hq * s.F * sizeof(float), 256);
+    t = std::max(t, u);
+  }
+  if (g.on && s.L == 3) {   // quadratic tail: xT | map 0 | R | T | wsum_L | cvec
+    const size_t u = align_up((size_t)s.M() * s.F * sizeof(float), 256) + align_up((size_t)s.M() * s.HS(0) * sizeof(float), 256) +
+                     align_up(qtail_saved_floats(s) * sizeof(float), 256);
     t = std::max(t, u);
   }
   return t;
@@ -266,6 +281,7 @@ static size_t fwd_ws_bytes(const CinShape& s) {
   for (int l = 0; l < s.L; ++l) t += align_up((size_t)pool_chunks(s, l) * s.M() * sizeof(float), 256);   // pool partials
   t += align_up((size_t)s.Hp(s.L - 1) * s.F * sizeof(float), 256);                                       // wsum of the last layer
   t += align_up(wf_floats(s) * sizeof(float), 256);                                                      // packed W
+  t += align_up((size_t)kCinMaxH * 64 * sizeof(float), 256) + align_up((size_t)kCinMaxH * sizeof(float), 256);   // quadratic tail: wsum_p, zero bias
   return t;
 }
 // floats of the dW partial-sum buffer: the largest splits * C * H over the layers (both first-layer forms, so the
@@ -295,11 +311,13 @@ static size_t bwd_ws_bytes(const CinShape& s) {
   const size_t nblk = (size_t)cdiv(std::max(1, s.B), kHeadChunk);
   const size_t ncol = (M + kColRows - 1) / kColRows;
   t += align_up(std::max(ncol * s.HSmax(), nblk * (LK + 1)) * sizeof(float), 256);   // colsum / head partials
-  const size_t cl = (size_t)s.Hp(s.L - 1) * s.F;
+  const size_t cl = (size_t)std::max(s.Hp(s.L - 1), s.L == 3 ? s.H[0] : 0) * s.F;   // (quadratic tail: the shortcut runs on layer L-2)
   t += 2 * align_up(cl * sizeof(float), 256);                            // wsum, v of the last layer
   t += align_up(wz_floats(s) * sizeof(float), 256);                      // packed W (slot order)
   t += 2 * align_up(M * s.F * sizeof(float), 256);                       // dxT, Gx^0
   t += align_up(gb_bytes(s), 256);                                       // split-bf16 planes of G (mode bit 1)
+  t += align_up((size_t)s.F * s.F * kCinMaxH * sizeof(float), 256);      // quadratic tail: dT
+  t += align_up(((M + 255) / 256) * kQtConst * sizeof(float), 256);      //                 column-sum partials of dP_L x
   return t;
 }
 
@@ -333,7 +351,7 @@ extern "C" size_t fil_cin_bwd_workspace_bytes(int B, int F, int K, int L, const 
 extern "C" int fil_cin_grad_ready_points(int B, int F, int K, int L, const int* H, int mode, int* point) {
   CinShape s;
   if (int rc = check_shape("fil_cin_grad_ready_points", B, F, K, L, H, s)) return rc;
-  if (point == nullptr || mode < 0 || mode > 255) return fail(FIL_ERR_ARG, "fil_cin_grad_ready_points: point == NULL or mode %d out of range", mode);
+  if (point == nullptr || mode < 0 || mode > 511) return fail(FIL_ERR_ARG, "fil_cin_grad_ready_points: point == NULL or mode %d out of range", mode);
   if (B == 0) {                                         // empty batch: zero gradients, every slot at once
     for (int i = 0; i <= L; ++i) point[i] = 0;
     return 1;
@@ -354,12 +372,13 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 255)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT)", mode);
+  if (mode < 0 || mode > 511)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);                    // last two layers as one implicit GEMM (cin_tail.h)
+  const bool qtail = qtail_used(s, mode, tune);            // ... as a quadratic form over field pairs (cin_qtail.h)
   const TailGeom tg = tail_geom(s);
   mode &= 1;
   if (B == 0) return FIL_OK;
@@ -378,12 +397,24 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   }
   float* wsum = ws.take<float>((size_t)s.Hp(L - 1) * F);
   float* Wf = ws.take<float>(wf_floats(s));
+  float* qt_wsum_p = ws.take<float>((size_t)kCinMaxH * 64);
+  float* qt_zbias = ws.take<float>((size_t)kCinMaxH);
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
   const float* xT = xt_in ? x : xT_own;
   // fused tail: its slices of `saved` (behind xT and the maps of the layers below it)
   float *tailY = nullptr, *tailUz = nullptr, *tailBmT = nullptr;
-  if (tail) {
+  float *qtR = nullptr, *qtT = nullptr, *qtWsumL = nullptr, *qtCvec = nullptr;
+  if (qtail) {
+    Carver pv(saved);
+    (void)pv.take<float>((size_t)M * F);
+    (void)pv.take<float>((size_t)M * s.HS(0));
+    float* q = pv.take<float>(qtail_saved_floats(s));
+    qtR = q;
+    qtT = qtR + (size_t)M * s.HS(0);
+    qtWsumL = qtT + (size_t)F * F * H[0];
+    qtCvec = qtWsumL + (size_t)H[1] * F;
+  } else if (tail) {
     Carver pv(saved);
     (void)pv.take<float>((size_t)M * F);
     for (int l = 0; l < tg.p; ++l) (void)pv.take<float>((size_t)M * s.HS(l));
@@ -400,7 +431,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
     const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
     const long npack = (long)chunks0 * F * 2 * JTs * 128;
-    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = cdiv(tg.Hq * F, 8), nz = 64;
+    // (quadratic tail: only the transpose and the first layer's weight pack ride here)
+    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = qtail ? 0 : cdiv(tg.Hq * F, 8), nz = qtail ? 0 : 64;
     const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
     allow_lds(cin_fwd_prep_kernel, sh);
     hipLaunchKernelGGL(cin_fwd_prep_kernel, dim3(nt + npk + nws + nz), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0,
@@ -414,6 +446,45 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   bool fused_last = false;   // the last layer's sum-pool was produced by the epilogue of the layer below
   for (int l = 0; l < L; ++l) {
     FIL_CHECK_ARG(W[l] && bias[l]);
+    if (qtail && l == tg.p) {
+      // ---- quadratic tail (cin_qtail.h): R = (pairs of x) T through the first layer's pair-symmetric forward kernel,
+      // pool_L = <x1, R> + <x, c> + const, pool_p through the pooled-weights shortcut
+      const int lL = L - 1, Hpp = tg.Hpp, Hq = tg.Hq, HS0 = s.HS(0);
+      FIL_CHECK_ARG(W[lL] && bias[lL]);
+      const int JTs = cin_jt_sym(F), chunks = chunks_of(Hpp);
+      {
+        ProfScope ps("cin_tail_prep", st);
+        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hq * F, 8)), dim3(256), 0, st, W[lL], qtWsumL, Hq * F, tg.HL);
+        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[l], qt_wsum_p, Hpp * F, Hq);
+        const size_t sh = ((size_t)F * (Hq + 1) + (size_t)Hq * F) * sizeof(float);
+        allow_lds(cin_qtail_t_kernel, sh);
+        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        const long npack = (long)chunks * F * 2 * JTs * 128;
+        hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, qtT, Wf, F, Hpp, 2 * JTs, chunks);
+      }
+      FIL_CHECK_LAUNCH();
+      {
+        const double algo = gemm_flops(M, Hpp, F, Hq) + gemm_flops(M, Hq, F, tg.HL);   // the two layers of the reference graph
+        ProfScope ps("cin_fwd_tail", st, algo, gemm_flops(M, 1, F * (F / 2 + 1), Hpp));
+        const int ks = tune.ksplit(M);
+        // (the kernel's own sum-pool output is not used: it goes to the last layer's slot, which the pool kernel below overwrites)
+        cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, Wf, qt_zbias, qtR, HS0,
+                            const_cast<float*>(pa.part[lL]), (int)M, F, Hpp, false, ks);
+      }
+      FIL_CHECK_LAUNCH();
+      {
+        ProfScope ps("cin_tail_pool", st);
+        const size_t sh = (size_t)Hpp * ((F + 3) & ~3) * sizeof(float);
+        allow_lds(cin_last_fwd_kernel, sh);
+        hipLaunchKernelGGL(cin_last_fwd_kernel, dim3(cdiv((int)M, kLastRows)), dim3(256), sh, st, xT, xpT, s.xps(l), qt_wsum_p, bias[l],
+                           const_cast<float*>(pa.part[l]), (int)M, F, Hpp, Hq);
+        hipLaunchKernelGGL(cin_qtail_pool_kernel, dim3((int)std::min<long>((M + 7) / 8, 4096)), dim3(256), 0, st, xT, xpT, s.xps(l), qtR, HS0, qtCvec,
+                           const_cast<float*>(pa.part[lL]), (int)M, F, Hpp);
+        pa.chunks[l] = pa.chunks[lL] = 1;
+      }
+      FIL_CHECK_LAUNCH();
+      break;
+    }
     if (tail && l == tg.p) {
       // ---- fused tail: layers p = L-2 and L-1 through Ueff = W_p [1 | wsum_L]: F+1 output columns instead of H_p
       const int lL = L - 1;
@@ -528,12 +599,13 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 255)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT)", mode);
+  if (mode < 0 || mode > 511)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);
+  const bool qtail = qtail_used(s, mode, tune);
   const TailGeom tg = tail_geom(s);
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
@@ -573,12 +645,16 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   const int ncol = (int)((M + kColRows - 1) / kColRows);
   float* small = ws.take<float>(std::max((size_t)ncol * s.HSmax(), (size_t)nblk * (LK + 1)));
   const size_t cl = (size_t)s.Hp(L - 1) * F;
-  float* wsum = ws.take<float>(cl);
-  float* vlast = ws.take<float>(cl);
+  const size_t cl_buf = (size_t)std::max(s.Hp(L - 1), L == 3 ? H[0] : 0) * F;
+  float* wsum = ws.take<float>(cl_buf);
+  float* vlast = ws.take<float>(cl_buf);
   float* Wz = ws.take<float>(wz_floats(s));
   float* dxT = ws.take<float>((size_t)M * F);
   float* gx0T = ws.take<float>((size_t)M * F);
   bf16x8* Gb = reinterpret_cast<bf16x8*>(ws.take<char>(gb_bytes(s)));
+  float* qt_dT = ws.take<float>((size_t)F * F * kCinMaxH);
+  const int qt_ndc = (int)((M + 255) / 256);
+  float* qt_dcpart = ws.take<float>((size_t)qt_ndc * kQtConst);
 
   // saved tensors
   Carver sv(const_cast<float*>(saved));
@@ -586,7 +662,15 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   const float* xT = xt_in ? x : xT_own;    // (X_TRANSPOSED: the caller's [B*K][F] copy; the forward left saved's own area unused)
   const float* maps[kCinMaxL];
   const float *tailY = nullptr, *tailUz = nullptr, *tailWsum = nullptr;
-  if (tail) {   // saved layout of the fused tail: xT | maps 0..L-3 | Y | Uz | wsum_L
+  const float *qtR = nullptr, *qtT = nullptr, *qtWsumL = nullptr, *qtCvec = nullptr;
+  if (qtail) {   // saved layout of the quadratic tail: xT | map 0 | R | T | wsum_L | cvec
+    maps[0] = sv.take<float>((size_t)M * s.HS(0));
+    const float* q = sv.take<float>(qtail_saved_floats(s));
+    qtR = q;
+    qtT = qtR + (size_t)M * s.HS(0);
+    qtWsumL = qtT + (size_t)F * F * H[0];
+    qtCvec = qtWsumL + (size_t)H[1] * F;
+  } else if (tail) {   // saved layout of the fused tail: xT | maps 0..L-3 | Y | Uz | wsum_L
     for (int l = 0; l < tg.p; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
     tailY = sv.take<float>((size_t)M * tg.JP);
     tailUz = sv.take<float>(tg.uz_floats + tg.uf_floats);
@@ -601,18 +685,100 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ProfScope ps("cin_head_bwd", st);
     hipLaunchKernelGGL(cin_head_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, dense_w, pooled, dP, small, B, (int)LK, kHeadChunk);
     // (fused tail: the fixed-order sum of the head's partials rides in the tail's first launch, below)
-    if (!tail) hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
+    if (!tail || qtail) hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
     FIL_CHECK_LAUNCH();
     dPsrc = dP;
   }
-  if (!tail) ready(L);
+  if (!tail || qtail) ready(L);
 
   int cur = 0;
   int ltop = L - 1;          // first layer handled by the general kernels
   bool dx_started = false;   // has dxT been initialised yet
   bool have_gx0 = false;     // did a general layer-1 kernel produce Gx^0
   bool wz_prepacked = false; // fused tail with L == 3: layer 0's dZ weights were packed by the tail's first launch
-  if (tail) {
+  if (qtail) {
+    // ---- quadratic tail (cin_qtail.h).  pool_p goes back through the pooled-weights shortcut of layer p; pool_L = <x1, R> through the
+    // first layer's pair-symmetric dW / dZ kernels with x1 (unscaled) as their "gradient" operand: dT = (pairs of x, one factor scaled
+    // by dP_L)^T x1, the two halves of d<x1,R>/dx come out per row and are scaled by dP_L afterwards; G^{p-1} += dP_L R is elementwise.
+    const int p = tg.p, lL = L - 1, Hpp = tg.Hpp, Hq = tg.Hq, HS0 = s.HS(0);
+    FIL_CHECK_ARG(bias && W[p] && W[lL] && bias[p] && dW[p] && dW[lL] && dbias[p] && dbias[lL]);
+    const float* xpT = maps[p - 1];
+    const int xps = s.xps(p);
+    const float* dPp = dPsrc + (size_t)p * K;
+    const float* dPL = dPsrc + (size_t)lL * K;
+    const float* dPprev = dPsrc + (size_t)(p - 1) * K;
+    const double algo = gemm_flops(M, Hpp, F, Hq) + gemm_flops(M, Hq, F, tg.HL);
+    // Gbuf[1] is free until the layer loop is over (L == 3: the loop runs layer 0 only): xs | yT, later xs | gxR | dxR
+    float* xs = Gbuf[1];
+    float* yT = xs + (size_t)M * F;
+    float* gxR = xs + (size_t)M * F;
+    float* dxR = gxR + (size_t)M * F;
+    const int YS = (F + 3) & ~3;
+    float* sl_p = small;            // slice partials of dP_p, dP_L (nblk each)
+    float* sl_L = small + nblk;
+    {
+      ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
+      const size_t sh = (size_t)256 * (F + 1) * sizeof(float);
+      allow_lds(cin_qtail_scale_kernel, sh);
+      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc), dim3(256), sh, st, xT, dPL, (int)LK, K, xs, qt_dcpart, (int)M, F);
+      hipLaunchKernelGGL(cin_slice_sum_kernel, dim3(nblk), dim3(256), 0, st, dPp, (int)LK, sl_p, B, K, kHeadChunk);
+      hipLaunchKernelGGL(cin_slice_sum_kernel, dim3(nblk), dim3(256), 0, st, dPL, (int)LK, sl_L, B, K, kHeadChunk);
+    }
+    FIL_CHECK_LAUNCH();
+    {
+      // pooled-weights shortcut of layer p: v^T [F][Hpp] (the rank-one part of dW_p), G^{p-1} = dP_p S + dP_{p-1}, dX = dP_p x1 wsum_p
+      ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
+      hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[p], wsum, Hpp * F, Hq, Wz, Hpp, F, 2 * JT, chunks_of(Hpp));
+      const long tot = M * YS;
+      hipLaunchKernelGGL(cin_scale_rows3_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, xT, dPp, (int)LK, K, yT, (int)M, F, YS);
+      const int nb = launch_dw3(st, dw_plan(M, F, Hpp), xpT, xps, nullptr, yT, YS, part, M, /*F=*/1, /*Hp=*/F, /*H=*/Hpp);
+      hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv(Hpp * F, 64)), dim3(256), 0, st, part, vlast, (long)Hpp * F, nb);
+      cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp);
+      const long tq = M * ((Hpp + 3) / 4);
+      hipLaunchKernelGGL(cin_qtail_gadd_kernel, dim3((int)std::min<long>((tq + 255) / 256, 8192)), dim3(256), 0, st, Gbuf[cur], HS0, qtR, HS0, dPL, (int)LK, K,
+                         (int)M, Hpp);
+    }
+    FIL_CHECK_LAUNCH();
+    const int symD = F / 2 + 1, Cl = F * symD;
+    const int JTs = cin_jt_sym(F);
+    {
+      ProfScope ps("cin_bwd_dw_tail", st, algo, gemm_flops(M, 1, Cl, Hpp));
+      const int parts = launch_dw3(st, dw_plan(M, Cl, Hpp), xpT, HS0, xT, xs, F, part, M, F, F, Hpp, symD);
+      const long nW = (long)Cl * Hpp;
+      hipLaunchKernelGGL(cin_reduce_expand_sym_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, qt_dT, F, symD, Hpp, parts);
+    }
+    FIL_CHECK_LAUNCH();
+    {
+      ProfScope ps("cin_tail_params", st);
+      const size_t sh = ((size_t)F * (Hq + 1) + (size_t)Hq * F + (size_t)F * (F + 1)) * sizeof(float);
+      allow_lds(cin_qtail_params_kernel, sh);
+      hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(Hpp), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq);
+      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, qt_dcpart, qt_ndc, sl_p, sl_L, nblk, bias[p], qtWsumL,
+                         dW[lL], dbias[p], dbias[lL], F, Hq, tg.HL);
+    }
+    FIL_CHECK_LAUNCH();
+    ready(lL);
+    ready(p);
+    {
+      const int periods = cdiv(F, cin_dz_h_per_period(JTs));
+      const int tiles = periods * cin_dz_tiles_per_period(JTs) + 1;
+      const long npack = (long)tiles * 32 * HS0;
+      hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, qtT, Wz, F, Hpp, JTs, HS0, tiles);
+      ProfScope ps("cin_bwd_dz_tail", st, algo, gemm_flops(M, 1, Cl, Hpp));
+      const int NHMAX = HS0 / 2;
+      const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
+      const int MBs = two_waves ? 1 : tune.mb_rows(M);
+      const int ks = MBs != 1 ? 1 : tune.ksplit(M);
+      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), xpT, HS0, Wz, xT, gxR, dxR, 0, (int)M, F, Hpp,
+                         periods, false, ks);
+      const long tot = M * F;
+      hipLaunchKernelGGL(cin_qtail_dx_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, dxT, gxR, dxR, qtCvec, dPL, (int)LK, K,
+                         (int)M, F);
+    }
+    FIL_CHECK_LAUNCH();
+    dx_started = true;
+    ltop = p - 1;
+  } else if (tail) {
     // ---- fused tail: both top layers' parameter gradients from Q = Z_p^T A (F+2 columns), data gradients from A Ueff^T
     const int p = tg.p, lL = L - 1;
     FIL_CHECK_ARG(bias && W[p] && W[lL] && bias[p] && dW[p] && dW[lL] && dbias[p] && dbias[lL]);
