@@ -208,7 +208,7 @@ static bool tail_used(const CinShape& s, int mode) {
 // Quadratic tail (cin_qtail.h): three layers, pair-symmetric first-layer kernels available, one 128-column chunk below the tail.
 // The top two layers then cost F(F+1)/2 x H_1 products per row -- half of the fused tail's H_1 F (F+1), and no column padding.
 static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
-  return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.H[0] <= 128 && 3 * s.F <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
+  return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.F + 2 <= kQtConst && s.H[0] <= 128 && 3 * s.F <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
          knobs().qtail != 0;   // (3 F: its three [M][F] scratch arrays share one gradient buffer)
 }
 static size_t qtail_saved_floats(const CinShape& s) {   // R | T | wsum_L | cvec, behind xT and the first layer's map
@@ -455,10 +455,11 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       {
         ProfScope ps("cin_tail_prep", st);
         hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hq * F, 8)), dim3(256), 0, st, W[lL], qtWsumL, Hq * F, tg.HL);
-        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[l], qt_wsum_p, Hpp * F, Hq);
+        // (wsum_p in the MFMA operand layout of the pool kernel, behind the plain copy)
+        hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[l], qt_wsum_p, Hpp * F, Hq, qt_wsum_p + 8192, Hpp, F, 2 * JT, chunks);
         const size_t sh = ((size_t)F * (Hq + 1) + (size_t)Hq * F) * sizeof(float);
         allow_lds(cin_qtail_t_kernel, sh);
-        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
         const long npack = (long)chunks * F * 2 * JTs * 128;
         hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, qtT, Wf, F, Hpp, 2 * JTs, chunks);
       }
@@ -474,12 +475,14 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       FIL_CHECK_LAUNCH();
       {
         ProfScope ps("cin_tail_pool", st);
-        const size_t sh = (size_t)Hpp * ((F + 3) & ~3) * sizeof(float);
-        allow_lds(cin_last_fwd_kernel, sh);
-        hipLaunchKernelGGL(cin_last_fwd_kernel, dim3(cdiv((int)M, kLastRows)), dim3(256), sh, st, xT, xpT, s.xps(l), qt_wsum_p, bias[l],
-                           const_cast<float*>(pa.part[l]), (int)M, F, Hpp, Hq);
-        hipLaunchKernelGGL(cin_qtail_pool_kernel, dim3((int)std::min<long>((M + 7) / 8, 4096)), dim3(256), 0, st, xT, xpT, s.xps(l), qtR, HS0, qtCvec,
-                           const_cast<float*>(pa.part[lL]), (int)M, F, Hpp);
+        const float* wsn = qt_wsum_p + 8192;
+        float* pp = const_cast<float*>(pa.part[l]);
+        float* pL = const_cast<float*>(pa.part[lL]);
+        const dim3 grid((int)((M + 127) / 128));
+#define FIL_QP(JTV) \
+  case JTV: hipLaunchKernelGGL((cin_qtail_pool2_kernel<JTV>), grid, dim3(256), 0, st, xT, xpT, s.xps(l), wsn, qtR, HS0, qtCvec, pp, pL, (int)M, F, Hpp); break;
+        switch (JT) { FIL_QP(4) FIL_QP(8) FIL_QP(12) FIL_QP(16) FIL_QP(20) FIL_QP(24) FIL_QP(28) FIL_QP(32) }
+#undef FIL_QP
         pa.chunks[l] = pa.chunks[lL] = 1;
       }
       FIL_CHECK_LAUNCH();
@@ -714,15 +717,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     float* gxR = xs + (size_t)M * F;
     float* dxR = gxR + (size_t)M * F;
     const int YS = (F + 3) & ~3;
-    float* sl_p = small;            // slice partials of dP_p, dP_L (nblk each)
-    float* sl_L = small + nblk;
     {
       ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
-      const size_t sh = (size_t)256 * (F + 1) * sizeof(float);
+      const size_t sh = (size_t)256 * (F + 3) * sizeof(float);
       allow_lds(cin_qtail_scale_kernel, sh);
-      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc), dim3(256), sh, st, xT, dPL, (int)LK, K, xs, qt_dcpart, (int)M, F);
-      hipLaunchKernelGGL(cin_slice_sum_kernel, dim3(nblk), dim3(256), 0, st, dPp, (int)LK, sl_p, B, K, kHeadChunk);
-      hipLaunchKernelGGL(cin_slice_sum_kernel, dim3(nblk), dim3(256), 0, st, dPL, (int)LK, sl_L, B, K, kHeadChunk);
+      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xs, qt_dcpart, (int)M, F);
     }
     FIL_CHECK_LAUNCH();
     {
@@ -733,10 +732,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       hipLaunchKernelGGL(cin_scale_rows3_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, xT, dPp, (int)LK, K, yT, (int)M, F, YS);
       const int nb = launch_dw3(st, dw_plan(M, F, Hpp), xpT, xps, nullptr, yT, YS, part, M, /*F=*/1, /*Hp=*/F, /*H=*/Hpp);
       hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv(Hpp * F, 64)), dim3(256), 0, st, part, vlast, (long)Hpp * F, nb);
-      cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp);
-      const long tq = M * ((Hpp + 3) / 4);
-      hipLaunchKernelGGL(cin_qtail_gadd_kernel, dim3((int)std::min<long>((tq + 255) / 256, 8192)), dim3(256), 0, st, Gbuf[cur], HS0, qtR, HS0, dPL, (int)LK, K,
-                         (int)M, Hpp);
+      // (+ dP_L R on the way out: the pool_L part of G^{p-1})
+      cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL);
     }
     FIL_CHECK_LAUNCH();
     const int symD = F / 2 + 1, Cl = F * symD;
@@ -750,11 +747,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     {
       ProfScope ps("cin_tail_params", st);
-      const size_t sh = ((size_t)F * (Hq + 1) + (size_t)Hq * F + (size_t)F * (F + 1)) * sizeof(float);
+      const size_t sh = ((size_t)F * (Hq + 1) + (size_t)F * (F + 1)) * sizeof(float);
       allow_lds(cin_qtail_params_kernel, sh);
-      hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(Hpp), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq);
-      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, qt_dcpart, qt_ndc, sl_p, sl_L, nblk, bias[p], qtWsumL,
-                         dW[lL], dbias[p], dbias[lL], F, Hq, tg.HL);
+      hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq);
+      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, qt_dcpart, qt_ndc, bias[p], qtWsumL, dW[lL], dbias[p],
+                         dbias[lL], F, Hq, tg.HL);
     }
     FIL_CHECK_LAUNCH();
     ready(lL);

@@ -1753,7 +1753,9 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
                                                             const float* __restrict__ wsum, const float* __restrict__ wsn,
                                                             const float* __restrict__ dP, int ldp, const float* __restrict__ dPprev,
                                                             float* __restrict__ GprevT, int HSp, float* __restrict__ dxT, int M, int F,
-                                                            int K, int Hp) {
+                                                            int K, int Hp, const float* __restrict__ Radd = nullptr, int HSr = 0,
+                                                            const float* __restrict__ dPadd = nullptr) {
+  // Radd != nullptr (quadratic tail): G^{L-1}[m,n] += dPadd[m] * Radd[m,n] on the way out (one pass over G less)
   extern __shared__ __attribute__((aligned(16))) float smem[];  // wsum [Hp][F]
   for (int i = threadIdx.x; i < Hp * F; i += 256) smem[i] = wsum[i];
   __syncthreads();
@@ -1768,13 +1770,14 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
     const int f = 2 * j + half;
     xr[j] = f < F ? xT[mq * F + f] : 0.f;
   }
-  float dpr[16], dppr[16];
+  float dpr[16], dppr[16], dpa[16];
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int mm = min(wrow0 + mfma32_row(reg, half), M - 1);
     const int b = mm / K, k = mm - b * K;
     dpr[reg] = dP[(long)b * ldp + k];
     dppr[reg] = dPprev != nullptr ? dPprev[(long)b * ldp + k] : 0.f;
+    dpa[reg] = Radd != nullptr ? dPadd[(long)b * ldp + k] : 0.f;
   }
   const int chunks = (Hp + 127) >> 7;
   for (int chunk = 0; chunk < chunks; ++chunk) {
@@ -1808,8 +1811,15 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
       const int m = wrow0 + mfma32_row(reg, half);
       if (m < M) {
         float* dst = GprevT + (long)m * HSp + n0;
-        const float v0 = fmaf(dpr[reg], t[0][reg], dppr[reg]), v1 = fmaf(dpr[reg], t[1][reg], dppr[reg]);
-        const float v2 = fmaf(dpr[reg], t[2][reg], dppr[reg]), v3 = fmaf(dpr[reg], t[3][reg], dppr[reg]);
+        float v0 = fmaf(dpr[reg], t[0][reg], dppr[reg]), v1 = fmaf(dpr[reg], t[1][reg], dppr[reg]);
+        float v2 = fmaf(dpr[reg], t[2][reg], dppr[reg]), v3 = fmaf(dpr[reg], t[3][reg], dppr[reg]);
+        if (Radd != nullptr) {   // (rows of a feature map are 512-byte aligned and padded to whole chunks)
+          const float4 ra = *reinterpret_cast<const float4*>(Radd + (long)m * HSr + n0);
+          v0 = fmaf(dpa[reg], ra.x, v0);
+          v1 = fmaf(dpa[reg], ra.y, v1);
+          v2 = fmaf(dpa[reg], ra.z, v2);
+          v3 = fmaf(dpa[reg], ra.w, v3);
+        }
         if (n0 + 3 < Hp) {
           *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
         } else {

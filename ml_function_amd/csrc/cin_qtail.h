@@ -15,7 +15,7 @@
 
 namespace fil {
 
-constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n]
+constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
 
 // T[(f'*F + f)*Hpp + h] for block h < Hpp; block Hpp writes cvec and a zero bias vector for the R GEMM.
 // LDS: wp [F][Hq+1] | wl [Hq][F]
@@ -24,7 +24,7 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
                                                                  float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
                                                                  int Hpp, int F, int Hq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int h = blockIdx.x;
+  const int h = blockIdx.x >> 1, part = blockIdx.x & 1;   // two workgroups per h (each half of the (f', f) outputs); the last one: cvec
   if (h == Hpp) {
     for (int f = threadIdx.x; f < F; f += 256) {
       float t = 0.f;
@@ -35,6 +35,11 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
       float t = 0.f;
       for (int n = 0; n < HL; ++n) t += bias_L[n];
       cvec[kQtConst] = t;
+    }
+    if (threadIdx.x == 64) {
+      float t = 0.f;
+      for (int n = 0; n < Hq; ++n) t += bias_p[n];
+      cvec[kQtConst + 1] = t;
     }
     for (int i = threadIdx.x; i < Hpp; i += 256) zbias[i] = 0.f;
     return;
@@ -47,12 +52,18 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
   }
   for (int i = threadIdx.x; i < Hq * F; i += 256) wl[i] = wsumL[i];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < F * F; idx += 256) {
+  const int nhalf = (F * F + 1) / 2;
+  for (int idx = part * nhalf + threadIdx.x; idx < min(F * F, (part + 1) * nhalf); idx += 256) {
     const int fp = idx / F, f = idx - fp * F;
     const float* a = wp + fp * (Hq + 1);
-    float t = 0.f;
-    for (int n = 0; n < Hq; ++n) t = fmaf(a[n], wl[n * F + f], t);
-    T[(long)idx * Hpp + h] = t;
+    float t0 = 0.f, t1 = 0.f;
+    int n = 0;
+    for (; n + 1 < Hq; n += 2) {
+      t0 = fmaf(a[n], wl[n * F + f], t0);
+      t1 = fmaf(a[n + 1], wl[(n + 1) * F + f], t1);
+    }
+    if (n < Hq) t0 = fmaf(a[n], wl[n * F + f], t0);
+    T[(long)idx * Hpp + h] = t0 + t1;
   }
 }
 
@@ -80,29 +91,122 @@ static __global__ __launch_bounds__(256) void cin_qtail_pool_kernel(const float*
   }
 }
 
-// xs[m,f] = dP_L[m] x[m,f]  (the scaled factor of the pair products in the dT GEMM) and, per block of 256 rows, the column sums
-// dcpart[blk][f] = sum_m xs[m,f] (-> dc[f] = d pool_L / d c[f]).  LDS: [256][F+1]
-static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float* __restrict__ xT, const float* __restrict__ dP, int ldp, int K,
-                                                                     float* __restrict__ xs, float* __restrict__ dcpart, int M, int F) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const long r0 = (long)blockIdx.x * 256;
-  const int nrow = (int)min((long)256, (long)M - r0);
-  for (int i = threadIdx.x; i < 256 * F; i += 256) {
-    const int rr = i / F, f = i - rr * F;
-    float v = 0.f;
-    if (rr < nrow) {
-      const long m = r0 + rr, b = m / K;
-      v = xT[m * F + f] * dP[b * ldp + (m - b * K)];
-      xs[m * F + f] = v;
+// Both sum-pools of the quadratic tail from ONE pass over x1 and R (MFMA form of the pooled-weights shortcut, cf. cin_last_bwd2_kernel):
+//   S[m,n]   = sum_f x[m,f] wsum_p[(n,f)]   (A = the lane's x fragment, B = wsn: wsum_p in the forward kernel's operand layout)
+//   pool_p[m] = sum_n x1[m,n] S[m,n] + cvec[kQtConst + 1]
+//   pool_L[m] = sum_n x1[m,n] R[m,n] + sum_f x[m,f] cvec[f] + cvec[kQtConst]
+// Wave = 32 rows; accumulator register `reg` of lane (r, half) is row mfma32_row(reg, half), columns 4r..4r+3.  Hp <= 128.
+template <int JT>
+__global__ __launch_bounds__(256, 2) void cin_qtail_pool2_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
+                                                                 const float* __restrict__ wsn, const float* __restrict__ R, int HSr,
+                                                                 const float* __restrict__ cvec, float* __restrict__ pool_p,
+                                                                 float* __restrict__ pool_L, int M, int F, int Hp) {
+  __shared__ float lin_s[4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
+  if (wrow0 >= M) return;
+  const long mq = min(wrow0 + r, M - 1);
+  float xr[JT];
+  float lin = 0.f;
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    const int f = 2 * j + half;
+    xr[j] = f < F ? xT[mq * F + f] : 0.f;
+    lin = fmaf(xr[j], f < F ? cvec[f] : 0.f, lin);
+  }
+  lin = lane_halves_sum(lin);
+  if (half == 0) lin_s[wave][r] = lin;
+  f32x16 t[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[nb][i] = 0.f;
+  const float4* wsb = reinterpret_cast<const float4*>(wsn) + (half * 32 + r);
+  constexpr int QB = JT % 5 == 0 ? 5 : 4;
+#pragma unroll
+  for (int j0 = 0; j0 < JT; j0 += QB) {
+    float4 wq[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) wq[j] = wsb[(long)(2 * (j0 + j)) * 32];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const float4 w = wq[j];
+      t[0] = mfma32(xr[j0 + j], w.x, t[0]);
+      t[1] = mfma32(xr[j0 + j], w.y, t[1]);
+      t[2] = mfma32(xr[j0 + j], w.z, t[2]);
+      t[3] = mfma32(xr[j0 + j], w.w, t[3]);
     }
-    smem[rr * (F + 1) + f] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float cp = cvec[kQtConst + 1], cL = cvec[kQtConst];
+  const int n0 = 4 * r;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = mfma32_row(reg, half);
+    const int m = wrow0 + row;
+    const long mc = min(m, M - 1);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 < Hp) {   // (rows of a feature map are padded to whole 128-column chunks: columns >= Hp read zeros)
+      a = *reinterpret_cast<const float4*>(xpT + mc * xps + n0);
+      b = *reinterpret_cast<const float4*>(R + mc * HSr + n0);
+    }
+    float ep = a.x * t[0][reg], eL = a.x * b.x;
+    ep = fmaf(a.y, t[1][reg], ep);
+    ep = fmaf(a.z, t[2][reg], ep);
+    ep = fmaf(a.w, t[3][reg], ep);
+    eL = fmaf(a.y, b.y, eL);
+    eL = fmaf(a.z, b.z, eL);
+    eL = fmaf(a.w, b.w, eL);
+    ep = half_wave_sum_hi(ep);
+    eL = half_wave_sum_hi(eL);
+    if (r == 31 && m < M) {
+      pool_p[m] = ep + cp;
+      pool_L[m] = (eL + lin_s[wave][row]) + cL;
+    }
+  }
+}
+
+// xs[m,f] = dP_L[m] x[m,f]  (the scaled factor of the pair products in the dT GEMM) and, per block of 256 rows, the column sums
+// dcpart[blk][f] = sum_m xs[m,f] (-> dc[f] = d pool_L / d c[f]), dcpart[blk][F] = sum_m dP_L[m], dcpart[blk][F+1] = sum_m dP_p[m].
+// One row per thread.  LDS: [256][F+3]
+static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
+                                                                     const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xs,
+                                                                     float* __restrict__ dcpart, int M, int F) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ld = F + 3;
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  float* row = smem + threadIdx.x * ld;
+  if (m < M) {
+    const long b = m / K;
+    const float dl = dPL[b * ldp + (m - b * K)], dp = dPp[b * ldp + (m - b * K)];
+    for (int f = 0; f < F; ++f) {
+      const float v = xT[m * F + f] * dl;
+      xs[m * F + f] = v;
+      row[f] = v;
+    }
+    row[F] = dl;
+    row[F + 1] = dp;
+  } else {
+    for (int f = 0; f < F + 2; ++f) row[f] = 0.f;
   }
   __syncthreads();
-  for (int f = threadIdx.x; f < F; f += 256) {
-    float t = 0.f;
-    for (int rr = 0; rr < 256; ++rr) t += smem[rr * (F + 1) + f];
-    dcpart[(long)blockIdx.x * kQtConst + f] = t;
+  // column sums: wave q takes rows 64q .. 64q+63 of column f = lane, the four partial sums meet in wave order
+  __shared__ float cs[4][64];
+  {
+    const int f = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float t0 = 0.f, t1 = 0.f;
+    if (f < F + 2) {
+      for (int rr = 64 * q; rr < 64 * q + 64; rr += 2) {
+        t0 += smem[rr * ld + f];
+        t1 += smem[(rr + 1) * ld + f];
+      }
+    }
+    cs[q][f] = t0 + t1;
   }
+  __syncthreads();
+  if (threadIdx.x < F + 2) dcpart[(long)blockIdx.x * kQtConst + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
 }
 
 // G[m,h] += dP_L[m] R[m,h]   (the pool_L part of the gradient of x^{p-1}); rows of both are 16-byte aligned
@@ -140,73 +244,102 @@ static __global__ __launch_bounds__(256) void cin_qtail_dx_kernel(float* __restr
   }
 }
 
-// Block h < Hpp:  dW_p[(h,f'),n] = v[(h,f')] + sum_f dT[(f',f),h] wsum_L[(n,f)]       (v: the pooled-weights shortcut's rank-one part,
-//                 partL[h][(n,f)] = sum_f' W_p[(h,f'),n] dT[(f',f),h]                   given transposed, vT[f'][Hpp])
-// LDS: wp [F][Hq+1] | wl [Hq][F] | dt [F][F+1]
+// Two workgroups per h < Hpp (phase = blockIdx & 1):
+//   phase 0:  dW_p[(h,f'),n] = v[(h,f')] + sum_f dT[(f',f),h] wsum_L[(n,f)]       (v: the pooled-weights shortcut's rank-one part,
+//   phase 1:  partL[h][(n,f)] = sum_f' W_p[(h,f'),n] dT[(f',f),h]                   given transposed, vT[f'][Hpp])
+// LDS: dt [F][F+1] | wl [Hq][F] (phase 0)  or  wp [F][Hq+1] (phase 1)
 static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
                                                                       const float* __restrict__ dT, const float* __restrict__ vT,
                                                                       float* __restrict__ dWp, float* __restrict__ partL, int Hpp, int F, int Hq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int h = blockIdx.x;
-  float* wp = smem;
-  float* wl = wp + F * (Hq + 1);
-  float* dt = wl + Hq * F;
-  for (int i = threadIdx.x; i < F * Hq; i += 256) {
-    const int fp = i / Hq, n = i - fp * Hq;
-    wp[fp * (Hq + 1) + n] = Wp[((long)h * F + fp) * Hq + n];
-  }
-  for (int i = threadIdx.x; i < Hq * F; i += 256) wl[i] = wsumL[i];
+  const int h = blockIdx.x >> 1, phase = blockIdx.x & 1;
+  float* dt = smem;
+  float* op = dt + F * (F + 1);
   for (int i = threadIdx.x; i < F * F; i += 256) {
     const int fp = i / F, f = i - fp * F;
     dt[fp * (F + 1) + f] = dT[(long)i * Hpp + h];
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < F * Hq; idx += 256) {
-    const int fp = idx / Hq, n = idx - fp * Hq;
-    const float* d = dt + fp * (F + 1);
-    const float* w = wl + n * F;
-    float t = 0.f;
-    for (int f = 0; f < F; ++f) t = fmaf(d[f], w[f], t);
-    dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + t;
-  }
-  float* pl = partL + (long)h * Hq * F;
-  for (int idx = threadIdx.x; idx < Hq * F; idx += 256) {
-    const int n = idx / F, f = idx - n * F;
-    float t = 0.f;
-    for (int fp = 0; fp < F; ++fp) t = fmaf(wp[fp * (Hq + 1) + n], dt[fp * (F + 1) + f], t);
-    pl[idx] = t;
+  if (phase == 0) {
+    for (int i = threadIdx.x; i < Hq * F; i += 256) op[i] = wsumL[i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < F * Hq; idx += 256) {
+      const int fp = idx / Hq, n = idx - fp * Hq;
+      const float* d = dt + fp * (F + 1);
+      const float* w = op + n * F;
+      float t0 = 0.f, t1 = 0.f;
+      int f = 0;
+      for (; f + 1 < F; f += 2) {
+        t0 = fmaf(d[f], w[f], t0);
+        t1 = fmaf(d[f + 1], w[f + 1], t1);
+      }
+      if (f < F) t0 = fmaf(d[f], w[f], t0);
+      dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + (t0 + t1);
+    }
+  } else {
+    for (int i = threadIdx.x; i < F * Hq; i += 256) {
+      const int fp = i / Hq, n = i - fp * Hq;
+      op[fp * (Hq + 1) + n] = Wp[((long)h * F + fp) * Hq + n];
+    }
+    __syncthreads();
+    float* pl = partL + (long)h * Hq * F;
+    for (int idx = threadIdx.x; idx < Hq * F; idx += 256) {
+      const int n = idx / F, f = idx - n * F;
+      float t0 = 0.f, t1 = 0.f;
+      int fp = 0;
+      for (; fp + 1 < F; fp += 2) {
+        t0 = fmaf(op[fp * (Hq + 1) + n], dt[fp * (F + 1) + f], t0);
+        t1 = fmaf(op[(fp + 1) * (Hq + 1) + n], dt[(fp + 1) * (F + 1) + f], t1);
+      }
+      if (fp < F) t0 = fmaf(op[fp * (Hq + 1) + n], dt[fp * (F + 1) + f], t0);
+      pl[idx] = t0 + t1;
+    }
   }
 }
 
 // dwsum_L[(n,f)] = sum_h partL[h][(n,f)] + bias_p[n] dc[f]  ->  dW_L[(n,f), n'] for every n' (64 rows (n,f) per workgroup);
 // workgroup 0 also finishes dbias_p[n] = sum_m dP_p[m] + sum_f wsum_L[(n,f)] dc[f] and dbias_L[n'] = sum_m dP_L[m].
-// dc[f] = sum of the ndc block partials of cin_qtail_scale_kernel; sp / sl: the nsl slice partials of dP_p / dP_L (cin_slice_sum_kernel).
+// dc[f] = sum of the ndc block partials of cin_qtail_scale_kernel (columns F, F+1 of the partials: sum_m dP_L[m], sum_m dP_p[m]).
 static __global__ __launch_bounds__(256) void cin_qtail_fill_kernel(const float* __restrict__ partL, int Hpp, const float* __restrict__ dcpart, int ndc,
-                                                                    const float* __restrict__ sp, const float* __restrict__ sl, int nsl,
                                                                     const float* __restrict__ bias_p, const float* __restrict__ wsumL,
                                                                     float* __restrict__ dWL, float* __restrict__ dbias_p, float* __restrict__ dbias_L,
                                                                     int F, int Hq, int HL) {
   __shared__ float dc[kQtConst];
   __shared__ float red[4][64];
-  __shared__ float tot[2];
   __shared__ float val[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int f = threadIdx.x; f < F; f += 256) {
-    float t = 0.f;
-    for (int p = 0; p < ndc; ++p) t += dcpart[(long)p * kQtConst + f];
-    dc[f] = t;
+  {
+    // dc[f]: the four waves take every fourth block partial (four independent chains each), folded in wave order
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (lane < F + 2) {
+      int p = wave;
+      for (; p + 12 < ndc; p += 16) {
+        a0 += dcpart[(long)p * kQtConst + lane];
+        a1 += dcpart[(long)(p + 4) * kQtConst + lane];
+        a2 += dcpart[(long)(p + 8) * kQtConst + lane];
+        a3 += dcpart[(long)(p + 12) * kQtConst + lane];
+      }
+      for (; p < ndc; p += 4) a0 += dcpart[(long)p * kQtConst + lane];
+    }
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
   }
-  if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 66) {
-    const float* s = threadIdx.x == 64 ? sp : sl;
-    float t = 0.f;
-    for (int p = 0; p < nsl; ++p) t += s[p];
-    tot[threadIdx.x - 64] = t;
-  }
+  __syncthreads();
+  if (wave == 0) dc[lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  __syncthreads();
   const int C = Hq * F;
   const int c = blockIdx.x * 64 + lane;
   float t = 0.f;
-  if (c < C)
-    for (int h = wave; h < Hpp; h += 4) t += partL[(long)h * C + c];
+  if (c < C) {
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+    int h = wave;
+    for (; h + 12 < Hpp; h += 16) {
+      u0 += partL[(long)h * C + c];
+      u1 += partL[(long)(h + 4) * C + c];
+      u2 += partL[(long)(h + 8) * C + c];
+      u3 += partL[(long)(h + 12) * C + c];
+    }
+    for (; h < Hpp; h += 4) u0 += partL[(long)h * C + c];
+    t = (u0 + u1) + (u2 + u3);
+  }
   red[wave][lane] = t;
   __syncthreads();
   if (wave == 0 && c < C) {
@@ -222,11 +355,11 @@ static __global__ __launch_bounds__(256) void cin_qtail_fill_kernel(const float*
   }
   if (blockIdx.x == 0) {
     for (int n = threadIdx.x; n < Hq; n += 256) {
-      float u = tot[0];
+      float u = dc[F + 1];
       for (int f = 0; f < F; ++f) u = fmaf(wsumL[n * F + f], dc[f], u);
       dbias_p[n] = u;
     }
-    for (int n = threadIdx.x; n < HL; n += 256) dbias_L[n] = tot[1];
+    for (int n = threadIdx.x; n < HL; n += 256) dbias_L[n] = dc[F];
   }
 }
 
