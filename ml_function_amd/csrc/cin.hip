@@ -152,12 +152,12 @@ static DwPlan dw_plan(long M, int C, int H) {
 }
 
 static int launch_dw3(hipStream_t st, const DwPlan& p, const float* gT, int HS, const float* xT, const float* xpT, int xps, float* part,
-                      long M, int F, int Hp, int H, int symD = 0) {
+                      long M, int F, int Hp, int H, int symD = 0, int xtra = 0) {
   const int items = p.blocks_x * p.splits * p.chunks;
   const dim3 grid((items + 7) / 8 * 8);
 #define FIL_DW3(MBV, ONES) \
   hipLaunchKernelGGL((cin_dw3_kernel<MBV, ONES>), grid, dim3(kCinThreads), 0, st, gT, HS, xT, xpT, xps, part, (int)M, F, Hp, H, p.rows_per_split, \
-                     p.blocks_x, p.chunks, items, symD)
+                     p.blocks_x, p.chunks, items, symD, xtra)
   if (xT == nullptr) {
     if (p.MB == 2) FIL_DW3(2, true); else FIL_DW3(1, true);
   } else {
@@ -208,7 +208,7 @@ static bool tail_used(const CinShape& s, int mode) {
 // Quadratic tail (cin_qtail.h): three layers, pair-symmetric first-layer kernels available, one 128-column chunk below the tail.
 // The top two layers then cost F(F+1)/2 x H_1 products per row -- half of the fused tail's H_1 F (F+1), and no column padding.
 static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
-  return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.F + 2 <= kQtConst && s.H[0] <= 128 && 3 * s.F <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
+  return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.F + 2 <= kQtConst && s.H[0] <= 128 && 3 * s.F + 1 <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
          knobs().qtail != 0;   // (3 F: its three [M][F] scratch arrays share one gradient buffer)
 }
 static size_t qtail_saved_floats(const CinShape& s) {   // R | T | wsum_L | cvec, behind xT and the first layer's map
@@ -291,6 +291,7 @@ static size_t dw_part_floats(const CinShape& s) {
   for (int l = 0; l < s.L; ++l) pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(l) * s.F, s.H[l]).splits * s.Hp(l) * s.F * s.H[l]);
   const int csym = s.F * (s.F / 2 + 1);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
+  pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym + s.F, s.H[0]).splits * (csym + s.F) * s.H[0]);   // quadratic tail: pairs + F single-field rows
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
   const TailGeom g = tail_geom(s);
@@ -711,12 +712,10 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const float* dPL = dPsrc + (size_t)lL * K;
     const float* dPprev = dPsrc + (size_t)(p - 1) * K;
     const double algo = gemm_flops(M, Hpp, F, Hq) + gemm_flops(M, Hq, F, tg.HL);
-    // Gbuf[1] is free until the layer loop is over (L == 3: the loop runs layer 0 only): xs | yT, later xs | gxR | dxR
-    float* xs = Gbuf[1];
-    float* yT = xs + (size_t)M * F;
-    float* gxR = xs + (size_t)M * F;
+    // Gbuf[1] is free until the layer loop is over (L == 3: the loop runs layer 0 only): xs | gxR | dxR
+    float* xs = Gbuf[1];                         // [M][F+1]: dP_L x | dP_p
+    float* gxR = xs + (size_t)M * (F + 1);
     float* dxR = gxR + (size_t)M * F;
-    const int YS = (F + 3) & ~3;
     {
       ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
       const size_t sh = (size_t)256 * (F + 3) * sizeof(float);
@@ -725,13 +724,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     }
     FIL_CHECK_LAUNCH();
     {
-      // pooled-weights shortcut of layer p: v^T [F][Hpp] (the rank-one part of dW_p), G^{p-1} = dP_p S + dP_{p-1}, dX = dP_p x1 wsum_p
+      // pooled-weights shortcut of layer p: G^{p-1} = dP_p S + dP_{p-1} (+ dP_L R), dX = dP_p x1 wsum_p
       ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
       hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[p], wsum, Hpp * F, Hq, Wz, Hpp, F, 2 * JT, chunks_of(Hpp));
-      const long tot = M * YS;
-      hipLaunchKernelGGL(cin_scale_rows3_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, xT, dPp, (int)LK, K, yT, (int)M, F, YS);
-      const int nb = launch_dw3(st, dw_plan(M, F, Hpp), xpT, xps, nullptr, yT, YS, part, M, /*F=*/1, /*Hp=*/F, /*H=*/Hpp);
-      hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv(Hpp * F, 64)), dim3(256), 0, st, part, vlast, (long)Hpp * F, nb);
       // (+ dP_L R on the way out: the pool_L part of G^{p-1})
       cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL);
     }
@@ -740,9 +735,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const int JTs = cin_jt_sym(F);
     {
       ProfScope ps("cin_bwd_dw_tail", st, algo, gemm_flops(M, 1, Cl, Hpp));
-      const int parts = launch_dw3(st, dw_plan(M, Cl, Hpp), xpT, HS0, xT, xs, F, part, M, F, F, Hpp, symD);
-      const long nW = (long)Cl * Hpp;
-      hipLaunchKernelGGL(cin_reduce_expand_sym_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, qt_dT, F, symD, Hpp, parts);
+      // F extra channel rows behind the pairs: v^T[f][h] = sum_m dP_p[m] x[m,f] x1[m,h], the rank-one part of dW_p (column F of xs)
+      const int parts = launch_dw3(st, dw_plan(M, Cl + F, Hpp), xpT, HS0, xT, xs, F + 1, part, M, F, F, Hpp, symD, /*xtra=*/F);
+      const long nW = (long)Cl * Hpp, pstride = (long)(Cl + F) * Hpp;
+      hipLaunchKernelGGL(cin_reduce_expand_sym_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, qt_dT, F, symD, Hpp, parts, pstride);
+      hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv(F * Hpp, 64)), dim3(256), 0, st, part + nW, vlast, (long)F * Hpp, parts, nullptr, 0L, pstride);
     }
     FIL_CHECK_LAUNCH();
     {

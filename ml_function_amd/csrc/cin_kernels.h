@@ -1142,11 +1142,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
 template <int MB, bool XONES, int DEPTH = kDwDepth>
 __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ xT,
                                                           const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
-                                                          int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items, int symD) {
+                                                          int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items, int symD,
+                                                          int xtra = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   // symD > 0 (first layer, x^{l-1} = x): channels are the unordered pairs c = h*symD + d <-> (h, f = (h+d) mod F)
-  const int C = symD > 0 ? F * symD : Hp * F;
+  // xtra > 0 (quadratic tail): `xtra` more channels behind the pairs, c = F*symD + f <-> x^{l-1} column F (an extra column of the
+  // xpT array: a per-row scale) times x[m,f] -- a second, rank-F product riding in the same pass over G
+  const int C = symD > 0 ? F * symD + xtra : Hp * F;
   // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup i
   // of XCD i%8 takes item (i%8)*(grid/8) + i/8 of the split-major item list: an XCD then streams only its own
   // row splits of G / x / x^{l-1} through its L2 instead of all of them (grid is a multiple of 8).
@@ -1172,8 +1175,12 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
   for (int mb = 0; mb < MB; ++mb) {
     const int c = c0 + mb * 32 + r;
     const int cc = c < C ? c : C - 1;
-    const int hh = symD > 0 ? cc / symD : cc / F;
-    const int ff = symD > 0 ? (hh + (cc - hh * symD)) % F : cc - hh * F;
+    int hh = symD > 0 ? cc / symD : cc / F;
+    int ff = symD > 0 ? (hh + (cc - hh * symD)) % F : cc - hh * F;
+    if (symD > 0 && cc >= F * symD) {
+      hh = F;
+      ff = cc - F * symD;
+    }
     ho[mb] = (half * xps + hh) * 4;            // byte offsets of the lane's column inside row (m_lo + half)
     fo[mb] = (half * F + ff) * 4;
   }
@@ -1477,21 +1484,23 @@ static __global__ __launch_bounds__(256) void cin_scale_rows3_kernel(const float
 // out[i] = sum_{p < parts} part[p*n + i]   (fixed order).  One workgroup per 64 outputs; the 4 waves take every 4th
 // partial (coalesced over i), then the 4 wave sums are added in wave order -> many loads in flight, fixed order.
 // out2 != nullptr: outputs i >= n1 go to out2[i - n1] (the dense head: ddense_w | ddense_b from one partial buffer, no copies).
+// pstride: distance between consecutive partials (0 = n: densely packed)
 __device__ __forceinline__ void cin_reduce_body(const float* __restrict__ part, float* __restrict__ out, long n, int parts,
-                                                float* __restrict__ out2, long n1, int bid) {
+                                                float* __restrict__ out2, long n1, int bid, long pstride = 0) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long i = (long)bid * 64 + lane;
+  const long ps = pstride > 0 ? pstride : n;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   if (i < n) {
     int p = wave;
     for (; p + 12 < parts; p += 16) {
-      t0 += part[(long)p * n + i];
-      t1 += part[(long)(p + 4) * n + i];
-      t2 += part[(long)(p + 8) * n + i];
-      t3 += part[(long)(p + 12) * n + i];
+      t0 += part[(long)p * ps + i];
+      t1 += part[(long)(p + 4) * ps + i];
+      t2 += part[(long)(p + 8) * ps + i];
+      t3 += part[(long)(p + 12) * ps + i];
     }
-    for (; p < parts; p += 4) t0 += part[(long)p * n + i];
+    for (; p < parts; p += 4) t0 += part[(long)p * ps + i];
   }
   red[wave][lane] = (t0 + t1) + (t2 + t3);
   __syncthreads();
@@ -1502,8 +1511,8 @@ __device__ __forceinline__ void cin_reduce_body(const float* __restrict__ part, 
   }
 }
 static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
-                                                         int parts, float* __restrict__ out2 = nullptr, long n1 = 0) {
-  cin_reduce_body(part, out, n, parts, out2, n1, blockIdx.x);
+                                                         int parts, float* __restrict__ out2 = nullptr, long n1 = 0, long pstride = 0) {
+  cin_reduce_body(part, out, n, parts, out2, n1, blockIdx.x, pstride);
 }
 
 // Pair-indexed first-layer weight gradient: fixed-order sum of the row-split partials (as cin_reduce_kernel: 64 outputs per
@@ -1511,21 +1520,22 @@ static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __r
 // slot (h, d) <-> f = (h + d) mod F gives dW[(h,f)] and, unless d == 0 or 2d == F (that pair's other end has its own slot),
 // dW[(f,h)].
 static __global__ __launch_bounds__(256) void cin_reduce_expand_sym_kernel(const float* __restrict__ part, float* __restrict__ dW, int F, int D,
-                                                                    int H, int parts) {
+                                                                    int H, int parts, long pstride = 0) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long n = (long)F * D * H;
+  const long ps = pstride > 0 ? pstride : n;   // (partials that carry extra rows behind the pair rows: cin_dw3_kernel's xtra)
   const long i = (long)blockIdx.x * 64 + lane;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   if (i < n) {
     int p = wave;
     for (; p + 12 < parts; p += 16) {
-      t0 += part[(long)p * n + i];
-      t1 += part[(long)(p + 4) * n + i];
-      t2 += part[(long)(p + 8) * n + i];
-      t3 += part[(long)(p + 12) * n + i];
+      t0 += part[(long)p * ps + i];
+      t1 += part[(long)(p + 4) * ps + i];
+      t2 += part[(long)(p + 8) * ps + i];
+      t3 += part[(long)(p + 12) * ps + i];
     }
-    for (; p < parts; p += 4) t0 += part[(long)p * n + i];
+    for (; p < parts; p += 4) t0 += part[(long)p * ps + i];
   }
   red[wave][lane] = (t0 + t1) + (t2 + t3);
   __syncthreads();

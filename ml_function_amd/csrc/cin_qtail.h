@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256, 2) void cin_qtail_pool2_kernel(const float* __
   }
 }
 
-// xs[m,f] = dP_L[m] x[m,f]  (the scaled factor of the pair products in the dT GEMM) and, per block of 256 rows, the column sums
+// xs[m][F+1]: xs[m,f] = dP_L[m] x[m,f] (the scaled factor of the pair products in the dT GEMM), xs[m,F] = dP_p[m] (the scale of the
+// F extra channels that give the shortcut's rank-one dW_p part); and, per block of 256 rows, the column sums
 // dcpart[blk][f] = sum_m xs[m,f] (-> dc[f] = d pool_L / d c[f]), dcpart[blk][F] = sum_m dP_L[m], dcpart[blk][F+1] = sum_m dP_p[m].
 // One row per thread.  LDS: [256][F+3]
 static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
@@ -183,9 +184,10 @@ static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float
     const float dl = dPL[b * ldp + (m - b * K)], dp = dPp[b * ldp + (m - b * K)];
     for (int f = 0; f < F; ++f) {
       const float v = xT[m * F + f] * dl;
-      xs[m * F + f] = v;
+      xs[m * (F + 1) + f] = v;
       row[f] = v;
     }
+    xs[m * (F + 1) + F] = dp;
     row[F] = dl;
     row[F + 1] = dp;
   } else {
