@@ -318,7 +318,7 @@ static size_t bwd_ws_bytes(const CinShape& s) {
   t += 2 * align_up(M * s.F * sizeof(float), 256);                       // dxT, Gx^0
   t += align_up(gb_bytes(s), 256);                                       // split-bf16 planes of G (mode bit 1)
   t += align_up((size_t)s.F * s.F * kCinMaxH * sizeof(float), 256);      // quadratic tail: dT
-  t += align_up(((M + 255) / 256) * kQtConst * sizeof(float), 256);      //                 column-sum partials of dP_L x
+  t += align_up(((M + 255) / 256 + 1) * kQtConst * sizeof(float), 256);  //                 column-sum partials of dP_L x, their sum
   return t;
 }
 
@@ -658,7 +658,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   bf16x8* Gb = reinterpret_cast<bf16x8*>(ws.take<char>(gb_bytes(s)));
   float* qt_dT = ws.take<float>((size_t)F * F * kCinMaxH);
   const int qt_ndc = (int)((M + 255) / 256);
-  float* qt_dcpart = ws.take<float>((size_t)qt_ndc * kQtConst);
+  float* qt_dcpart = ws.take<float>((size_t)(qt_ndc + 1) * kQtConst);   // block partials | their sum
 
   // saved tensors
   Carver sv(const_cast<float*>(saved));
@@ -689,11 +689,12 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ProfScope ps("cin_head_bwd", st);
     hipLaunchKernelGGL(cin_head_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, dense_w, pooled, dP, small, B, (int)LK, kHeadChunk);
     // (fused tail: the fixed-order sum of the head's partials rides in the tail's first launch, below)
-    if (!tail || qtail) hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
+    // (fused / quadratic tail: the fixed-order sum of the head's partials rides in the tail's first launch, below)
+    if (!tail) hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv((int)LK + 1, 64)), dim3(256), 0, st, small, ddense_w, (long)(LK + 1), nblk, ddense_b, (long)LK);
     FIL_CHECK_LAUNCH();
     dPsrc = dP;
   }
-  if (!tail || qtail) ready(L);
+  if (!tail) ready(L);
 
   int cur = 0;
   int ltop = L - 1;          // first layer handled by the general kernels
@@ -720,9 +721,12 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
       const size_t sh = (size_t)256 * (F + 3) * sizeof(float);
       allow_lds(cin_qtail_scale_kernel, sh);
-      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xs, qt_dcpart, (int)M, F);
+      const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + the head's partial sums (as in the fused tail's first launch)
+      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc + nh), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xs, qt_dcpart, (int)M, F, qt_ndc, small,
+                         ddense_w, ddense_b, (int)LK, nblk);
     }
     FIL_CHECK_LAUNCH();
+    ready(L);
     {
       // pooled-weights shortcut of layer p: G^{p-1} = dP_p S + dP_{p-1} (+ dP_L R), dX = dP_p x1 wsum_p
       ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
@@ -746,9 +750,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       ProfScope ps("cin_tail_params", st);
       const size_t sh = ((size_t)F * (Hq + 1) + (size_t)F * (F + 1)) * sizeof(float);
       allow_lds(cin_qtail_params_kernel, sh);
-      hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq);
-      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, qt_dcpart, qt_ndc, bias[p], qtWsumL, dW[lL], dbias[p],
-                         dbias[lL], F, Hq, tg.HL);
+      float* dcfin = qt_dcpart + (size_t)qt_ndc * kQtConst;
+      hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq, qt_dcpart, qt_ndc,
+                         dcfin);
+      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, dcfin, bias[p], qtWsumL, dW[lL], dbias[p], dbias[lL], F, Hq,
+                         tg.HL);
     }
     FIL_CHECK_LAUNCH();
     ready(lL);
@@ -765,9 +771,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const int ks = MBs != 1 ? 1 : tune.ksplit(M);
       cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), xpT, HS0, Wz, xT, gxR, dxR, 0, (int)M, F, Hpp,
                          periods, false, ks);
-      const long tot = M * F;
-      hipLaunchKernelGGL(cin_qtail_dx_kernel, dim3((int)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st, dxT, gxR, dxR, qtCvec, dPL, (int)LK, K,
-                         (int)M, F);
+      // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
     }
     FIL_CHECK_LAUNCH();
     dx_started = true;
@@ -982,7 +986,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   }
   {
     ProfScope ps("cin_transpose_out", st, 2.0 * M * F * sizeof(float));
-    hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K);
+    if (qtail)
+      hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K,
+                         Gbuf[1] + (size_t)M * (F + 1), Gbuf[1] + (size_t)M * (F + 1) + (size_t)M * F, qtCvec, dPsrc + (size_t)(L - 1) * K, (int)LK);
+    else
+      hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K);
   }
   FIL_CHECK_LAUNCH();
   return FIL_OK;

@@ -62,12 +62,24 @@ static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const floa
 }
 
 // dx [B,F,K] = dxT [M][F] (+ addT [M][F])
+// q1 != nullptr (quadratic tail): + scale[m] * (q1[m,f] + q2[m,f] + qc[f]), scale[m] = qs[b*ldq + k] -- the two halves of the
+// quadratic form's gradient and its linear term, computed on the unscaled x1
 static __global__ __launch_bounds__(256) void cin_transpose_out_kernel(const float* __restrict__ dxT, const float* __restrict__ addT,
-                                                                float* __restrict__ dx, int F, int K) {
+                                                                float* __restrict__ dx, int F, int K, const float* __restrict__ q1 = nullptr,
+                                                                const float* __restrict__ q2 = nullptr, const float* __restrict__ qc = nullptr,
+                                                                const float* __restrict__ qs = nullptr, int ldq = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][F+1]
   const long b = blockIdx.x;
   const float* src = dxT + b * K * F;
   const float* src2 = addT != nullptr ? addT + b * K * F : nullptr;
+  if (q1 != nullptr) {
+    const float* a1 = q1 + b * K * F;
+    const float* a2 = q2 + b * K * F;
+    for (int i = threadIdx.x; i < F * K; i += 256) {
+      const int k = i / F, f = i - k * F;
+      smem[k * (F + 1) + f] = (src[i] + (src2 ? src2[i] : 0.f)) + qs[b * ldq + k] * ((a1[i] + a2[i]) + qc[f]);
+    }
+  } else
   for (int i = threadIdx.x; i < F * K; i += 256) smem[(i / F) * (F + 1) + (i % F)] = src[i] + (src2 ? src2[i] : 0.f);
   __syncthreads();
   float* dst = dx + b * F * K;

@@ -46,11 +46,43 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
   }
   float* wp = smem;
   float* wl = smem + F * (Hq + 1);
-  for (int i = threadIdx.x; i < F * Hq; i += 256) {
-    const int fp = i / Hq, n = i - fp * Hq;
-    wp[fp * (Hq + 1) + n] = Wp[((long)h * F + fp) * Hq + n];
+  if ((Hq & 3) == 0) {   // 16-byte loads, all of a thread's pieces in flight before the first LDS store
+    const float4* src = reinterpret_cast<const float4*>(Wp + (long)h * F * Hq);
+    const int q = Hq >> 2, tot = F * q;
+    for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * 256) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = i0 + u * 256 < tot ? src[i0 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < tot) {
+          const int fp = i / q, n = 4 * (i - fp * q);
+          float* d = wp + fp * (Hq + 1) + n;
+          d[0] = v[u].x;
+          d[1] = v[u].y;
+          d[2] = v[u].z;
+          d[3] = v[u].w;
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < F * Hq; i += 256) {
+      const int fp = i / Hq, n = i - fp * Hq;
+      wp[fp * (Hq + 1) + n] = Wp[((long)h * F + fp) * Hq + n];
+    }
   }
-  for (int i = threadIdx.x; i < Hq * F; i += 256) wl[i] = wsumL[i];
+  {
+    const int tot = Hq * F;
+    for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = i0 + u * 256 < tot ? wsumL[i0 + u * 256] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * 256 < tot) wl[i0 + u * 256] = v[u];
+    }
+  }
   __syncthreads();
   const int nhalf = (F * F + 1) / 2;
   for (int idx = part * nhalf + threadIdx.x; idx < min(F * F, (part + 1) * nhalf); idx += 256) {
@@ -64,30 +96,6 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
     }
     if (n < Hq) t0 = fmaf(a[n], wl[n * F + f], t0);
     T[(long)idx * Hpp + h] = t0 + t1;
-  }
-}
-
-// pool_L[m] = sum_h xp[m,h] R[m,h] + sum_f x[m,f] cvec[f] + cvec[kQtConst]; 32 lanes per row.
-static __global__ __launch_bounds__(256) void cin_qtail_pool_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
-                                                                    const float* __restrict__ R, int HS, const float* __restrict__ cvec,
-                                                                    float* __restrict__ pool, int M, int F, int Hpp) {
-  const int l = threadIdx.x & 31;
-  const long row0 = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
-  const float c0 = l < F ? cvec[l] : 0.f, c1 = l + 32 < F ? cvec[l + 32] : 0.f, cc = cvec[kQtConst];
-  for (long m = row0; m < M; m += (long)gridDim.x * 8) {
-    float t = 0.f;
-    for (int h0 = 4 * l; h0 < Hpp; h0 += 128) {
-      const float4 a = *reinterpret_cast<const float4*>(xpT + m * xps + h0);
-      const float4 b = *reinterpret_cast<const float4*>(R + m * HS + h0);
-      t = fmaf(a.x, b.x, t);
-      if (h0 + 1 < Hpp) t = fmaf(a.y, b.y, t);
-      if (h0 + 2 < Hpp) t = fmaf(a.z, b.z, t);
-      if (h0 + 3 < Hpp) t = fmaf(a.w, b.w, t);
-    }
-    if (l < F) t = fmaf(xT[m * F + l], c0, t);
-    if (l + 32 < F) t = fmaf(xT[m * F + l + 32], c1, t);
-    t = half_wave_sum(t);
-    if (l == 0) pool[m] = t + cc;
   }
 }
 
@@ -174,8 +182,14 @@ __global__ __launch_bounds__(256, 2) void cin_qtail_pool2_kernel(const float* __
 // One row per thread.  LDS: [256][F+3]
 static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
                                                                      const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xs,
-                                                                     float* __restrict__ dcpart, int M, int F) {
+                                                                     float* __restrict__ dcpart, int M, int F, int nscale,
+                                                                     const float* __restrict__ hpart, float* __restrict__ ddw, float* __restrict__ ddb,
+                                                                     int LK, int nhp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= nscale) {   // the dense head's partial sums -> ddense_w | ddense_b (fixed order)
+    cin_reduce_body(hpart, ddw, (long)LK + 1, nhp, ddb, (long)LK, blockIdx.x - nscale);
+    return;
+  }
   const int ld = F + 3;
   const long m = (long)blockIdx.x * 256 + threadIdx.x;
   float* row = smem + threadIdx.x * ld;
@@ -211,49 +225,35 @@ static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float
   if (threadIdx.x < F + 2) dcpart[(long)blockIdx.x * kQtConst + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
 }
 
-// G[m,h] += dP_L[m] R[m,h]   (the pool_L part of the gradient of x^{p-1}); rows of both are 16-byte aligned
-static __global__ __launch_bounds__(256) void cin_qtail_gadd_kernel(float* __restrict__ G, int HSg, const float* __restrict__ R, int HSr,
-                                                                    const float* __restrict__ dP, int ldp, int K, int M, int Hpp) {
-  const int q = (Hpp + 3) >> 2;
-  const long total = (long)M * q;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / q;
-    const int h0 = 4 * (int)(i - m * q);
-    const long b = m / K;
-    const float d = dP[b * ldp + (m - b * K)];
-    float4* g = reinterpret_cast<float4*>(G + m * HSg + h0);
-    const float4 r = *reinterpret_cast<const float4*>(R + m * HSr + h0);
-    float4 v = *g;
-    v.x = fmaf(d, r.x, v.x);
-    v.y = fmaf(d, r.y, v.y);
-    v.z = fmaf(d, r.z, v.z);
-    v.w = fmaf(d, r.w, v.w);
-    *g = v;
-  }
-}
-
-// dxT[m,f] += dP_L[m] (gxR[m,f] + dxR[m,f] + c[f]): the two halves of the quadratic form's gradient (pair-symmetric dZ kernel run on
-// the UNSCALED x1) and the linear term
-static __global__ __launch_bounds__(256) void cin_qtail_dx_kernel(float* __restrict__ dxT, const float* __restrict__ gxR, const float* __restrict__ dxR,
-                                                                  const float* __restrict__ cvec, const float* __restrict__ dP, int ldp, int K,
-                                                                  int M, int F) {
-  const long total = (long)M * F;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / F;
-    const int f = (int)(i - m * F);
-    const long b = m / K;
-    dxT[i] = fmaf(dP[b * ldp + (m - b * K)], (gxR[i] + dxR[i]) + cvec[f], dxT[i]);
-  }
-}
-
 // Two workgroups per h < Hpp (phase = blockIdx & 1):
 //   phase 0:  dW_p[(h,f'),n] = v[(h,f')] + sum_f dT[(f',f),h] wsum_L[(n,f)]       (v: the pooled-weights shortcut's rank-one part,
 //   phase 1:  partL[h][(n,f)] = sum_f' W_p[(h,f'),n] dT[(f',f),h]                   given transposed, vT[f'][Hpp])
 // LDS: dt [F][F+1] | wl [Hq][F] (phase 0)  or  wp [F][Hq+1] (phase 1)
 static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
                                                                       const float* __restrict__ dT, const float* __restrict__ vT,
-                                                                      float* __restrict__ dWp, float* __restrict__ partL, int Hpp, int F, int Hq) {
+                                                                      float* __restrict__ dWp, float* __restrict__ partL, int Hpp, int F, int Hq,
+                                                                      const float* __restrict__ dcpart, int ndc, float* __restrict__ dcfin) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x == 2 * Hpp) {
+    // the extra workgroup: dc[f] (and the two dP sums behind it) = fixed-order sum of the block partials, for cin_qtail_fill_kernel
+    float* red = smem;   // [4][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (lane < F + 2) {
+      int p = wave;
+      for (; p + 12 < ndc; p += 16) {
+        a0 += dcpart[(long)p * kQtConst + lane];
+        a1 += dcpart[(long)(p + 4) * kQtConst + lane];
+        a2 += dcpart[(long)(p + 8) * kQtConst + lane];
+        a3 += dcpart[(long)(p + 12) * kQtConst + lane];
+      }
+      for (; p < ndc; p += 4) a0 += dcpart[(long)p * kQtConst + lane];
+    }
+    red[wave * 64 + lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0) dcfin[lane] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    return;
+  }
   const int h = blockIdx.x >> 1, phase = blockIdx.x & 1;
   float* dt = smem;
   float* op = dt + F * (F + 1);
@@ -300,8 +300,8 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
 
 // dwsum_L[(n,f)] = sum_h partL[h][(n,f)] + bias_p[n] dc[f]  ->  dW_L[(n,f), n'] for every n' (64 rows (n,f) per workgroup);
 // workgroup 0 also finishes dbias_p[n] = sum_m dP_p[m] + sum_f wsum_L[(n,f)] dc[f] and dbias_L[n'] = sum_m dP_L[m].
-// dc[f] = sum of the ndc block partials of cin_qtail_scale_kernel (columns F, F+1 of the partials: sum_m dP_L[m], sum_m dP_p[m]).
-static __global__ __launch_bounds__(256) void cin_qtail_fill_kernel(const float* __restrict__ partL, int Hpp, const float* __restrict__ dcpart, int ndc,
+// dcfin[f] = dc[f], dcfin[F] = sum_m dP_L[m], dcfin[F+1] = sum_m dP_p[m] (summed by the extra workgroup of cin_qtail_params_kernel).
+static __global__ __launch_bounds__(256) void cin_qtail_fill_kernel(const float* __restrict__ partL, int Hpp, const float* __restrict__ dcfin,
                                                                     const float* __restrict__ bias_p, const float* __restrict__ wsumL,
                                                                     float* __restrict__ dWL, float* __restrict__ dbias_p, float* __restrict__ dbias_L,
                                                                     int F, int Hq, int HL) {
@@ -309,23 +309,7 @@ static __global__ __launch_bounds__(256) void cin_qtail_fill_kernel(const float*
   __shared__ float red[4][64];
   __shared__ float val[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    // dc[f]: the four waves take every fourth block partial (four independent chains each), folded in wave order
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (lane < F + 2) {
-      int p = wave;
-      for (; p + 12 < ndc; p += 16) {
-        a0 += dcpart[(long)p * kQtConst + lane];
-        a1 += dcpart[(long)(p + 4) * kQtConst + lane];
-        a2 += dcpart[(long)(p + 8) * kQtConst + lane];
-        a3 += dcpart[(long)(p + 12) * kQtConst + lane];
-      }
-      for (; p < ndc; p += 4) a0 += dcpart[(long)p * kQtConst + lane];
-    }
-    red[wave][lane] = (a0 + a1) + (a2 + a3);
-  }
-  __syncthreads();
-  if (wave == 0) dc[lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0) dc[lane] = lane < F + 2 ? dcfin[lane] : 0.f;
   __syncthreads();
   const int C = Hq * F;
   const int c = blockIdx.x * 64 + lane;
