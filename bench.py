@@ -374,19 +374,25 @@ def pmc_traffic(scope):
     with open(files[-1]) as fh:
         per = json.load(fh)["per_launch"]
     src = "committed profile " + os.path.basename(files[-1])
-    if m.group(2) == "tail":
-        prefix = {"fwd": "cin_tail_fwd_kernel", "bwd_dz": "cin_tail_dz_kernel", "bwd_dw": "cin_tail_dw_kernel"}[m.group(1)]
-        hits = [v["hbm_bytes"] for k, v in per.items() if k.startswith(prefix)]
-        return (hits[0], src) if len(hits) == 1 else (None, None)
-    prefix = {"fwd": "cin_fwd3_kernel", "bwd_dz": "cin_dz3_kernel", "bwd_dw": "cin_dw3_kernel"}[m.group(1)]
-    hits = sorted((v["first_dispatch"], v["hbm_bytes"]) for k, v in per.items() if k.startswith(prefix) and not _split_instance(k))
-    if len(hits) == 1:
-        return hits[0][1], src
-    if len(hits) != 2:
-        return None, None
-    # two MFMA layers (l = 1, 2): the forward visits l1 then l2, the backward l2 then l1
-    first_is_l1 = m.group(1) == "fwd"
-    return hits[0 if (m.group(2) == "l1") == first_is_l1 else 1][1], src
+    hit = _gemm_launch_of(per, m.group(1), m.group(2))
+    return (per[hit]["hbm_bytes"], src) if hit is not None else (None, None)
+
+
+def _gemm_launch_of(per, kind, layer):
+    """Key (in a per-launch PMC summary) of the GEMM launch behind profiler scope cin_<kind>_<layer>.  The exact-fp32 step runs its
+    GEMMs in a fixed order: forward l1, l2, .., tail; backward tail, .., l2, l1 -- and a kernel launched several times per step appears
+    as '<name> #slot' entries.  The quadratic tail runs the FIRST layer's kernels a second time (forward: second launch; backward:
+    first), the fused tail has kernels of its own (cin_tail_*)."""
+    prefixes = {"fwd": ("cin_fwd3_kernel", "cin_tail_fwd_kernel"), "bwd_dz": ("cin_dz3_kernel", "cin_tail_dz_kernel"),
+                "bwd_dw": ("cin_dw3_kernel", "cin_tail_dw_kernel")}[kind]
+    hits = sorted((v["first_dispatch"], k) for k, v in per.items() if k.startswith(prefixes) and not _split_instance(k))
+    if not hits:
+        return None
+    order = [k for _, k in hits] if kind == "fwd" else [k for _, k in hits][::-1]     # -> l1, l2, .., (tail)
+    if layer == "tail":
+        return order[-1] if len(order) >= 2 else None
+    i = int(layer[1:]) - 1
+    return order[i] if i < len(order) else None
 
 
 def mfma_util(scope):

@@ -365,8 +365,11 @@ TAIL_SHAPES = [
 
 
 @pytest.mark.parametrize("B,F,K,conv", TAIL_SHAPES)
-# (| 4: the 64-row waves large batches get; | 128: one wave per row block instead of the small-batch reduction split)
-@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 4), (1, 64 | 128)])
+# (| 4: the 64-row waves large batches get; | 128: one wave per row block instead of the small-batch reduction split;
+#  | 256: FIL_CIN_NOQTAIL -- three-layer nets take the quadratic tail (cin_qtail.h) by default, this bit keeps them on the F+1-column
+#  fused tail so that both stay covered; four-layer, wide-F and NOSYM cases run the fused tail either way)
+@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 4), (1, 64 | 128), (1, 64 | 256), (2, 64 | 256), (1, 64 | 256 | 4),
+                                             (1, 64 | 8)])
 def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
     from ml_function_amd import functional as Fn
     c = synth.cin_case(B, F, K, conv, dist="uniform", output_dim=output_dim)
@@ -427,6 +430,9 @@ def test_cin_fused_tail_is_the_default_where_it_pays():
         assert torch.equal(a, b2) == same
         assert torch.equal(a, t) == (not same)
         assert rel(a, b2.cpu().numpy()) < 1e-5
+        # three layers: mode 64 is the quadratic tail, 64 | 256 the F+1-column fused tail -- different kernels, same function
+        u = Fn.cin(*args, mode=64 | 256)
+        assert not torch.equal(t, u) and rel(t, u.cpu().numpy()) < 1e-5
 
 
 _BENCH_ORACLE = {}
@@ -456,7 +462,7 @@ def _bench_shape_oracle():
     return _BENCH_ORACLE
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 32])
+@pytest.mark.parametrize("mode", [0, 1, 2, 32, 256])
 def test_cin_at_the_benchmark_shape(mode):
     """The launch configuration bench.py times (M = B*K = 65,536 rows: 64-row waves, the fused tail's forward / weight-gradient
     split plan / data-gradient kernels, the dW split plan and XCD mapping of that size) against the fp64 oracle -- every output

@@ -91,8 +91,10 @@ def test_workspace_sizes(lib):
     H = _lib.int_array([128, 128, 128])
     B, F, K = 4096, 39, 16
     M = B * K
-    # saved = xT [M][F] + the m-major feature maps x^1, x^2 ([M][128] each; the last layer's map is never stored)
-    assert lib.fil_cin_saved_bytes(B, F, K, 3, H) == M * F * 4 + 2 * M * 128 * 4
+    # saved = xT [M][F] + the first layer's m-major feature map [M][128] + the quadratic tail's R [M][128], T [F*F][128], wsum_L [128*F]
+    # and cvec [128] (one 256-byte-aligned slice); the upper layers' maps are never stored
+    qt = (M * 128 + F * F * 128 + 128 * F + 128) * 4
+    assert lib.fil_cin_saved_bytes(B, F, K, 3, H) == M * F * 4 + M * 128 * 4 + (qt + 255) // 256 * 256
     assert lib.fil_cin_fwd_workspace_bytes(B, F, K, 3, H) >= 3 * M * 4
     assert lib.fil_cin_bwd_workspace_bytes(B, F, K, 3, H) > 2 * M * 128 * 4
     assert lib.fil_cin_saved_bytes(B, F, K, 1, H) == M * F * 4

@@ -30,24 +30,34 @@ def is_split_instance(key):
 
 
 def scopes_of(res):
-    """bench.py's profiler scope -> the counters of the kernel instantiation behind it."""
+    """bench.py's profiler scope -> the counters of the GEMM launch behind it (bench._gemm_launch_of: forward l1, .., tail; backward
+    tail, .., l1; '#slot' entries for a kernel launched several times per step, as the quadratic tail does)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
     def pick(k):
         return {"kernel": k, "mfma_busy_frac": res[k].get("mfma_busy_frac"),
                 "wave_cycles_waiting_frac": res[k].get("wave_cycles_waiting_frac"),
                 "wave_cycles_issue_stalled_frac": res[k].get("wave_cycles_issue_stalled_frac")}
     by_scope = {}
-    for kind, prefix in (("fwd", "cin_fwd3_kernel"), ("bwd_dz", "cin_dz3_kernel"), ("bwd_dw", "cin_dw3_kernel")):
-        hits = sorted((v["first_dispatch"], k) for k, v in res.items() if k.startswith(prefix) and not is_split_instance(k))
-        order = ((1, 2) if kind == "fwd" else (2, 1)) if len(hits) == 2 else ((1,) if len(hits) == 1 else ())
-        # two general MFMA layers (l = 1, 2): the forward visits l1 first, the backward l2 first; with the fused tail only l1 is left
-        for (_, k), l in zip(hits, order):
-            by_scope["cin_%s_l%d" % (kind, l)] = pick(k)
-    for scope, prefix in (("cin_fwd_tail", "cin_tail_fwd_kernel"), ("cin_bwd_dw_tail", "cin_tail_dw_kernel"), ("cin_bwd_dz_tail", "cin_tail_dz_kernel")):
-        hits = [k for k in res if k.startswith(prefix)]
-        if len(hits) == 1:
-            by_scope[scope] = pick(hits[0])
+    base = lambda k: k.split(" #")[0]
+    for kind in ("fwd", "bwd_dz", "bwd_dw"):
+        first, last = bench._gemm_launch_of(res, kind, "l1"), bench._gemm_launch_of(res, kind, "tail")
+        # a tail is in use when the last GEMM of the chain is a cin_tail_* kernel (fused tail) or a second launch of the first
+        # layer's kernel (quadratic tail); otherwise the chain is l1, l2, ..
+        has_tail = last is not None and (base(last).startswith("cin_tail_") or (last != first and base(last) == base(first)))
+        n = 1
+        while True:
+            k = bench._gemm_launch_of(res, kind, "l%d" % n)
+            if k is None or (has_tail and k == last):
+                break
+            by_scope["cin_%s_l%d" % (kind, n)] = pick(k)
+            n += 1
+        if has_tail:
+            by_scope["cin_%s_tail" % kind] = pick(last)
     return by_scope
-
 
 def main():
     d, out, iters = sys.argv[1], sys.argv[2], int(sys.argv[3])
