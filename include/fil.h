@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 207
+#define FIL_ABI_VERSION 208
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -104,6 +104,11 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *         + FIL_CIN_NOTAIL (32): mode 0 without the fused tail (last layer through wsum_L only: the round-2 path);
  *           FIL_CIN_TAIL_ALWAYS (64): the fused tail whenever it is defined (L >= 3, F <= 62), also where it saves nothing
  *           (by default it is used when F+2 columns padded to 16 are at most 3/4 of H_{L-1}); both exist for tests / comparison.
+ *         + FIL_CIN_NOQTAIL (256): for THREE layers (and F + 2 <= 64, H_1 <= 128, 3F + 1 <= the widest feature-map row) mode 0 goes one
+ *           step further than the fused tail: pool_L = sum_h x^1[h] (x^T T_h x) + <x, c> + const is a quadratic form in x for every
+ *           feature map h of the FIRST layer, so the top two layers run as a product over UNORDERED field pairs with the first layer's
+ *           pair-symmetric GEMM kernels -- F(F+1)/2 x H_1 products per row, half of the fused tail's, no column padding
+ *           (csrc/cin_qtail.h).  This bit keeps three-layer nets on the F+1-column fused tail (tests / comparison).
  *         + FIL_CIN_NOKSPLIT (128): small batches (B*K <= 16,384 rows) give each block of 32 rows to the FOUR waves of a workgroup,
  *           which split the reduction between them (strong-scaling shards: without it the row-parallel kernels stop getting faster
  *           below one row block per SIMD); this bit keeps one wave per row block.  Same function up to summation order.

@@ -15,6 +15,36 @@
 
 namespace fil {
 
+// global -> LDS staging with all of a thread's loads in flight before its first store (a plain copy loop is one exposed L2 round
+// trip per element and thread: these kernels are small enough for that to be most of their time)
+__device__ __forceinline__ void qt_stage(const float* __restrict__ src, float* dst, int n) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < n ? src[i0 + u * 256] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * 256 < n) dst[i0 + u * 256] = v[u];
+  }
+}
+// rows of `cols` floats -> rows of ld floats (ld > cols: bank padding)
+__device__ __forceinline__ void qt_stage_rows(const float* __restrict__ src, float* dst, int rows, int cols, int ld) {
+  const int n = rows * cols;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < n ? src[i0 + u * 256] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n) {
+        const int r = i / cols;
+        dst[r * ld + (i - r * cols)] = v[u];
+      }
+    }
+  }
+}
+
 constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
 
 // T[(f'*F + f)*Hpp + h] for block h < Hpp; block Hpp writes cvec and a zero bias vector for the R GEMM.
@@ -26,63 +56,33 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int h = blockIdx.x >> 1, part = blockIdx.x & 1;   // two workgroups per h (each half of the (f', f) outputs); the last one: cvec
   if (h == Hpp) {
+    float* wl = smem;            // wsum_L [Hq][F]
+    float* bp = wl + Hq * F;     // bias_p [Hq]
+    qt_stage(wsumL, wl, Hq * F);
+    qt_stage(bias_p, bp, Hq);
+    __syncthreads();
     for (int f = threadIdx.x; f < F; f += 256) {
       float t = 0.f;
-      for (int n = 0; n < Hq; ++n) t = fmaf(bias_p[n], wsumL[n * F + f], t);
+      for (int n = 0; n < Hq; ++n) t = fmaf(bp[n], wl[n * F + f], t);
       cvec[f] = t;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x >= 64 && threadIdx.x < 192) {   // wave 1: sum bias_L, wave 2: sum bias_p (64 strided chains, then the lanes in order)
+      const int lane = threadIdx.x & 63, which = (threadIdx.x >> 6) - 1;
+      const float* b = which == 0 ? bias_L : bias_p;
+      const int nb = which == 0 ? HL : Hq;
       float t = 0.f;
-      for (int n = 0; n < HL; ++n) t += bias_L[n];
-      cvec[kQtConst] = t;
-    }
-    if (threadIdx.x == 64) {
-      float t = 0.f;
-      for (int n = 0; n < Hq; ++n) t += bias_p[n];
-      cvec[kQtConst + 1] = t;
+      for (int n = lane; n < nb; n += 64) t += b[n];
+      float tot = 0.f;
+      for (int i = 0; i < 64; ++i) tot += __shfl(t, i);
+      if (lane == 0) cvec[kQtConst + which] = tot;
     }
     for (int i = threadIdx.x; i < Hpp; i += 256) zbias[i] = 0.f;
     return;
   }
   float* wp = smem;
   float* wl = smem + F * (Hq + 1);
-  if ((Hq & 3) == 0) {   // 16-byte loads, all of a thread's pieces in flight before the first LDS store
-    const float4* src = reinterpret_cast<const float4*>(Wp + (long)h * F * Hq);
-    const int q = Hq >> 2, tot = F * q;
-    for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * 256) {
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = i0 + u * 256 < tot ? src[i0 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * 256;
-        if (i < tot) {
-          const int fp = i / q, n = 4 * (i - fp * q);
-          float* d = wp + fp * (Hq + 1) + n;
-          d[0] = v[u].x;
-          d[1] = v[u].y;
-          d[2] = v[u].z;
-          d[3] = v[u].w;
-        }
-      }
-    }
-  } else {
-    for (int i = threadIdx.x; i < F * Hq; i += 256) {
-      const int fp = i / Hq, n = i - fp * Hq;
-      wp[fp * (Hq + 1) + n] = Wp[((long)h * F + fp) * Hq + n];
-    }
-  }
-  {
-    const int tot = Hq * F;
-    for (int i0 = threadIdx.x; i0 < tot; i0 += 4 * 256) {
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = i0 + u * 256 < tot ? wsumL[i0 + u * 256] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i0 + u * 256 < tot) wl[i0 + u * 256] = v[u];
-    }
-  }
+  qt_stage_rows(Wp + (long)h * F * Hq, wp, F, Hq, Hq + 1);
+  qt_stage(wsumL, wl, Hq * F);
   __syncthreads();
   const int nhalf = (F * F + 1) / 2;
   for (int idx = part * nhalf + threadIdx.x; idx < min(F * F, (part + 1) * nhalf); idx += 256) {
@@ -257,12 +257,21 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
   const int h = blockIdx.x >> 1, phase = blockIdx.x & 1;
   float* dt = smem;
   float* op = dt + F * (F + 1);
-  for (int i = threadIdx.x; i < F * F; i += 256) {
-    const int fp = i / F, f = i - fp * F;
-    dt[fp * (F + 1) + f] = dT[(long)i * Hpp + h];
+  for (int i0 = threadIdx.x; i0 < F * F; i0 += 8 * 256) {   // (a column of dT: one dword per 512-byte row, all in flight together)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < F * F ? dT[(long)(i0 + u * 256) * Hpp + h] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < F * F) {
+        const int fp = i / F;
+        dt[fp * (F + 1) + (i - fp * F)] = v[u];
+      }
+    }
   }
   if (phase == 0) {
-    for (int i = threadIdx.x; i < Hq * F; i += 256) op[i] = wsumL[i];
+    qt_stage(wsumL, op, Hq * F);
     __syncthreads();
     for (int idx = threadIdx.x; idx < F * Hq; idx += 256) {
       const int fp = idx / Hq, n = idx - fp * Hq;
@@ -278,10 +287,7 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
       dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + (t0 + t1);
     }
   } else {
-    for (int i = threadIdx.x; i < F * Hq; i += 256) {
-      const int fp = i / Hq, n = i - fp * Hq;
-      op[fp * (Hq + 1) + n] = Wp[((long)h * F + fp) * Hq + n];
-    }
+    qt_stage_rows(Wp + (long)h * F * Hq, op, F, Hq, Hq + 1);
     __syncthreads();
     float* pl = partL + (long)h * Hq * F;
     for (int idx = threadIdx.x; idx < Hq * F; idx += 256) {
