@@ -108,7 +108,8 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *           step further than the fused tail: pool_L = sum_h x^1[h] (x^T T_h x) + <x, c> + const is a quadratic form in x for every
  *           feature map h of the FIRST layer, so the top two layers run as a product over UNORDERED field pairs with the first layer's
  *           pair-symmetric GEMM kernels -- F(F+1)/2 x H_1 products per row, half of the fused tail's, no column padding
- *           (csrc/cin_qtail.h).  This bit keeps three-layer nets on the F+1-column fused tail (tests / comparison).
+ *           (csrc/cin_qtail.h).  Used above 16,384 rows (B*K; smaller batches are launch-latency bound and keep the fused tail,
+ *           FIL_CIN_TAIL_ALWAYS lifts that rule).  This bit keeps three-layer nets on the F+1-column fused tail (tests / comparison).
  *         + FIL_CIN_NOKSPLIT (128): small batches (B*K <= 16,384 rows) give each block of 32 rows to the FOUR waves of a workgroup,
  *           which split the reduction between them (strong-scaling shards: without it the row-parallel kernels stop getting faster
  *           below one row block per SIMD); this bit keeps one wave per row block.  Same function up to summation order.

@@ -207,7 +207,10 @@ static bool tail_used(const CinShape& s, int mode) {
 }
 // Quadratic tail (cin_qtail.h): three layers, pair-symmetric first-layer kernels available, one 128-column chunk below the tail.
 // The top two layers then cost F(F+1)/2 x H_1 products per row -- half of the fused tail's H_1 F (F+1), and no column padding.
+// It takes ~10 more small launches than the fused tail: below ~16 K rows (a strong-scaling shard: the step is launch-latency bound
+// there, B=512: 0.40 ms against 0.33) the fused tail stays the default; FIL_CIN_TAIL_ALWAYS lifts the size rule (tests).
 static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
+  if (s.M() <= 16384 && (mode & FIL_CIN_TAIL_ALWAYS) == 0) return false;
   return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.F + 2 <= kQtConst && s.H[0] <= 128 && 3 * s.F + 1 <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
          knobs().qtail != 0;   // (3 F: its three [M][F] scratch arrays share one gradient buffer)
 }
