@@ -214,8 +214,14 @@ static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
   return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.F + 2 <= kQtConst && s.H[0] <= 128 && 3 * s.F + 1 <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
          knobs().qtail != 0;   // (3 F: its three [M][F] scratch arrays share one gradient buffer)
 }
-static size_t qtail_saved_floats(const CinShape& s) {   // R | T | wsum_L | cvec, behind xT and the first layer's map
-  return (size_t)s.M() * s.HS(0) + (size_t)s.F * s.F * s.H[0] + (size_t)s.H[1] * s.F + 128;
+static size_t qtail_wz_floats(const CinShape& s) {      // T in the dZ kernel's slot order
+  const int jts = cin_jt_sym(s.F);
+  return ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
+}
+static size_t qtail_wsn_floats(const CinShape& s) { return (size_t)chunks_of(s.H[0]) * 2 * s.JT() * 128; }
+static size_t qtail_saved_floats(const CinShape& s) {   // R | T | wsum_L | cvec | wsum_p | wsn_p | Wz(T), behind xT and the first layer's map
+  return (size_t)s.M() * s.HS(0) + (size_t)s.F * s.F * s.H[0] + (size_t)s.H[1] * s.F + 128 + (size_t)s.H[0] * s.F + qtail_wsn_floats(s) +
+         qtail_wz_floats(s);
 }
 struct TailDwPlan {
   int blocks_x, splits, rows_per_split;
@@ -408,7 +414,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   const float* xT = xt_in ? x : xT_own;
   // fused tail: its slices of `saved` (behind xT and the maps of the layers below it)
   float *tailY = nullptr, *tailUz = nullptr, *tailBmT = nullptr;
-  float *qtR = nullptr, *qtT = nullptr, *qtWsumL = nullptr, *qtCvec = nullptr;
+  float *qtR = nullptr, *qtT = nullptr, *qtWsumL = nullptr, *qtCvec = nullptr, *qtWsumP = nullptr, *qtWsnP = nullptr, *qtWzT = nullptr;
   if (qtail) {
     Carver pv(saved);
     (void)pv.take<float>((size_t)M * F);
@@ -418,6 +424,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     qtT = qtR + (size_t)M * s.HS(0);
     qtWsumL = qtT + (size_t)F * F * H[0];
     qtCvec = qtWsumL + (size_t)H[1] * F;
+    qtWsumP = qtCvec + 128;
+    qtWsnP = qtWsumP + (size_t)H[0] * F;
+    qtWzT = qtWsnP + qtail_wsn_floats(s);
   } else if (tail) {
     Carver pv(saved);
     (void)pv.take<float>((size_t)M * F);
@@ -430,13 +439,22 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   // alone -- x transpose, first-layer weight pack, pooled weights of the last layer, clearing the tail's operand buffers -- in ONE
   // launch instead of four
   const bool prep_fused = tail && tune.sym && !split;
-  if (prep_fused) {
+  if (qtail) {
+    FIL_CHECK_ARG(W[0] && W[L - 1] && W[L - 2]);
+    ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
+    const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
+    const long npack = (long)chunks0 * F * 2 * JTs * 128;
+    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nwl = cdiv(tg.Hq * F, 8), nwp = cdiv(tg.Hpp * F, 8);
+    const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
+    allow_lds(cin_qtail_prep_kernel, sh);
+    hipLaunchKernelGGL(cin_qtail_prep_kernel, dim3(nt + npk + nwl + nwp), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0, npk,
+                       W[L - 1], qtWsumL, tg.Hq, tg.HL, nwl, W[L - 2], qtWsumP, qtWsnP, tg.Hpp, 2 * JT, chunks_of(tg.Hpp));
+  } else if (prep_fused) {
     FIL_CHECK_ARG(W[0] && W[L - 1]);
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
     const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
     const long npack = (long)chunks0 * F * 2 * JTs * 128;
-    // (quadratic tail: only the transpose and the first layer's weight pack ride here)
-    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = qtail ? 0 : cdiv(tg.Hq * F, 8), nz = qtail ? 0 : 64;
+    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = cdiv(tg.Hq * F, 8), nz = 64;
     const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
     allow_lds(cin_fwd_prep_kernel, sh);
     hipLaunchKernelGGL(cin_fwd_prep_kernel, dim3(nt + npk + nws + nz), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0,
@@ -458,14 +476,15 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       const int JTs = cin_jt_sym(F), chunks = chunks_of(Hpp);
       {
         ProfScope ps("cin_tail_prep", st);
-        hipLaunchKernelGGL(cin_wsum_kernel, dim3(cdiv(Hq * F, 8)), dim3(256), 0, st, W[lL], qtWsumL, Hq * F, tg.HL);
-        // (wsum_p in the MFMA operand layout of the pool kernel, behind the plain copy)
-        hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[l], qt_wsum_p, Hpp * F, Hq, qt_wsum_p + 8192, Hpp, F, 2 * JT, chunks);
+        // (wsum_L, wsum_p and its MFMA operand copy came out of the preparation launch)
         const size_t sh = ((size_t)F * (Hq + 1) + (size_t)Hq * F) * sizeof(float);
         allow_lds(cin_qtail_t_kernel, sh);
         hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        // T in the forward kernel's operand layout (workspace) and in the dZ kernel's slot order (saved for the backward): one launch
         const long npack = (long)chunks * F * 2 * JTs * 128;
-        hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, qtT, Wf, F, Hpp, 2 * JTs, chunks);
+        const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
+        const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);
+        hipLaunchKernelGGL(cin_qtail_pack_kernel, dim3(nbf + nbz), dim3(256), 0, st, qtT, Wf, qtWzT, F, Hpp, JTs, chunks, nbf, HS0, tiles);
       }
       FIL_CHECK_LAUNCH();
       {
@@ -479,7 +498,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       FIL_CHECK_LAUNCH();
       {
         ProfScope ps("cin_tail_pool", st);
-        const float* wsn = qt_wsum_p + 8192;
+        const float* wsn = qtWsnP;
         float* pp = const_cast<float*>(pa.part[l]);
         float* pL = const_cast<float*>(pa.part[lL]);
         const dim3 grid((int)((M + 127) / 128));
@@ -669,7 +688,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   const float* xT = xt_in ? x : xT_own;    // (X_TRANSPOSED: the caller's [B*K][F] copy; the forward left saved's own area unused)
   const float* maps[kCinMaxL];
   const float *tailY = nullptr, *tailUz = nullptr, *tailWsum = nullptr;
-  const float *qtR = nullptr, *qtT = nullptr, *qtWsumL = nullptr, *qtCvec = nullptr;
+  const float *qtR = nullptr, *qtT = nullptr, *qtWsumL = nullptr, *qtCvec = nullptr, *qtWsumP = nullptr, *qtWsnP = nullptr, *qtWzT = nullptr;
   if (qtail) {   // saved layout of the quadratic tail: xT | map 0 | R | T | wsum_L | cvec
     maps[0] = sv.take<float>((size_t)M * s.HS(0));
     const float* q = sv.take<float>(qtail_saved_floats(s));
@@ -677,6 +696,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     qtT = qtR + (size_t)M * s.HS(0);
     qtWsumL = qtT + (size_t)F * F * H[0];
     qtCvec = qtWsumL + (size_t)H[1] * F;
+    qtWsumP = qtCvec + 128;
+    qtWsnP = qtWsumP + (size_t)H[0] * F;
+    qtWzT = qtWsnP + qtail_wsn_floats(s);
   } else if (tail) {   // saved layout of the fused tail: xT | maps 0..L-3 | Y | Uz | wsum_L
     for (int l = 0; l < tg.p; ++l) maps[l] = sv.take<float>((size_t)M * s.HS(l));
     tailY = sv.take<float>((size_t)M * tg.JP);
@@ -733,9 +755,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     {
       // pooled-weights shortcut of layer p: G^{p-1} = dP_p S + dP_{p-1} (+ dP_L R), dX = dP_p x1 wsum_p
       ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
-      hipLaunchKernelGGL(cin_wsum_wsn_kernel, dim3(cdiv(Hpp * F, 8)), dim3(256), 0, st, W[p], wsum, Hpp * F, Hq, Wz, Hpp, F, 2 * JT, chunks_of(Hpp));
-      // (+ dP_L R on the way out: the pool_L part of G^{p-1})
-      cin_launch_last_bwd2(st, JT, xT, xpT, xps, wsum, Wz, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL);
+      // (wsum_p and its operand copy were saved by the forward; + dP_L R on the way out: the pool_L part of G^{p-1})
+      cin_launch_last_bwd2(st, JT, xT, xpT, xps, qtWsumP, qtWsnP, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL);
     }
     FIL_CHECK_LAUNCH();
     const int symD = F / 2 + 1, Cl = F * symD;
@@ -745,8 +766,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       // F extra channel rows behind the pairs: v^T[f][h] = sum_m dP_p[m] x[m,f] x1[m,h], the rank-one part of dW_p (column F of xs)
       const int parts = launch_dw3(st, dw_plan(M, Cl + F, Hpp), xpT, HS0, xT, xs, F + 1, part, M, F, F, Hpp, symD, /*xtra=*/F);
       const long nW = (long)Cl * Hpp, pstride = (long)(Cl + F) * Hpp;
-      hipLaunchKernelGGL(cin_reduce_expand_sym_kernel, dim3((int)((nW + 63) / 64)), dim3(256), 0, st, part, qt_dT, F, symD, Hpp, parts, pstride);
-      hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv(F * Hpp, 64)), dim3(256), 0, st, part + nW, vlast, (long)F * Hpp, parts, nullptr, 0L, pstride);
+      hipLaunchKernelGGL(cin_reduce_expand_sym_kernel, dim3((int)((nW + 63) / 64) + cdiv(F * Hpp, 64)), dim3(256), 0, st, part, qt_dT, F, symD, Hpp, parts,
+                         pstride, vlast, (long)F * Hpp);
     }
     FIL_CHECK_LAUNCH();
     {
@@ -764,15 +785,12 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ready(p);
     {
       const int periods = cdiv(F, cin_dz_h_per_period(JTs));
-      const int tiles = periods * cin_dz_tiles_per_period(JTs) + 1;
-      const long npack = (long)tiles * 32 * HS0;
-      hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, qtT, Wz, F, Hpp, JTs, HS0, tiles);
-      ProfScope ps("cin_bwd_dz_tail", st, algo, gemm_flops(M, 1, Cl, Hpp));
+      ProfScope ps("cin_bwd_dz_tail", st, algo, gemm_flops(M, 1, Cl, Hpp));   // (T in slot order: packed and saved by the forward)
       const int NHMAX = HS0 / 2;
       const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
       const int MBs = two_waves ? 1 : tune.mb_rows(M);
       const int ks = MBs != 1 ? 1 : tune.ksplit(M);
-      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), xpT, HS0, Wz, xT, gxR, dxR, 0, (int)M, F, Hpp,
+      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp,
                          periods, false, ks);
       // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
     }

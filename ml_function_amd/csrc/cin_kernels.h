@@ -1531,8 +1531,18 @@ static __global__ __launch_bounds__(256) void cin_reduce_kernel(const float* __r
 // workgroup, the 4 waves take every 4th partial) written straight to BOTH dW rows of the pair (cin_expand_sym_kernel's map):
 // slot (h, d) <-> f = (h + d) mod F gives dW[(h,f)] and, unless d == 0 or 2d == F (that pair's other end has its own slot),
 // dW[(f,h)].
+// vout != nullptr: the workgroups past the pair rows reduce nv more values that sit behind them in every partial (the extra
+// channel rows of cin_dw3_kernel's xtra) into vout, unexpanded
 static __global__ __launch_bounds__(256) void cin_reduce_expand_sym_kernel(const float* __restrict__ part, float* __restrict__ dW, int F, int D,
-                                                                    int H, int parts, long pstride = 0) {
+                                                                    int H, int parts, long pstride = 0, float* __restrict__ vout = nullptr,
+                                                                    long nv = 0) {
+  if (vout != nullptr) {
+    const long nbw = ((long)F * D * H + 63) / 64;
+    if ((long)blockIdx.x >= nbw) {
+      cin_reduce_body(part + (long)F * D * H, vout, nv, parts, nullptr, 0, (int)(blockIdx.x - nbw), pstride);
+      return;
+    }
+  }
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long n = (long)F * D * H;

@@ -45,6 +45,53 @@ __device__ __forceinline__ void qt_stage_rows(const float* __restrict__ src, flo
   }
 }
 
+// row sums of W [C][H] (8 rows per workgroup) -> wsum[C]; wsn != nullptr: also in the forward kernels' operand layout (as
+// cin_wsum_wsn_kernel: wsn[chunk][fp < JT2][128] = wsum[(chunk*128 + col)*F + fp], padding zeroed by a stride pass over `nblocks`)
+__device__ __forceinline__ void qt_wsum_body(const float* __restrict__ W, float* __restrict__ wsum, int C, int H, float* __restrict__ wsn, int Hp,
+                                             int F, int JT2, int chunks, int bid, int nblocks) {
+  const int row = bid * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  float t = 0.f;
+  if (row < C)
+    for (int n = l; n < H; n += 32) t += W[(long)row * H + n];
+  t = half_wave_sum(t);
+  if (row < C && l == 0) {
+    wsum[row] = t;
+    if (wsn != nullptr) {
+      const int n = row / F, fp = row - n * F;
+      wsn[(((n >> 7) * JT2) + fp) * 128 + (n & 127)] = t;
+    }
+  }
+  if (wsn != nullptr) {
+    const int total = chunks * JT2 * 128;
+    for (int i = bid * 256 + threadIdx.x; i < total; i += nblocks * 256) {
+      const int col = i & 127, fp = (i >> 7) % JT2, chunk = (i >> 7) / JT2;
+      if (fp >= F || chunk * 128 + col >= Hp) wsn[i] = 0.f;
+    }
+  }
+}
+
+// One launch for the forward's input-only preparation (cf. cin_fwd_prep_kernel): [0, nt) x -> xT transposes; [.., +npk) the first
+// layer's pair-symmetric weight pack; [.., +nwl) wsum_L; the rest (nwp workgroups): wsum_p and its MFMA operand copy.
+static __global__ __launch_bounds__(256) void cin_qtail_prep_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K, int nt,
+                                                                    const float* __restrict__ W0, float* __restrict__ Wf, int H0, int JT2s, int chunks0,
+                                                                    int npk, const float* __restrict__ WL, float* __restrict__ wsumL, int Hq, int HL,
+                                                                    int nwl, const float* __restrict__ Wp, float* __restrict__ wsum_p,
+                                                                    float* __restrict__ wsn_p, int Hpp, int JT2, int chunksp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < nt) cin_transpose_in_body(x, xT, F, K, b, smem);
+  else if (b < nt + npk) cin_pack_wf_sym_body(W0, Wf, F, H0, JT2s, chunks0, b - nt, npk);
+  else if (b < nt + npk + nwl) qt_wsum_body(WL, wsumL, Hq * F, HL, nullptr, 0, F, 0, 0, b - nt - npk, nwl);
+  else qt_wsum_body(Wp, wsum_p, Hpp * F, Hq, wsn_p, Hpp, F, JT2, chunksp, b - nt - npk - nwl, gridDim.x - nt - npk - nwl);
+}
+
+// T in both operand layouts from one launch: [0, nbf) the forward kernel's (cin_pack_wf_sym_body), the rest the dZ kernel's slot order
+static __global__ __launch_bounds__(256) void cin_qtail_pack_kernel(const float* __restrict__ T, float* __restrict__ Wf, float* __restrict__ Wz, int F,
+                                                                    int H, int JTs, int chunks, int nbf, int HS, int tiles) {
+  if ((int)blockIdx.x < nbf) cin_pack_wf_sym_body(T, Wf, F, H, 2 * JTs, chunks, blockIdx.x, nbf);
+  else cin_pack_wz_sym_body(T, Wz, F, H, JTs, HS, tiles, blockIdx.x - nbf, gridDim.x - nbf);
+}
+
 constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
 
 // T[(f'*F + f)*Hpp + h] for block h < Hpp; block Hpp writes cvec and a zero bias vector for the R GEMM.

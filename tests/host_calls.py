@@ -55,7 +55,8 @@ def run(lib):
         assert lib.fil_cin_fwd_workspace_bytes(B, 39, 16, 3, H3) >= 0
         assert lib.fil_cin_bwd_workspace_bytes(B, 39, 16, 3, H3) >= 0
     # xT | first layer's map | quadratic tail: R [M][128], T [F*F][128], wsum_L [128*F], cvec [128] (rounded up to 256 bytes)
-    qt = (65536 * 128 + 39 * 39 * 128 + 128 * 39 + 128) * 4
+    # (+ wsum_p [128*F], its MFMA operand copy [40*128], T in the dZ kernel's slot order [26 tiles * 32 * 128])
+    qt = (65536 * 128 + 39 * 39 * 128 + 128 * 39 + 128 + 128 * 39 + 40 * 128 + 26 * 32 * 128) * 4
     assert lib.fil_cin_saved_bytes(4096, 39, 16, 3, H3) == 65536 * 39 * 4 + 65536 * 128 * 4 + (qt + 255) // 256 * 256
     pts = (ctypes.c_int * 4)()
     assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 0, pts) == 3 and list(pts) == [2, 1, 1, 0]     # fused tail: layers 1, 2 together

@@ -93,7 +93,8 @@ def test_workspace_sizes(lib):
     M = B * K
     # saved = xT [M][F] + the first layer's m-major feature map [M][128] + the quadratic tail's R [M][128], T [F*F][128], wsum_L [128*F]
     # and cvec [128] (one 256-byte-aligned slice); the upper layers' maps are never stored
-    qt = (M * 128 + F * F * 128 + 128 * F + 128) * 4
+    # ... + wsum_p [128*F], its MFMA operand copy [40*128] and T in the dZ kernel's slot order [26 tiles * 32 * 128]
+    qt = (M * 128 + F * F * 128 + 128 * F + 128 + 128 * F + 40 * 128 + 26 * 32 * 128) * 4
     assert lib.fil_cin_saved_bytes(B, F, K, 3, H) == M * F * 4 + M * 128 * 4 + (qt + 255) // 256 * 256
     assert lib.fil_cin_fwd_workspace_bytes(B, F, K, 3, H) >= 3 * M * 4
     assert lib.fil_cin_bwd_workspace_bytes(B, F, K, 3, H) > 2 * M * 128 * 4
