@@ -747,8 +747,14 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const size_t sh = (size_t)256 * (F + 3) * sizeof(float);
       allow_lds(cin_qtail_scale_kernel, sh);
       const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + the head's partial sums (as in the fused tail's first launch)
-      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc + nh), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xs, qt_dcpart, (int)M, F, qt_ndc, small,
-                         ddense_w, ddense_b, (int)LK, nblk);
+      // ... and the first layer's dZ weights in slot order (the packed-W buffer is idle until that layer's dZ kernel)
+      FIL_CHECK_ARG(W[0]);
+      const int JTs0 = cin_jt_sym(F);
+      const int tiles0 = cdiv(F, cin_dz_h_per_period(JTs0)) * cin_dz_tiles_per_period(JTs0) + 1;
+      const int np = (int)std::min<long>(((long)tiles0 * 32 * HS0 + 255) / 256, 1024);
+      hipLaunchKernelGGL(cin_qtail_scale_kernel, dim3(qt_ndc + nh + np), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xs, qt_dcpart, (int)M, F, qt_ndc, small,
+                         ddense_w, ddense_b, (int)LK, nblk, nh, W[0], Wz, H[0], JTs0, HS0, tiles0);
+      wz_prepacked = true;
     }
     FIL_CHECK_LAUNCH();
     ready(L);
@@ -756,7 +762,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       // pooled-weights shortcut of layer p: G^{p-1} = dP_p S + dP_{p-1} (+ dP_L R), dX = dP_p x1 wsum_p
       ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
       // (wsum_p and its operand copy were saved by the forward; + dP_L R on the way out: the pool_L part of G^{p-1})
-      cin_launch_last_bwd2(st, JT, xT, xpT, xps, qtWsumP, qtWsnP, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL);
+      // (... and the partial column sums of G^{p-1} for dbias_{p-1}: `small` is free again, the head's partials were reduced above)
+      cin_launch_last_bwd2(st, JT, xT, xpT, xps, qtWsumP, qtWsnP, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL, small);
     }
     FIL_CHECK_LAUNCH();
     const int symD = F / 2 + 1, Cl = F * symD;
@@ -920,7 +927,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     // dbias
     {
       ProfScope ps("cin_dbias", st, (double)M * Hl * sizeof(float));
-      hipLaunchKernelGGL(cin_colsum3_kernel, dim3(ncol), dim3(256), 0, st, G, HSl, small, (int)M, Hl, kColRows);
+      // (quadratic tail: the kernel that wrote G left its per-128-row column sums in `small` already)
+      if (!(qtail && l == ltop)) hipLaunchKernelGGL(cin_colsum3_kernel, dim3(ncol), dim3(256), 0, st, G, HSl, small, (int)M, Hl, kColRows);
       hipLaunchKernelGGL(cin_reduce_kernel, dim3(cdiv(Hl, 64)), dim3(256), 0, st, small, dbias[l], (long)Hl, ncol);
     }
     FIL_CHECK_LAUNCH();

@@ -60,19 +60,19 @@ void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float*
 template <int JT>
 static void last_bwd2(hipStream_t st, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn, const float* dP,
                       int ldp, const float* dPprev, float* GprevT, int HSp, float* dxT, int M, int F, int K, int Hp, const float* Radd, int HSr,
-                      const float* dPadd) {
+                      const float* dPadd, float* colpart) {
   const size_t sh = (size_t)Hp * F * sizeof(float);
   if (sh > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_last_bwd2_kernel<JT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   hipLaunchKernelGGL((cin_last_bwd2_kernel<JT>), dim3((M + 127) / 128), dim3(kCinThreads), sh, st, xT, xpT, xps, wsum, wsn, dP, ldp, dPprev,
-                     GprevT, HSp, dxT, M, F, K, Hp, Radd, HSr, dPadd);
+                     GprevT, HSp, dxT, M, F, K, Hp, Radd, HSr, dPadd, colpart);
 }
 
 void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn,
                           const float* dP, int ldp, const float* dPprev, float* GprevT, int HSp, float* dxT, int M, int F, int K, int Hp,
-                          const float* Radd, int HSr, const float* dPadd) {
+                          const float* Radd, int HSr, const float* dPadd, float* colpart) {
 #define FIL_LB(JTV) \
-  case JTV: last_bwd2<JTV>(st, xT, xpT, xps, wsum, wsn, dP, ldp, dPprev, GprevT, HSp, dxT, M, F, K, Hp, Radd, HSr, dPadd); break;
+  case JTV: last_bwd2<JTV>(st, xT, xpT, xps, wsum, wsn, dP, ldp, dPprev, GprevT, HSp, dxT, M, F, K, Hp, Radd, HSr, dPadd, colpart); break;
   switch (JT) { FIL_LB(4) FIL_LB(8) FIL_LB(12) FIL_LB(16) FIL_LB(20) FIL_LB(24) FIL_LB(28) FIL_LB(32) }
 #undef FIL_LB
 }

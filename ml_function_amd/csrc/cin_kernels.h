@@ -1786,15 +1786,18 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
                                                             const float* __restrict__ dP, int ldp, const float* __restrict__ dPprev,
                                                             float* __restrict__ GprevT, int HSp, float* __restrict__ dxT, int M, int F,
                                                             int K, int Hp, const float* __restrict__ Radd = nullptr, int HSr = 0,
-                                                            const float* __restrict__ dPadd = nullptr) {
+                                                            const float* __restrict__ dPadd = nullptr, float* __restrict__ colpart = nullptr) {
   // Radd != nullptr (quadratic tail): G^{L-1}[m,n] += dPadd[m] * Radd[m,n] on the way out (one pass over G less)
+  // colpart != nullptr: colpart[blockIdx][n < Hp] = sum over this workgroup's 128 rows of the G^{L-1} it writes (the partial
+  // column sums of the next layer's dbias: cin_colsum3_kernel's output without its pass over G)
+  __shared__ float colred[4][128];
   extern __shared__ __attribute__((aligned(16))) float smem[];  // wsum [Hp][F]
   for (int i = threadIdx.x; i < Hp * F; i += 256) smem[i] = wsum[i];
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int wrow0 = (blockIdx.x * 4 + wave) * 32;
-  if (wrow0 >= M) return;
+  if (wrow0 >= M && colpart == nullptr) return;   // (with column sums every wave stays for the workgroup barriers; its rows are masked)
   const long mq = min(wrow0 + r, M - 1);
   float xr[JT];
 #pragma unroll
@@ -1838,6 +1841,7 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
       }
     }
     const int n0 = chunk * 128 + 4 * r;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int m = wrow0 + mfma32_row(reg, half);
@@ -1852,6 +1856,10 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
           v2 = fmaf(dpa[reg], ra.z, v2);
           v3 = fmaf(dpa[reg], ra.w, v3);
         }
+        c0 += v0;
+        c1 += v1;
+        c2 += v2;
+        c3 += v3;
         if (n0 + 3 < Hp) {
           *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
         } else {
@@ -1861,7 +1869,19 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
         }
       }
     }
+    if (colpart != nullptr) {   // rows in register order, the two wave halves, then the four waves: a fixed order
+      c0 = lane_halves_sum(c0);
+      c1 = lane_halves_sum(c1);
+      c2 = lane_halves_sum(c2);
+      c3 = lane_halves_sum(c3);
+      if (half == 0) *reinterpret_cast<float4*>(&colred[wave][4 * r]) = make_float4(c0, c1, c2, c3);
+      __syncthreads();
+      for (int n = tid; n < 128; n += 256)
+        if (chunk * 128 + n < Hp) colpart[(long)blockIdx.x * Hp + chunk * 128 + n] = (colred[0][n] + colred[1][n]) + (colred[2][n] + colred[3][n]);
+      __syncthreads();
+    }
   }
+  if (wrow0 >= M) return;
   // u = x^{L-1} wsum: two column blocks of fields (f = r, f = 32 + r)
   f32x16 u0, u1;
 #pragma unroll

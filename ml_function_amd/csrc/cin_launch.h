@@ -38,7 +38,7 @@ void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const 
 // MFMA data gradients of the last layer in mode 0 (L >= 2): see cin_last_bwd2_kernel
 void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn,
                           const float* dP, int ldp, const float* dPprev, float* GprevT, int HSp, float* dxT, int M, int F, int K, int Hp,
-                          const float* Radd = nullptr, int HSr = 0, const float* dPadd = nullptr);
+                          const float* Radd = nullptr, int HSr = 0, const float* dPadd = nullptr, float* colpart = nullptr);
 
 // symmetric first layer (x^{l-1} = x); FR = field rows of the LDS scratch (see cin_dz_sym_rows)
 void cin_launch_dz3_sym(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,

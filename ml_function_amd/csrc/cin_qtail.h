@@ -231,8 +231,13 @@ static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float
                                                                      const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xs,
                                                                      float* __restrict__ dcpart, int M, int F, int nscale,
                                                                      const float* __restrict__ hpart, float* __restrict__ ddw, float* __restrict__ ddb,
-                                                                     int LK, int nhp) {
+                                                                     int LK, int nhp, int nhead, const float* __restrict__ W0, float* __restrict__ Wz,
+                                                                     int H0, int JTs, int HS0, int tiles0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= nscale + nhead) {   // the first layer's weights in the dZ kernel's slot order (nothing else uses that buffer here)
+    cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, blockIdx.x - nscale - nhead, gridDim.x - nscale - nhead);
+    return;
+  }
   if ((int)blockIdx.x >= nscale) {   // the dense head's partial sums -> ddense_w | ddense_b (fixed order)
     cin_reduce_body(hpart, ddw, (long)LK + 1, nhp, ddb, (long)LK, blockIdx.x - nscale);
     return;
