@@ -85,8 +85,10 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *   dense_w [L*K], dense_b [1] (ignored when output_dim != 1).
  *   fwd outputs: out [B] (output_dim==1; may be NULL otherwise), pooled [B, L*K] (always written),
  *                saved = opaque buffer of fil_cin_saved_bytes bytes that bwd needs (internally: x transposed to
- *                [B*K][F] and the feature maps x^1..x^{L-1} as [B*K][128*ceil(H_l/128)]; the last layer's map is
- *                never materialised).
+ *                [B*K][F], the feature maps of the layers BELOW the top two as [B*K][128*ceil(H_l/128)], and what the
+ *                mode's form of the top two layers keeps: their maps, or the fused tail's [B*K][F+1 columns] and operand
+ *                copies, or the quadratic tail's R [B*K][128], T and packed operands; the last layer's map is never
+ *                materialised).  Forward and backward must be called with the same shape and mode bits.
  *   bwd: g = dL/dout [B] (output_dim==1) or dL/dpooled [B,L*K];
  *        writes dx [B,F,K], dW[l], dbias[l], ddense_w [L*K], ddense_b [1] (dense grads only if output_dim==1).
  *   mode: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact fp32 products) with the last layer contracted against

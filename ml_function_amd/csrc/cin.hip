@@ -290,7 +290,7 @@ static size_t fwd_ws_bytes(const CinShape& s) {
   for (int l = 0; l < s.L; ++l) t += align_up((size_t)pool_chunks(s, l) * s.M() * sizeof(float), 256);   // pool partials
   t += align_up((size_t)s.Hp(s.L - 1) * s.F * sizeof(float), 256);                                       // wsum of the last layer
   t += align_up(wf_floats(s) * sizeof(float), 256);                                                      // packed W
-  t += align_up((size_t)kCinMaxH * 64 * sizeof(float), 256) + align_up((size_t)kCinMaxH * sizeof(float), 256);   // quadratic tail: wsum_p, zero bias
+  t += align_up((size_t)kCinMaxH * sizeof(float), 256);                                                  // quadratic tail: zero bias of the R GEMM
   return t;
 }
 // floats of the dW partial-sum buffer: the largest splits * C * H over the layers (both first-layer forms, so the
@@ -407,7 +407,6 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   }
   float* wsum = ws.take<float>((size_t)s.Hp(L - 1) * F);
   float* Wf = ws.take<float>(wf_floats(s));
-  float* qt_wsum_p = ws.take<float>((size_t)kCinMaxH * 64);
   float* qt_zbias = ws.take<float>((size_t)kCinMaxH);
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
