@@ -816,8 +816,11 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
   const int pq_ = (periods + KS - 1) / KS;
   const int per_lo = KS == 1 ? 0 : min(periods, kpart * pq_);
   const int per_hi = KS == 1 ? periods : (wrow0 < M ? min(periods, per_lo + pq_) : per_lo);
-  float* xs = SYM ? smem + wave * 32 + r : smem + tid;                                    // xs[(mb*JT + j)*256]   | SYM: xs[(mb*FR + f)*kSymStride]
-  float* dxs = SYM ? xs + MB * FR * kSymStride : smem + MB * JT * 256 + tid;              // dxs[(mb*JT + j)*256]  | SYM: same shape as xs
+  // SYM: x entry and dX accumulator of a field sit side by side, [mb][f][x | dX][kSymStride]: one run-time row address per slot, the
+  // rest are compile-time offsets of the LDS instructions
+  constexpr int kSymRow = 2 * kSymStride;
+  float* xs = SYM ? smem + wave * 32 + r : smem + tid;                                    // xs[(mb*JT + j)*256]   | SYM: xs[(mb*FR + f)*kSymRow]
+  float* dxs = SYM ? xs + kSymStride : smem + MB * JT * 256 + tid;                        // dxs[(mb*JT + j)*256]  | SYM: xs + kSymStride
   constexpr bool GLINE = !SYM;                                                             // (the first layer has no G^{l-1})
   float* gl = smem + 2 * MB * JT * 256 + wave * (MB * 32 * kGlStride);                     // GLINE: [mb][row 32][kGlStride]
   long mq[MB];
@@ -840,8 +843,8 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
           const int f = f0 + 2 * u;
           if (f < FR) {
             const int keep = (vq[mb] && f < F) ? -1 : 0;
-            xs[(mb * FR + f) * kSymStride] = __builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep);
-            dxs[(mb * FR + f) * kSymStride] = 0.f;
+            xs[(mb * FR + f) * kSymRow] = __builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep);
+            dxs[(mb * FR + f) * kSymRow] = 0.f;
           }
         }
       }
@@ -937,19 +940,27 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
   // Within a group the apply (write) precedes the next fetch (read), so slots that alias one word stay ordered.
   float lx[MB], ldx[MB];
   int lfo = 0;
+  // SYM: row index (in floats) of field hb + half, per period: the slot's field is that row + (hl + 2j) rows, minus F rows past the
+  // wrap -- a compare against a scalar, a select between the two precomputed bases, and a compile-time LDS offset per slot (the
+  // form with the field computed per slot cost ~9 vector instructions and a 32-bit multiply each).  The fake tile before the first
+  // one (hb < 0, dZ = 0) is clamped to h = 0.
+  int symb = 0, symw = 0, symh = 0;
+  auto sym_period = [&](int hb) {
+    symh = max(hb, 0) + half;
+    symb = symh * kSymRow;
+    symw = symb - F * kSymRow;
+  };
   auto slot_fetch = [&](int hb, int tp, int rr) {
     const int sp = 16 * tp + rr;
     const int hl = sp / JT, j = sp % JT;  // compile-time after unrolling
     if constexpr (SYM) {
-      // f = (h + 2j + half) mod F; h + 2j + half < F + FR by the choice of FR; the fake tile before the first
-      // one (hb < 0, dZ = 0) is clamped to field 0
-      int t = hb + (hl + 2 * j) + half;
-      t -= t >= F ? F : 0;
-      lfo = max(t, 0) * kSymStride;
+      // f = (h + 2j + half) mod F; h + 2j + half < F + FR by the choice of FR
+      (void)hb;
+      lfo = (symh >= F - (hl + 2 * j) ? symw : symb) + (hl + 2 * j) * kSymRow;
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int xi = SYM ? mb * FR * kSymStride + lfo : (mb * JT + j) * 256;
+      const int xi = SYM ? mb * FR * kSymRow + lfo : (mb * JT + j) * 256;
       lx[mb] = xs[xi];
       ldx[mb] = dxs[xi];
     }
@@ -960,7 +971,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const float dz = d[mb][rr];
-      const int xi = SYM ? mb * FR * kSymStride + lfo : (mb * JT + j) * 256;
+      const int xi = SYM ? mb * FR * kSymRow + lfo : (mb * JT + j) * 256;
       gx[mb] = fmaf(dz, lx[mb], gx[mb]);
       dxs[xi] = fmaf(dz, xpv[mb][hl], ldx[mb]);
       if (j == JT - 1) {
@@ -1010,6 +1021,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
         }
       }
   };
+  sym_period(hprev);
   slot_fetch(hprev, P - 1, 0);
 
 #pragma unroll 1
@@ -1054,6 +1066,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
               if (tp == 0) slot_fetch(hprev, P - 1, sl + 1);
               else slot_fetch(hbase, tp - 1, sl + 1);
             } else {
+              if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
               slot_fetch(hbase, tp, 0);
             }
           }
@@ -1079,6 +1092,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
             if (tp == 0) slot_fetch(hprev, P - 1, s4 + 1);
             else slot_fetch(hbase, tp - 1, s4 + 1);
           } else {
+            if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
             slot_fetch(hbase, tp, 0);  // first slot of this tile, applied in the first group of the next one
           }
         }
@@ -1116,7 +1130,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
   } else {
     __builtin_amdgcn_wave_barrier();
   }
-  const float* dsc = smem + (SYM ? MB * FR * kSymStride + wave * 32 : MB * JT * 256 + wave * 64);
+  const float* dsc = smem + (SYM ? kSymStride + wave * 32 : MB * JT * 256 + wave * 64);
 #pragma unroll 1
   for (int mb = 0; mb < MB; ++mb) {
     const int row0 = wrow0 + mb * 32;
@@ -1124,10 +1138,10 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
     float* dst = dxT + (long)row0 * F;
     for (int idx = lane; idx < nrow * F; idx += 64) {
       const int rr = idx / F, f = idx - rr * F;
-      float v = SYM ? dsc[(mb * FR + f) * kSymStride + rr] : dsc[(mb * JT + (f >> 1)) * 256 + (f & 1) * 32 + rr];
+      float v = SYM ? dsc[(mb * FR + f) * kSymRow + rr] : dsc[(mb * JT + (f >> 1)) * 256 + (f & 1) * 32 + rr];
       if constexpr (KS > 1) {   // (SYM only) the group's partial sums, in wave order
 #pragma unroll
-        for (int k = 1; k < KS; ++k) v += dsc[(mb * FR + f) * kSymStride + rr + 32 * k];
+        for (int k = 1; k < KS; ++k) v += dsc[(mb * FR + f) * kSymRow + rr + 32 * k];
       }
       dst[idx] = accumulate ? dst[idx] + v : v;
     }
