@@ -80,6 +80,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise FilError("libfil_hip.so not found at %s -- build it with `python -m ml_function_amd.build` "
                        "(there is no CPU fallback)" % LIB_PATH)
+    # torch first: it ships its own libamdhip64, and the process must end up with ONE HIP runtime -- loaded the other way round
+    # (this library pulling in /opt/rocm's copy before torch brings its own) every launch fails with "no ROCm-capable device"
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     missing = [name for name in SIGNATURES if not hasattr(lib, name)]
     if missing:
