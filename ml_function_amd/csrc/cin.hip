@@ -476,7 +476,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       {
         ProfScope ps("cin_tail_prep", st);
         // (wsum_L, wsum_p and its MFMA operand copy came out of the preparation launch)
-        const size_t sh = ((size_t)F * (Hq + 1) + (size_t)Hq * F) * sizeof(float);
+        const size_t sh = std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq) * sizeof(float);
         allow_lds(cin_qtail_t_kernel, sh);
         hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
         // T in the forward kernel's operand layout (workspace) and in the dZ kernel's slot order (saved for the backward): one launch
@@ -778,7 +778,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     {
       ProfScope ps("cin_tail_params", st);
-      const size_t sh = ((size_t)F * (Hq + 1) + (size_t)F * (F + 1)) * sizeof(float);
+      const size_t ldf = (((size_t)F + 3) & ~(size_t)3) + 4;
+      const size_t sh = (F * ldf + std::max((size_t)Hq * ldf, (size_t)F * (Hq + 1))) * sizeof(float);
       allow_lds(cin_qtail_params_kernel, sh);
       float* dcfin = qt_dcpart + (size_t)qt_ndc * kQtConst;
       hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq, qt_dcpart, qt_ndc,

@@ -95,7 +95,6 @@ static __global__ __launch_bounds__(256) void cin_qtail_pack_kernel(const float*
 constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
 
 // T[(f'*F + f)*Hpp + h] for block h < Hpp; block Hpp writes cvec and a zero bias vector for the R GEMM.
-// LDS: wp [F][Hq+1] | wl [Hq][F]
 static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
                                                                  const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
                                                                  float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
@@ -126,23 +125,43 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
     for (int i = threadIdx.x; i < Hpp; i += 256) zbias[i] = 0.f;
     return;
   }
+  // LDS: wp [F][ldn] (W_p rows of this h) | wlT [F][ldn] (wsum_L transposed: [f][n]); ldn = Hq rounded up to 4, + 4: rows are
+  // 16-byte aligned and 4 banks apart, the dot products over n run on 16-byte LDS reads
+  const int ldn = ((Hq + 3) & ~3) + 4;
   float* wp = smem;
-  float* wl = smem + F * (Hq + 1);
-  qt_stage_rows(Wp + (long)h * F * Hq, wp, F, Hq, Hq + 1);
-  qt_stage(wsumL, wl, Hq * F);
+  float* wlT = smem + F * ldn;
+  for (int i = threadIdx.x; i < 2 * F * ldn; i += 256) smem[i] = 0.f;   // (padding columns must be zero)
+  __syncthreads();
+  qt_stage_rows(Wp + (long)h * F * Hq, wp, F, Hq, ldn);
+  for (int i0 = threadIdx.x; i0 < Hq * F; i0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < Hq * F ? wsumL[i0 + u * 256] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < Hq * F) {
+        const int n = i / F;
+        wlT[(i - n * F) * ldn + n] = v[u];
+      }
+    }
+  }
   __syncthreads();
   const int nhalf = (F * F + 1) / 2;
+  const int nq = (Hq + 3) >> 2;
   for (int idx = part * nhalf + threadIdx.x; idx < min(F * F, (part + 1) * nhalf); idx += 256) {
     const int fp = idx / F, f = idx - fp * F;
-    const float* a = wp + fp * (Hq + 1);
-    float t0 = 0.f, t1 = 0.f;
-    int n = 0;
-    for (; n + 1 < Hq; n += 2) {
-      t0 = fmaf(a[n], wl[n * F + f], t0);
-      t1 = fmaf(a[n + 1], wl[(n + 1) * F + f], t1);
+    const float4* a = reinterpret_cast<const float4*>(wp + fp * ldn);
+    const float4* b = reinterpret_cast<const float4*>(wlT + f * ldn);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int q = 0; q < nq; ++q) {
+      const float4 av = a[q], bv = b[q];
+      t0 = fmaf(av.x, bv.x, t0);
+      t1 = fmaf(av.y, bv.y, t1);
+      t2 = fmaf(av.z, bv.z, t2);
+      t3 = fmaf(av.w, bv.w, t3);
     }
-    if (n < Hq) t0 = fmaf(a[n], wl[n * F + f], t0);
-    T[(long)idx * Hpp + h] = t0 + t1;
+    T[(long)idx * Hpp + h] = (t0 + t1) + (t2 + t3);
   }
 }
 
@@ -280,7 +299,6 @@ static __global__ __launch_bounds__(256) void cin_qtail_scale_kernel(const float
 // Two workgroups per h < Hpp (phase = blockIdx & 1):
 //   phase 0:  dW_p[(h,f'),n] = v[(h,f')] + sum_f dT[(f',f),h] wsum_L[(n,f)]       (v: the pooled-weights shortcut's rank-one part,
 //   phase 1:  partL[h][(n,f)] = sum_f' W_p[(h,f'),n] dT[(f',f),h]                   given transposed, vT[f'][Hpp])
-// LDS: dt [F][F+1] | wl [Hq][F] (phase 0)  or  wp [F][Hq+1] (phase 1)
 static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
                                                                       const float* __restrict__ dT, const float* __restrict__ vT,
                                                                       float* __restrict__ dWp, float* __restrict__ partL, int Hpp, int F, int Hq,
@@ -307,8 +325,14 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
     return;
   }
   const int h = blockIdx.x >> 1, phase = blockIdx.x & 1;
+  // LDS: dt [F][ldf] | phase 0: wl [Hq][ldf] -- phase 1: wp [F][Hq+1];  ldf = F rounded up to 4, + 4: 16-byte rows, zero padded
+  const int ldf = ((F + 3) & ~3) + 4, nq = (F + 3) >> 2;   // (+4: eight consecutive rows start in eight different bank quads)
   float* dt = smem;
-  float* op = dt + F * (F + 1);
+  float* op = dt + F * ldf;
+  for (int i = threadIdx.x; i < F * ldf; i += 256) dt[i] = 0.f;
+  if (phase == 0)
+    for (int i = threadIdx.x; i < Hq * ldf; i += 256) op[i] = 0.f;
+  __syncthreads();
   for (int i0 = threadIdx.x; i0 < F * F; i0 += 8 * 256) {   // (a column of dT: one dword per 512-byte row, all in flight together)
     float v[8];
 #pragma unroll
@@ -318,40 +342,48 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
       const int i = i0 + u * 256;
       if (i < F * F) {
         const int fp = i / F;
-        dt[fp * (F + 1) + (i - fp * F)] = v[u];
+        dt[fp * ldf + (i - fp * F)] = v[u];
       }
     }
   }
   if (phase == 0) {
-    qt_stage(wsumL, op, Hq * F);
+    qt_stage_rows(wsumL, op, Hq, F, ldf);
     __syncthreads();
     for (int idx = threadIdx.x; idx < F * Hq; idx += 256) {
       const int fp = idx / Hq, n = idx - fp * Hq;
-      const float* d = dt + fp * (F + 1);
-      const float* w = op + n * F;
-      float t0 = 0.f, t1 = 0.f;
-      int f = 0;
-      for (; f + 1 < F; f += 2) {
-        t0 = fmaf(d[f], w[f], t0);
-        t1 = fmaf(d[f + 1], w[f + 1], t1);
+      const float4* d = reinterpret_cast<const float4*>(dt + fp * ldf);
+      const float4* w = reinterpret_cast<const float4*>(op + n * ldf);
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      for (int q = 0; q < nq; ++q) {
+        const float4 dv = d[q], wv = w[q];
+        t0 = fmaf(dv.x, wv.x, t0);
+        t1 = fmaf(dv.y, wv.y, t1);
+        t2 = fmaf(dv.z, wv.z, t2);
+        t3 = fmaf(dv.w, wv.w, t3);
       }
-      if (f < F) t0 = fmaf(d[f], w[f], t0);
-      dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + (t0 + t1);
+      dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + ((t0 + t1) + (t2 + t3));
     }
   } else {
     qt_stage_rows(Wp + (long)h * F * Hq, op, F, Hq, Hq + 1);
     __syncthreads();
     float* pl = partL + (long)h * Hq * F;
-    for (int idx = threadIdx.x; idx < Hq * F; idx += 256) {
-      const int n = idx / F, f = idx - n * F;
-      float t0 = 0.f, t1 = 0.f;
-      int fp = 0;
-      for (; fp + 1 < F; fp += 2) {
-        t0 = fmaf(op[fp * (Hq + 1) + n], dt[fp * (F + 1) + f], t0);
-        t1 = fmaf(op[(fp + 1) * (Hq + 1) + n], dt[(fp + 1) * (F + 1) + f], t1);
+    // thread (n, quad of f): four outputs from one scalar of W_p and one 16-byte read of dT per f'
+    for (int idx = threadIdx.x; idx < Hq * nq; idx += 256) {
+      const int n = idx / nq, f0 = 4 * (idx - n * nq);
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      for (int fp = 0; fp < F; ++fp) {
+        const float wv = op[fp * (Hq + 1) + n];
+        const float4 dv = *reinterpret_cast<const float4*>(dt + fp * ldf + f0);
+        t0 = fmaf(wv, dv.x, t0);
+        t1 = fmaf(wv, dv.y, t1);
+        t2 = fmaf(wv, dv.z, t2);
+        t3 = fmaf(wv, dv.w, t3);
       }
-      if (fp < F) t0 = fmaf(op[fp * (Hq + 1) + n], dt[fp * (F + 1) + f], t0);
-      pl[idx] = t0 + t1;
+      float* o = pl + n * F + f0;
+      o[0] = t0;
+      if (f0 + 1 < F) o[1] = t1;
+      if (f0 + 2 < F) o[2] = t2;
+      if (f0 + 3 < F) o[3] = t3;
     }
   }
 }
