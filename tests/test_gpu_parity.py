@@ -392,8 +392,8 @@ def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
         check("tail ddense_b", db.grad, ddb)
 
 
-@pytest.mark.parametrize("B", [128, 512, 1024])
-@pytest.mark.parametrize("mode", [0, 128])
+# (2048: M = 32,768 rows -- above the quadratic tail's size rule, below the 64-row-wave threshold: its kernels at 32 rows per wave)
+@pytest.mark.parametrize("mode,B", [(0, 128), (0, 512), (0, 1024), (0, 2048), (128, 128), (128, 512), (128, 1024)])
 def test_cin_small_batches_of_the_benchmark_shape(B, mode):
     """A strong-scaling shard of the benchmark (global B = 4096 over 8 / 32 GPUs: 512 / 128 samples, and 1024): mode 0 splits the
     reduction of every row-parallel kernel over the four waves of a workgroup (fil.h FIL_CIN_NOKSPLIT), mode 128
@@ -413,7 +413,7 @@ def test_cin_small_batches_of_the_benchmark_shape(B, mode):
         check("shard dW%d" % l, Ws[l].grad, dWs[l], tol=2e-5)
         check("shard db%d" % l, bs[l].grad, dbs[l], tol=2e-5)
     check("shard ddense_w", dw.grad, ddw, tol=2e-5)
-    if mode == 0:
+    if mode == 0 and B <= 1024:     # (the reduction split is used up to 16,384 rows)
         other = Fn.cin(dev(c["x"]), [dev(w) for w in c["Ws"]], [dev(b) for b in c["bs"]], dev(c["dense_w"]), dev(c["dense_b"]), mode=128)
         assert not torch.equal(out, other) and rel(out, other.detach().cpu().numpy()) < 1e-5      # other kernels ran, same function
 
