@@ -5,7 +5,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfil_hip.so")
+# FIL_LIB_PATH (development only): an alternative build of the SAME library -- kernel experiments built side by side by
+# tools/abl_build.py and timed against the default one in separate processes.  Unset = the in-tree default.
+LIB_PATH = os.environ.get("FIL_LIB_PATH") or os.path.join(_HERE, "libfil_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "fil.h")
 
 FIL_F32, FIL_BF16 = 0, 1

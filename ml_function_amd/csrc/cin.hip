@@ -291,6 +291,7 @@ static size_t fwd_ws_bytes(const CinShape& s) {
   t += align_up((size_t)s.Hp(s.L - 1) * s.F * sizeof(float), 256);                                       // wsum of the last layer
   t += align_up(wf_floats(s) * sizeof(float), 256);                                                      // packed W
   t += align_up((size_t)kCinMaxH * sizeof(float), 256);                                                  // quadratic tail: zero bias of the R GEMM
+  t += align_up(cin_x2_floats(s.M(), cin_x2_len(s.F)) * sizeof(float), 256);                             // wrapped rows of x (pair-symmetric forward)
   return t;
 }
 // floats of the dW partial-sum buffer: the largest splits * C * H over the layers (both first-layer forms, so the
@@ -408,6 +409,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   float* wsum = ws.take<float>((size_t)s.Hp(L - 1) * F);
   float* Wf = ws.take<float>(wf_floats(s));
   float* qt_zbias = ws.take<float>((size_t)kCinMaxH);
+  const int XL = cin_x2_len(F);
+  float* x2T = ws.take<float>(cin_x2_floats(M, XL));
+  const bool need_x2 = tune.sym && !split;   // the exact pair-symmetric forward kernel reads the wrapped rows
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
   const float* xT = xt_in ? x : xT_own;
@@ -443,24 +447,26 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
     const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
     const long npack = (long)chunks0 * F * 2 * JTs * 128;
-    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nwl = cdiv(tg.Hq * F, 8), nwp = cdiv(tg.Hpp * F, 8);
+    const int nt = B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nwl = cdiv(tg.Hq * F, 8), nwp = cdiv(tg.Hpp * F, 8);
     const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
     allow_lds(cin_qtail_prep_kernel, sh);
     hipLaunchKernelGGL(cin_qtail_prep_kernel, dim3(nt + npk + nwl + nwp), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0, npk,
-                       W[L - 1], qtWsumL, tg.Hq, tg.HL, nwl, W[L - 2], qtWsumP, qtWsnP, tg.Hpp, 2 * JT, chunks_of(tg.Hpp));
+                       W[L - 1], qtWsumL, tg.Hq, tg.HL, nwl, W[L - 2], qtWsumP, qtWsnP, tg.Hpp, 2 * JT, chunks_of(tg.Hpp), x2T, XL, xt_in ? 1 : 0);
   } else if (prep_fused) {
     FIL_CHECK_ARG(W[0] && W[L - 1]);
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
     const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
     const long npack = (long)chunks0 * F * 2 * JTs * 128;
-    const int nt = xt_in ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = cdiv(tg.Hq * F, 8), nz = 64;
+    const int nt = B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nws = cdiv(tg.Hq * F, 8), nz = 64;
     const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
     allow_lds(cin_fwd_prep_kernel, sh);
     hipLaunchKernelGGL(cin_fwd_prep_kernel, dim3(nt + npk + nws + nz), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0,
-                       npk, W[L - 1], tailBmT, tg.Hq, tg.HL, nws, reinterpret_cast<float4*>(tailUz), (long)((tg.uz_floats + tg.uf_floats) / 4));
-  } else if (!xt_in) {
+                       npk, W[L - 1], tailBmT, tg.Hq, tg.HL, nws, reinterpret_cast<float4*>(tailUz), (long)((tg.uz_floats + tg.uf_floats) / 4), x2T, XL,
+                       xt_in ? 1 : 0);
+  } else if (!xt_in || need_x2) {
     ProfScope ps("cin_transpose_in", st, 2.0 * M * F * sizeof(float));
-    hipLaunchKernelGGL(cin_transpose_in_kernel, dim3(B), dim3(256), (size_t)F * (K + 1) * sizeof(float), st, x, xT_own, F, K);
+    hipLaunchKernelGGL(cin_transpose_in_kernel, dim3(B), dim3(256), xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float), st, x, xT_own, F, K,
+                       need_x2 ? x2T : nullptr, XL, xt_in ? 1 : 0);
   }
   FIL_CHECK_LAUNCH();
   const float* xpT = xT;
@@ -491,7 +497,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         ProfScope ps("cin_fwd_tail", st, algo, gemm_flops(M, 1, F * (F / 2 + 1), Hpp));
         const int ks = tune.ksplit(M);
         // (the kernel's own sum-pool output is not used: it goes to the last layer's slot, which the pool kernel below overwrites)
-        cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, Wf, qt_zbias, qtR, HS0,
+        cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, x2T, XL, Wf, qt_zbias, qtR, HS0,
                             const_cast<float*>(pa.part[lL]), (int)M, F, Hpp, false, ks);
       }
       FIL_CHECK_LAUNCH();
@@ -576,7 +582,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         }
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));   // (executed: unordered pairs)
         const int ks = split ? 1 : tune.ksplit(M);
-        cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, Wf, bias[l], xoutT, s.HS(l), part,
+        cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, x2T, XL, Wf, bias[l], xoutT, s.HS(l), part,
                             (int)M, F, Hl, split, ks);
       } else {
         long npack = (long)chunks * Hp * 2 * JT * 128;

@@ -29,11 +29,12 @@ void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT,
 }
 
 template <int MB, int JT>
-static void fwd3s(hipStream_t st, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT, int HS, float* pool_part,
-                  int M, int F, int H, bool split, int ks) {
+static void fwd3s(hipStream_t st, dim3 grid, const float* xT, const float* x2T, int XL, const float* Wf, const float* bias, float* xoutT, int HS,
+                  float* pool_part, int M, int F, int H, bool split, int ks) {
+  // exact kernels: the wrapped rows x2T [M][XL] travel in the xpT / xps slots (x^{l-1} = x needs no operand of its own)
   if constexpr (MB == 1) {
     if (ks == 4 && !split) {
-      hipLaunchKernelGGL((cin_fwd3_kernel<1, JT, true, false, 4>), grid, dim3(kCinThreads), 0, st, xT, xT, F, Wf, bias, xoutT, HS, pool_part, M, F,
+      hipLaunchKernelGGL((cin_fwd3_kernel<1, JT, true, false, 4>), grid, dim3(kCinThreads), 0, st, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F,
                          F, H, nullptr, nullptr, 0, nullptr);
       return;
     }
@@ -42,16 +43,16 @@ static void fwd3s(hipStream_t st, dim3 grid, const float* xT, const float* Wf, c
     hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, true, true>), grid, dim3(kCinThreads), 0, st, xT, xT, F, Wf, bias, xoutT, HS, pool_part, M, F, F,
                        H, nullptr, nullptr, 0, nullptr);
   else
-    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, true>), grid, dim3(kCinThreads), 0, st, xT, xT, F, Wf, bias, xoutT, HS, pool_part, M, F, F, H,
+    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, true>), grid, dim3(kCinThreads), 0, st, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, F, H,
                        nullptr, nullptr, 0, nullptr);
 }
 
-void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT,
-                         int HS, float* pool_part, int M, int F, int H, bool split, int ks) {
+void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* x2T, int XL, const float* Wf, const float* bias,
+                         float* xoutT, int HS, float* pool_part, int M, int F, int H, bool split, int ks) {
 #define FIL_F3S(JTV)                                                                             \
   case JTV:                                                                                      \
-    if (MB == 2) fwd3s<2, JTV>(st, grid, xT, Wf, bias, xoutT, HS, pool_part, M, F, H, split, 1);  \
-    else fwd3s<1, JTV>(st, grid, xT, Wf, bias, xoutT, HS, pool_part, M, F, H, split, ks);         \
+    if (MB == 2) fwd3s<2, JTV>(st, grid, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, H, split, 1);  \
+    else fwd3s<1, JTV>(st, grid, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, H, split, ks);         \
     break;
   switch (JT) { FIL_F3S(2) FIL_F3S(4) FIL_F3S(6) FIL_F3S(8) FIL_F3S(10) FIL_F3S(12) FIL_F3S(14) FIL_F3S(16) FIL_F3S(18) }
 #undef FIL_F3S

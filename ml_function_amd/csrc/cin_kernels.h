@@ -34,6 +34,20 @@ __device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void settle(f32x4s& v) { asm volatile("" : "+v"(v)); }
 
+// Raw buffer descriptor over [p, p + bytes): loads take a constant per-lane 32-bit voffset plus a scalar soffset, and anything
+// past the end reads as zero through the range check -- no per-load 64-bit address arithmetic, no clamping.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)std::min<long>(bytes, 0x7fffffffL), 0x00020000);
+}
+// the same from values the compiler cannot prove wave-uniform (derived from threadIdx >> 6): pinned to scalar registers, otherwise
+// every load through the descriptor is wrapped in a waterfall loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const float* p, long bytes) {
+  const unsigned long a = reinterpret_cast<unsigned long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)std::min<long>(bytes, 0x7fffffffL));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long)hi << 32) | lo), 0, n, 0x00020000);
+}
+
 // #################################################################################################
 // v3 kernels: m-major internal layouts + LDS-free streaming GEMMs.
 //
@@ -49,16 +63,41 @@ __device__ __forceinline__ void settle(f32x4s& v) { asm volatile("" : "+v"(v)); 
 constexpr int kQDepthMax = 10;
 
 // x [B,F,K] -> xT [M][F]   (one workgroup per sample, transposed through LDS)
-__device__ __forceinline__ void cin_transpose_in_body(const float* __restrict__ x, float* __restrict__ xT, int F, int K, long b, float* smem) {
+// x2T != nullptr: also the wrapped rows of x, x2[m][p] = x[m][p mod F] for p < XL = F + 2*JTs, POSITION-major in blocks of 64 rows:
+//   x2T[((m >> 6) * XL + p) * 64 + (m & 63)]
+// The pair-symmetric forward kernel reads x[m, (h + d) mod F] as x2[m][h + d]: a per-lane constant offset plus a SCALAR offset h (no
+// per-load index arithmetic), and the 32 rows of a wave half are 128 contiguous bytes (read row-major, [M][F], every such load
+// touched 64 different lines: at 22 loads per h the vector memory pipeline, not the MFMA, set that kernel's pace -- 0.128 ms against
+// 0.098 with the loads removed).
+__device__ __forceinline__ long cin_x2_index(long m, int p, int XL) { return ((m >> 6) * XL + p) * 64 + (m & 63); }
+inline __host__ __device__ size_t cin_x2_floats(long M, int XL) { return (size_t)((M + 63) >> 6) * XL * 64; }
+__device__ __forceinline__ void cin_transpose_in_body(const float* __restrict__ x, float* __restrict__ xT, int F, int K, long b, float* smem,
+                                                      float* __restrict__ x2T = nullptr, int XL = 0) {
   const float* src = x + b * F * K;
   for (int i = threadIdx.x; i < F * K; i += 256) smem[(i / K) * (K + 1) + (i % K)] = src[i];
   __syncthreads();
   float* dst = xT + b * K * F;
   for (int i = threadIdx.x; i < F * K; i += 256) dst[i] = smem[(i % F) * (K + 1) + (i / F)];
+  if (x2T != nullptr) {
+    for (int i = threadIdx.x; i < XL * K; i += 256) {
+      const int p = i / K, k = i - p * K;
+      x2T[cin_x2_index(b * K + k, p, XL)] = smem[(p % F) * (K + 1) + k];
+    }
+  }
 }
-static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K) {
+// the same from an input that is already transposed (FIL_CIN_X_TRANSPOSED): the K rows of sample b
+__device__ __forceinline__ void cin_wrap_rows_body(const float* __restrict__ xT, float* __restrict__ x2T, int F, int K, long b, int XL) {
+  const float* src = xT + b * K * F;
+  for (int i = threadIdx.x; i < XL * K; i += 256) {
+    const int p = i / K, k = i - p * K;
+    x2T[cin_x2_index(b * K + k, p, XL)] = src[k * F + p % F];
+  }
+}
+static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K,
+                                                               float* __restrict__ x2T = nullptr, int XL = 0, int xt_in = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [F][K+1]
-  cin_transpose_in_body(x, xT, F, K, blockIdx.x, smem);
+  if (xt_in) cin_wrap_rows_body(x, x2T, F, K, blockIdx.x, XL);
+  else cin_transpose_in_body(x, xT, F, K, blockIdx.x, smem, x2T, XL);
 }
 
 // dx [B,F,K] = dxT [M][F] (+ addT [M][F])
@@ -306,13 +345,6 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
       }
     }
   }
-  if constexpr (SYM && !SPLIT) {
-    load_x(hs, xn);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int j = 0; j < JT; ++j) xr[mb][j] = xn[mb][j];
-  }
   f32x16 acc[MB][4];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -496,6 +528,90 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) xph[mb][u] = xpn[mb][u];
     }
+  } else if constexpr (SYM) {
+    // Exact pair-symmetric first layer.  Step (h, j) of lane half `half` multiplies x[m,h] by x[m,(h + 2j + half) mod F], read from the
+    // WRAPPED, position-major rows x2 (cin_transpose_in_body; xpT / xps carry x2T / XL here) as x2[m][h + 2j + half]: the lane part of
+    // the address is a constant, h a scalar offset and 2j an immediate -- raw buffer loads, no per-load index arithmetic, two lines per
+    // load instruction.  The W stream is linear in the step s = h*JT + j: one descriptor, scalar offsets.
+    // Two values of h per loop iteration: the fragment of h+1 lands in the registers h-1 released (no copies).
+    const int XL = xps;
+    const int wrow_u = __builtin_amdgcn_readfirstlane(wrow0);
+    // this wave's 64-row block of the wrapped rows ([p][64 rows]; a 32-row wave takes one half of it)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(xpT + (long)(wrow_u >> 6) * XL * 64, (long)XL * 256);
+    const int chunk_u = __builtin_amdgcn_readfirstlane(chunk);
+    const long wbytes = (long)Hp * (2 * JT) * 128 * 4;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc_uniform(Wf + (long)chunk_u * (wbytes >> 2), wbytes);     // steps past the end read zeros
+    const int wo = (half * 32 + r) * 16;
+    int vrow[MB], vhalf[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      vrow[mb] = ((wrow_u & 63) + mb * 32 + r) * 4;
+      vhalf[mb] = vrow[mb] + half * 256;
+    }
+    auto ldw = [&](int s) {   // B operands of step s (uniform)
+      return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo, s * 1024, 0));
+    };
+    auto ldfrag = [&](int h, float (&xf)[MB][JT], float (&xp)[MB]) {
+      const int hb = __builtin_amdgcn_readfirstlane(h) * 256;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        xp[mb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vrow[mb], hb, 0));
+#pragma unroll
+        for (int j = 0; j < JT; ++j) xf[mb][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vhalf[mb] + 512 * j, hb, 0));
+      }
+    };
+    f32x4s q[DEPTH];
+    const int s_lo = hs * JT;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) q[d] = ldw(s_lo + d);
+    float xa[MB][JT], xb[MB][JT], pa[MB], pb[MB];
+    ldfrag(hs, xa, pa);
+#ifdef FIL_ABL_NOXLOAD
+    ldfrag(hs, xb, pb);
+#endif
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) settle(q[d]);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) settle(pa[mb]);
+    float ac[MB], an[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) ac[mb] = pa[mb] * xa[mb][0];
+    // one value of h: fragment (xc, pc) in use, (xn_, pn) being fetched for h + 1
+    auto run_h = [&](int h, float (&xc)[MB][JT], float (&pc)[MB], float (&xn_)[MB][JT], float (&pn)[MB]) {
+#ifndef FIL_ABL_NOXLOAD
+      ldfrag(min(h + 1, Hp - 1), xn_, pn);
+#endif
+      const int sb = h * JT;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const f32x4s w = q[j % DEPTH];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) an[mb] = j + 1 < JT ? pc[mb] * xc[mb][j + 1 < JT ? j + 1 : 0] : pn[mb] * xn_[mb][0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float a = ac[mb];
+          acc[mb][0] = mfma32(a, w[0], acc[mb][0]);
+          acc[mb][1] = mfma32(a, w[1], acc[mb][1]);
+          acc[mb][2] = mfma32(a, w[2], acc[mb][2]);
+          acc[mb][3] = mfma32(a, w[3], acc[mb][3]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) ac[mb] = an[mb];
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef FIL_ABL_NOWLOAD
+        q[j % DEPTH] = ldw(sb + j + DEPTH);   // (after the step's MFMAs: it may land in the registers it replaces)
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    int h = h_lo;
+#pragma unroll 1
+    for (; h + 1 < h_hi; h += 2) {
+      run_h(h, xa, pa, xb, pb);
+      run_h(h + 1, xb, pb, xa, pa);
+    }
+    if (h < h_hi) run_h(h, xa, pa, xb, pb);
   } else {
   const float4* wbase = reinterpret_cast<const float4*>(Wf + (long)chunk * Hp * (2 * JT) * 128) + (half * 32 + r);
     float4 q[DEPTH];
@@ -1161,9 +1277,6 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // voffset, the per-step part a scalar soffset, and rows past the end of a tensor read as zero through the
 // descriptor's range check -- no per-load 64-bit address arithmetic, no clamping (plain global loads with per-step
 // 64-bit address math measured 105 TFLOP/s on this kernel, this form 124).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)std::min<long>(bytes, 0x7fffffffL), 0x00020000);
-}
 
 template <int MB, bool XONES, int DEPTH = kDwDepth>
 __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ xT,

@@ -12,8 +12,10 @@ inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
 
 // ks = 4: four waves share a block of 32 rows and split the reduction over h (small M; exact kernels, MB = 1 only; the grid must
 // then be cdiv(M, 32) workgroups in x)
-void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* Wf, const float* bias, float* xoutT,
-                         int HS, float* pool_part, int M, int F, int H, bool split = false, int ks = 1);
+// x2T [M][XL]: the wrapped rows of x (cin_transpose_in_body), XL = cin_x2_len(F); read by the exact kernels only (split: may be NULL)
+inline int cin_x2_len(int F) { return F + 2 * cin_jt_sym(F); }
+void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* x2T, int XL, const float* Wf, const float* bias,
+                         float* xoutT, int HS, float* pool_part, int M, int F, int H, bool split = false, int ks = 1);
 
 // split-bf16 form of the symmetric first layer: h per super-period, and floats of its packed weight planes
 inline int cin_sym_hps(int JTs) { return JTs % 4 == 0 ? 4 : 8; }

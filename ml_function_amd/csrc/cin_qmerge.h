@@ -1,0 +1,521 @@
+// Quadratic tail of a three-layer CIN, merged form (round 4): ONE data-gradient GEMM and ONE weight-gradient GEMM for the first layer
+// and the quadratic form together, instead of two launches each (cin_qtail.h explains the algebra; reference interactive_layer.py:310-327).
+//
+// With P[m,c] = x[m,h_c] x[m,f_c] over the unordered field pairs c (cin_pack_wf_sym_kernel's pair weights W1s, Ts):
+//   x1 = P W1s + b1,  R = P Ts,  pool_L = <x1, R> + ...                                   (forward: cin_fwd3_kernel, twice)
+//   dP  = G1 W1s^T + (dP_L x1) Ts^T      = [G1 | dP_L x1] [W1s ; Ts]^T                     -> cin_dzq_kernel: reduction length 256
+//   [dW1s | dTs] = P^T [G1 | dP_L x1]                                                       -> cin_dwq_kernel: 256 output columns
+// The f32 MFMA shares the vector ALU on gfx950, so every vector instruction beside the MFMAs is matrix time: the data-gradient kernel's
+// contraction of a dZ tile into dX (two FMAs, an LDS read and an LDS write per element) and the weight-gradient kernel's generated
+// operand (two gathers and a multiply per step) are paid once per 256 columns here instead of once per 128.
+#pragma once
+#include "cin_kernels.h"
+#include "cin_launch.h"
+#include "cin_qtail.h"
+
+namespace fil {
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Data gradients.  Wave = 32*MB rows m (on the lanes), ONE wave per SIMD (the lane's two half rows of [G1 | dP_L x1] take
+// MB * 2 * 64 registers).  dZ^T tile = 32 slot rows (A operand: the slot-ordered pair weights, streamed through a 16-deep register
+// queue by scalar-offset buffer loads) x 32 rows m (B operand: the lane's half row), reduced over KH * 128 columns.
+// Slot (h, j) of lane half `half` is the unordered pair (h, f = (h + 2j + half) mod F) (cin_pack_wz_sym_kernel); accumulator
+// register rr of tile t is slot 16 t + rr, so with a compile-time JT the (tile, register) -> (h, j) pattern repeats every P tiles:
+//   dX[m,f] += dZ x[m,h]          LDS read-modify-write on the field's row
+//   gx      += dZ x[m,f]          -> dX[m,h] += gx when the h is complete (both lane halves, one LDS add)
+// x entry and dX accumulator of a field sit side by side in LDS, [f][mb][row 128][x | dX]: one 8-byte read per slot, a compare and a
+// select for the wrap of f, everything else compile-time offsets.  The 16 slots of tile t are contracted while the MFMA chain of tile
+// t+1 runs, their LDS operands fetched one step group earlier.
+constexpr int kDzqFieldStride = 128 * 2;   // floats per (field, mb): 128 rows x (x, dX)
+
+// Wzq[(t*KH + kh)][32 slot rows][128 columns]: the pair weights of W1 (kh = 0) and T (kh = 1) in slot order
+__device__ __forceinline__ void cin_pack_wzq_body(const float* __restrict__ W1, const float* __restrict__ T, float* __restrict__ Wzq, int F, int H1,
+                                                  int H2, int JT, int KH, int tiles, int bid, int nblocks) {
+  const long total = (long)tiles * KH * 32 * 128;
+  for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblocks * 256) {
+    const int col = (int)(idx & 127);
+    const long row = idx >> 7;
+    const int i = (int)(row & 31);
+    const long st = row >> 5;
+    const int kh = (int)(st % KH);
+    const long t = st / KH;
+    const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
+    const long slot = 16 * t + rr;
+    const int h = (int)(slot / JT), j = (int)(slot - (long)h * JT);
+    const int d = 2 * j + hf;
+    const float* W = kh == 0 ? W1 : T;
+    const int H = kh == 0 ? H1 : H2;
+    float v = 0.f;
+    if (h < F && d <= F / 2 && col < H) {
+      const int f = (h + d) % F;
+      if (d == 0) v = W[((long)h * F + h) * H + col];
+      else {
+        v = W[((long)h * F + f) * H + col] + W[((long)f * F + h) * H + col];
+        if (2 * d == F) v *= 0.5f;
+      }
+    }
+    Wzq[idx] = v;
+  }
+}
+
+template <int MB, int JT, int KH>
+__global__ __launch_bounds__(256, 1) void cin_dzq_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
+                                                         const float* __restrict__ dsc, int ldp, int K, const float* __restrict__ Wzq,
+                                                         const float* __restrict__ xT, float* __restrict__ dxT, int accumulate, int M, int F,
+                                                         int H1, int H2, int periods, int FR) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [FR][MB][128 rows][2]
+  constexpr int P = JT / gcd_c(16, JT);
+  constexpr int HPP = 16 * P / JT;
+  constexpr int NQ = 16;                               // float4 per sub-tile and lane (64 columns per wave half)
+  constexpr int FS = MB * kDzqFieldStride;             // floats per field
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
+  if (wrow0 >= M) return;   // (no workgroup barriers in this kernel)
+  float* lrow = smem + (wave * 32 + r) * 2;            // this lane's row: field f, block mb at lrow[f*FS + mb*kDzqFieldStride + {0: x, 1: dX}]
+  long mq[MB];
+  bool vq[MB];
+  float greg[MB][KH * 64];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = wrow0 + mb * 32 + r;
+    vq[mb] = m < M;
+    mq[mb] = vq[mb] ? m : M - 1;
+    // x entries (zero past F and for rows past M) and zeroed dX accumulators: eight loads per batch, then the LDS writes
+    for (int f0 = half; f0 < FR; f0 += 16) {
+      float xt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xt[u] = xT[mq[mb] * F + min(f0 + 2 * u, F - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + 2 * u;
+        if (f < FR) {
+          const int keep = (vq[mb] && f < F) ? -1 : 0;
+          *reinterpret_cast<float2*>(lrow + f * FS + mb * kDzqFieldStride) = make_float2(__builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep), 0.f);
+        }
+      }
+    }
+  }
+  // the lane's half rows: 16-byte loads, all in flight together
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const float4* grow4 = reinterpret_cast<const float4*>((kh == 0 ? g1T : g2T) + mq[mb] * HS + half * 64);
+      const int Hk = kh == 0 ? H1 : H2;
+      float sc = 1.f;
+      if (kh == 1) {
+        const long bb = mq[mb] / K;
+        sc = dsc[bb * ldp + (mq[mb] - bb * K)];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) {
+        const float4 g4 = grow4[s4];
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int keep = (vq[mb] && half * 64 + 4 * s4 + e < Hk) ? -1 : 0;
+          const float v = __builtin_bit_cast(float, __builtin_bit_cast(int, gv[e]) & keep);
+          greg[mb][kh * 64 + 4 * s4 + e] = kh == 1 ? v * sc : v;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
+  // A operand stream: sub-tile st = tile*KH + kh is [32][128] floats; lane (r, half) reads row r, columns half*64 + 4*s4 .. +3
+  const long wbytes = ((long)periods * P + 1) * KH * 32 * 128 * 4;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wzq, wbytes);
+  const int wo = (r * 128 + half * 64) * 4;
+  auto ldw = [&](int st, int s4) {
+    return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo + 16 * s4, st * (32 * 128 * 4), 0));
+  };
+  f32x4s q[NQ];
+#pragma unroll
+  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = ldw(0, s4);
+  float gx[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) gx[mb] = 0.f;
+  f32x16 dprev[MB];
+  float xprev[MB][HPP], xcur[MB][HPP];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dprev[mb][i] = 0.f;
+#pragma unroll
+    for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl] = 0.f;
+  }
+  int hprev = 0;   // h base of the period the previous tile belongs to (the fake tile before the first one: dZ = 0, any valid rows)
+  // A slot is contracted in two halves one step group apart (read, then FMA + write a group later): the LDS latency stays off the MFMA
+  // chain.  Within a group the apply (write) precedes the next fetch (read), so slots that alias one word stay ordered.
+  float2 lv[MB];
+  float* la = lrow;
+  float *abase = lrow, *awrap = lrow;
+  int symh = 0;
+  auto sym_period = [&](int hb) {
+    symh = hb + half;
+    abase = lrow + symh * FS;
+    awrap = abase - F * FS;
+  };
+  auto slot_fetch = [&](int tp, int rr) {
+    const int sp = 16 * tp + rr;
+    const int off = sp / JT + 2 * (sp % JT);   // compile-time after unrolling: f = (h + off + half) mod F, h + off + half < F + FR
+    la = (symh >= F - off ? awrap : abase) + off * FS;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) lv[mb] = *reinterpret_cast<const float2*>(la + mb * kDzqFieldStride);
+  };
+  auto slot_apply = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
+    const int sp = 16 * tp + rr;
+    const int hl = sp / JT, j = sp % JT;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float dz = d[mb][rr];
+      gx[mb] = fmaf(dz, lv[mb].x, gx[mb]);
+      la[mb * kDzqFieldStride + 1] = fmaf(dz, xpv[mb][hl], lv[mb].y);
+      if (j == JT - 1) {
+        // h = hb + hl is complete: dX[m,h] += sum over both lane halves (one LDS add by the lower half; the row's own words only)
+        const float t = lane_halves_sum(gx[mb]);
+        gx[mb] = 0.f;
+        if (half == 0) {
+          float* dst = lrow + (hb + hl) * FS + mb * kDzqFieldStride + 1;
+          __hip_atomic_fetch_add(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  };
+  sym_period(hprev);
+  slot_fetch(P - 1, 0);
+#pragma unroll 1
+  for (int per = 0; per < periods; ++per) {
+    const int hbase = per * HPP;
+    // x[m, hbase + hl] from the LDS image (rows >= F hold zeros; FR >= periods * HPP)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xcur[mb][hl] = lrow[(hbase + hl) * FS + mb * kDzqFieldStride];
+#pragma unroll
+    for (int tp = 0; tp < P; ++tp) {
+      f32x16 d[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[mb][i] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        const int st = (per * P + tp) * KH + kh;
+#pragma unroll
+        for (int s4 = 0; s4 < NQ; ++s4) {
+          const f32x4s w = q[s4];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            d[mb] = mfma32(w[0], greg[mb][kh * 64 + 4 * s4 + 0], d[mb]);
+            d[mb] = mfma32(w[1], greg[mb][kh * 64 + 4 * s4 + 1], d[mb]);
+            d[mb] = mfma32(w[2], greg[mb][kh * 64 + 4 * s4 + 2], d[mb]);
+            d[mb] = mfma32(w[3], greg[mb][kh * 64 + 4 * s4 + 3], d[mb]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          q[s4] = ldw(st + 1, s4);   // (the stream is allocated one tile past the last period)
+          // previous tile's slots, spread evenly over this tile's KH * 16 step groups
+          if ((kh * NQ + s4) % KH == 0) {
+            const int sl = (kh * NQ + s4) / KH;
+            if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, sl);
+            else slot_apply(dprev, xcur, hbase, tp - 1, sl);
+            if (sl < 15) {
+              slot_fetch(tp == 0 ? P - 1 : tp - 1, sl + 1);
+            } else {
+              if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
+              slot_fetch(tp, 0);                // first slot of this tile, applied in the first group of the next one
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) dprev[mb] = d[mb];
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl];
+    hprev = hbase;
+  }
+  // the last tile's slots
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    slot_apply(dprev, xprev, hprev, P - 1, rr);
+    if (rr < 15) slot_fetch(P - 1, rr + 1);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // dX rows of the wave are contiguous in dxT ([32*MB rows][F]): written cooperatively from the LDS image, whole lines per store
+  const float* dsc_l = smem + wave * 32 * 2 + 1;
+#pragma unroll 1
+  for (int mb = 0; mb < MB; ++mb) {
+    const int row0 = wrow0 + mb * 32;
+    const int nrow = min(32, M - row0);
+    float* dst = dxT + (long)row0 * F;
+    for (int idx = lane; idx < nrow * F; idx += 64) {
+      const int rr = idx / F, f = idx - rr * F;
+      const float v = dsc_l[f * FS + mb * kDzqFieldStride + rr * 2];
+      dst[idx] = accumulate ? dst[idx] + v : v;
+    }
+  }
+}
+
+// LDS field rows of the image: the wrapped slot fields (cin_dz_sym_rows) and the x entries of every period's h values
+inline int cin_dzq_rows(int F, int JT) {
+  const int hpp = cin_dz_h_per_period(JT);
+  return std::max(cin_dz_sym_rows(F, JT), (F + hpp - 1) / hpp * hpp);
+}
+void cin_launch_dzq(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const float* Wzq,
+                    const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods);
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradients.  Wave = 32 channel rows (A-operand rows, on the lanes) x 256 columns [G1 | x1]; the reduction runs over the rows
+// m of one row split, two per step (one per wave half), every operand streamed through a DEPTH-step register queue by raw buffer
+// loads with scalar step offsets (as cin_dw3_kernel):
+//   channel c < Cp = F*symD: the unordered pair (h, f = (h + d) mod F), c = h*symD + d;   c in [Cp, Cp + F): field f = c - Cp alone
+//   xe [M][XE = F+3] = x[m,0..F-1] | 1 | dP_L[m] | dP_p[m]           (cin_qtail_xe_kernel)
+//   A [c][m] = xe[m,h_c] xe[m,f_c]  (h_c = F, the ones column, for the single-field rows)      -> columns   0..127 (x G1):  dW1 pairs
+//   A'[c][m] = A[c][m] * (c < Cp ? dP_L[m] : dP_p[m])                                          -> columns 128..255 (x x1):  dT pairs | v^T
+// i.e. the scale of the quadratic form sits on the generated operand (one more gathered dword and multiply per step), nothing of
+// size [M, 128] is written for it.  Work: a workgroup = 4 channel tiles of one row split (its waves share the B rows through L1);
+// the tiles left over after the last full group of four (26 tiles at F = 39: 2) form workgroups of their own in which the spare
+// waves take further row splits, so every wave of the grid carries the same number of steps.
+constexpr int kDwqDepth = 6;
+struct DwqPlan {
+  int tiles, ncol_full, rem, splits, rows_per_split, wgs_full, wgs;
+};
+inline int cin_dwq_rem_wgs(int rem, int splits) { return rem == 0 ? 0 : (rem == 1 ? (splits + 3) / 4 : (rem == 2 ? (splits + 1) / 2 : splits)); }
+inline DwqPlan cin_dwq_plan(long M, int C, int cus) {
+  DwqPlan p;
+  p.tiles = (C + 31) / 32;
+  p.ncol_full = p.tiles / 4;
+  p.rem = p.tiles % 4;
+  const long unit = 2 * kDwqDepth;
+  const long slots = 2L * cus;                           // two workgroups (two waves per SIMD) per CU, all resident at once
+  int best = 1;
+  for (int s = 1; s <= 1024; ++s) {
+    if ((long)p.ncol_full * s + cin_dwq_rem_wgs(p.rem, s) > slots) break;
+    best = s;
+  }
+  long want = std::max<long>(best, (M + (1L << 20) - 1) >> 20);    // byte offsets inside a split (rows * 1 KiB) stay below 2^31
+  long rows = std::max(unit, ((M + want - 1) / want + unit - 1) / unit * unit);
+  p.rows_per_split = (int)rows;
+  p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
+  p.wgs_full = p.ncol_full * p.splits;
+  p.wgs = p.wgs_full + cin_dwq_rem_wgs(p.rem, p.splits);
+  return p;
+}
+
+template <int DEPTH = kDwqDepth>
+__global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
+                                                         int XE, float* __restrict__ part, int M, int F, int symD, int rows_per_split, int splits,
+                                                         int ncol_full, int rem, int wgs_full, int wgs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int Cp = F * symD, C = Cp + F;
+  // XCD-aware work mapping (as cin_dw3_kernel): workgroup i of XCD i%8 takes item (i%8)*(grid/8) + i/8 of the split-major list
+  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (item >= wgs) return;
+  int tile, split;
+  if (item < wgs_full) {
+    tile = (item % ncol_full) * 4 + wave;
+    split = item / ncol_full;
+  } else {
+    const int j = item - wgs_full;
+    const int per = rem == 1 ? 4 : (rem == 2 ? 2 : 1);   // row splits per leftover workgroup
+    const int tw = rem == 3 ? wave : wave % rem;
+    if (rem == 3 && wave == 3) return;
+    tile = ncol_full * 4 + tw;
+    split = j * per + (rem == 3 ? 0 : wave / rem);
+  }
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  split = __builtin_amdgcn_readfirstlane(split);
+  if (split >= splits) return;
+  const int c0 = tile * 32;
+  const int m_lo = split * rows_per_split;
+  const int m_hi = min(M, m_lo + rows_per_split);
+  if (m_lo >= m_hi) return;
+  // the descriptors cover exactly the split's rows: the last step's spare row and the prefetch past the end read zeros
+  const long mrem = (long)m_hi - m_lo;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(gT + (long)m_lo * HS, mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t r1 = make_rsrc_uniform(x1T + (long)m_lo * HS, mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(xe + (long)m_lo * XE, mrem * XE * 4);
+  const int c = c0 + r;
+  const int cc = c < C ? c : C - 1;
+  int hh, ff, sel;
+  if (cc < Cp) {
+    hh = cc / symD;
+    ff = (hh + (cc - hh * symD)) % F;
+    sel = 0;
+  } else {
+    hh = F;
+    ff = cc - Cp;
+    sel = 1;
+  }
+  const int ho = (half * XE + hh) * 4, fo = (half * XE + ff) * 4, so = (half * XE + F + 1 + sel) * 4;
+  const int go = (half * HS + 4 * r) * 4;
+  const int steps = (m_hi - m_lo + 1) >> 1;
+  const int groups = (steps + DEPTH - 1) / DEPTH;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  f32x4s qg[DEPTH], q1[DEPTH];
+  float qh[DEPTH], qf[DEPTH], qs[DEPTH];
+  auto fetch = [&](int s, int d) {
+    const int row = 2 * s;   // uniform, relative to the split's first row
+    qg[d] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rg, go, row * HS * 4, 0));
+    q1[d] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(r1, go, row * HS * 4, 0));
+    qh[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ho, row * XE * 4, 0));
+    qf[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, fo, row * XE * 4, 0));
+    qs[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, so, row * XE * 4, 0));
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) fetch(d, d);
+  // the generated operands of step s+1 are computed in front of step s's MFMAs and consumed a step later
+  float ac = qh[0] * qf[0], ac2 = ac * qs[0], an, an2;
+#pragma unroll 1
+  for (int g = 0; g < groups; ++g) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const f32x4s g4 = qg[d], x4 = q1[d];
+      an = qh[(d + 1) % DEPTH] * qf[(d + 1) % DEPTH];   // (slot 0 of the next group was refilled a group ago)
+      an2 = an * qs[(d + 1) % DEPTH];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mfma32(ac, g4[0], acc[0]);
+      acc[1] = mfma32(ac, g4[1], acc[1]);
+      acc[2] = mfma32(ac, g4[2], acc[2]);
+      acc[3] = mfma32(ac, g4[3], acc[3]);
+      acc[4] = mfma32(ac2, x4[0], acc[4]);
+      acc[5] = mfma32(ac2, x4[1], acc[5]);
+      acc[6] = mfma32(ac2, x4[2], acc[6]);
+      acc[7] = mfma32(ac2, x4[3], acc[7]);
+      ac = an;
+      ac2 = an2;
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(g * DEPTH + d + DEPTH, d);   // after the step's MFMAs: the refill may land in the registers it replaces
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* pout = part + (long)split * C * 256;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int cr = c0 + mfma32_row(reg, half);
+    if (cr < C) {
+      float* dst = pout + (long)cr * 256 + 4 * r;
+      if (cr < Cp) *reinterpret_cast<float4*>(dst) = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+      *reinterpret_cast<float4*>(dst + 128) = make_float4(acc[4][reg], acc[5][reg], acc[6][reg], acc[7][reg]);
+    }
+  }
+}
+
+// Fixed-order sum of the row-split partials [splits][C][256] of cin_dwq_kernel (64 outputs per workgroup, the 4 waves take every
+// 4th partial, as cin_reduce_kernel), written straight to their destinations:
+//   pair row c = h*D + d, column n < H1:        dW1[(h,f), n] and, unless d == 0 or 2d == F, dW1[(f,h), n]      (f = (h + d) mod F)
+//   pair row c, column 128 + n, n < H2:         dT[(h,f), n] / dT[(f,h), n] likewise  ([F*F][H2])
+//   single-field row c = Cp + f, column 128+n:  vT[f][n]                                                          ([F][H2])
+// Workgroups past those rows: the fixed-order sum of the nbp column-sum partials bpart [nbp][H1] -> dbias1 (cin_reduce_body).
+static __global__ __launch_bounds__(256) void cin_reduce_expand_q_kernel(const float* __restrict__ part, int parts, int F, int D, int H1, int H2,
+                                                                          float* __restrict__ dW1, float* __restrict__ dT, float* __restrict__ vT,
+                                                                          const float* __restrict__ bpart, int nbp, float* __restrict__ dbias1) {
+  const int Cp = F * D, C = Cp + F;
+  const int nbw = C * 4;   // 64-column groups
+  if ((int)blockIdx.x >= nbw) {
+    cin_reduce_body(bpart, dbias1, (long)H1, nbp, nullptr, 0, (int)blockIdx.x - nbw);
+    return;
+  }
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x >> 2, col = (blockIdx.x & 3) * 64 + lane;
+  const int n = col & 127;
+  const bool second = col >= 128;
+  const bool live = second ? n < H2 : (c < Cp && n < H1);
+  const long ps = (long)C * 256;
+  const long i = (long)c * 256 + col;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (live) {
+    int p = wave;
+    for (; p + 12 < parts; p += 16) {
+      t0 += part[(long)p * ps + i];
+      t1 += part[(long)(p + 4) * ps + i];
+      t2 += part[(long)(p + 8) * ps + i];
+      t3 += part[(long)(p + 12) * ps + i];
+    }
+    for (; p < parts; p += 4) t0 += part[(long)p * ps + i];
+  }
+  red[wave][lane] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (wave == 0 && live) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (c >= Cp) {
+      vT[(long)(c - Cp) * H2 + n] = v;
+    } else {
+      const int h = c / D, d = c - h * D;
+      const int f = (h + d) % F;
+      float* dst = second ? dT : dW1;
+      const int H = second ? H2 : H1;
+      dst[((long)h * F + f) * H + n] = v;
+      if (d != 0 && 2 * d != F) dst[((long)f * F + h) * H + n] = v;
+    }
+  }
+}
+
+// xe[m][XE = F+3] = x[m,0..F-1] | 1 | dP_L[m] | dP_p[m]  (operand rows of cin_dwq_kernel), and per block of 256 rows the column sums
+// dcpart[blk][f] = sum_m dP_L[m] x[m,f] (-> dc[f] = d pool_L / d c[f]), dcpart[blk][F] = sum_m dP_L[m], dcpart[blk][F+1] = sum_m dP_p[m]
+// (cf. cin_qtail_scale_kernel).  Further workgroups: [nscale, +nhead) the dense head's partial sums -> ddense_w | ddense_b; the
+// rest: the slot-ordered pair weights of W1 and T for cin_dzq_kernel.   LDS: [256][F+3]
+static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
+                                                                  const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xe,
+                                                                  float* __restrict__ dcpart, int M, int F, int nscale,
+                                                                  const float* __restrict__ hpart, float* __restrict__ ddw, float* __restrict__ ddb,
+                                                                  int LK, int nhp, int nhead, const float* __restrict__ W0, const float* __restrict__ T,
+                                                                  float* __restrict__ Wzq, int H0, int JTs, int tiles0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= nscale + nhead) {
+    cin_pack_wzq_body(W0, T, Wzq, F, H0, H0, JTs, 2, tiles0, blockIdx.x - nscale - nhead, gridDim.x - nscale - nhead);
+    return;
+  }
+  if ((int)blockIdx.x >= nscale) {   // the dense head's partial sums -> ddense_w | ddense_b (fixed order)
+    cin_reduce_body(hpart, ddw, (long)LK + 1, nhp, ddb, (long)LK, blockIdx.x - nscale);
+    return;
+  }
+  const int ld = F + 3, XE = F + 3;
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  float* row = smem + threadIdx.x * ld;
+  if (m < M) {
+    const long b = m / K;
+    const float dl = dPL[b * ldp + (m - b * K)], dp = dPp[b * ldp + (m - b * K)];
+    for (int f = 0; f < F; ++f) {
+      const float v = xT[m * F + f];
+      xe[m * XE + f] = v;
+      row[f] = v * dl;
+    }
+    xe[m * XE + F] = 1.f;
+    xe[m * XE + F + 1] = dl;
+    xe[m * XE + F + 2] = dp;
+    row[F] = dl;
+    row[F + 1] = dp;
+  } else {
+    for (int f = 0; f < F + 2; ++f) row[f] = 0.f;
+  }
+  __syncthreads();
+  // column sums: wave q takes rows 64q .. 64q+63 of column f = lane, the four partial sums meet in wave order
+  __shared__ float cs[4][64];
+  {
+    const int f = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float t0 = 0.f, t1 = 0.f;
+    if (f < F + 2) {
+      for (int rr = 64 * q; rr < 64 * q + 64; rr += 2) {
+        t0 += smem[rr * ld + f];
+        t1 += smem[(rr + 1) * ld + f];
+      }
+    }
+    cs[q][f] = t0 + t1;
+  }
+  __syncthreads();
+  if (threadIdx.x < F + 2) dcpart[(long)blockIdx.x * kQtConst + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
+}
+
+}  // namespace fil

@@ -76,10 +76,14 @@ static __global__ __launch_bounds__(256) void cin_qtail_prep_kernel(const float*
                                                                     const float* __restrict__ W0, float* __restrict__ Wf, int H0, int JT2s, int chunks0,
                                                                     int npk, const float* __restrict__ WL, float* __restrict__ wsumL, int Hq, int HL,
                                                                     int nwl, const float* __restrict__ Wp, float* __restrict__ wsum_p,
-                                                                    float* __restrict__ wsn_p, int Hpp, int JT2, int chunksp) {
+                                                                    float* __restrict__ wsn_p, int Hpp, int JT2, int chunksp,
+                                                                    float* __restrict__ x2T, int XL, int xt_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
-  if (b < nt) cin_transpose_in_body(x, xT, F, K, b, smem);
+  if (b < nt) {
+    if (xt_in) cin_wrap_rows_body(x, x2T, F, K, b, XL);
+    else cin_transpose_in_body(x, xT, F, K, b, smem, x2T, XL);
+  }
   else if (b < nt + npk) cin_pack_wf_sym_body(W0, Wf, F, H0, JT2s, chunks0, b - nt, npk);
   else if (b < nt + npk + nwl) qt_wsum_body(WL, wsumL, Hq * F, HL, nullptr, 0, F, 0, 0, b - nt - npk, nwl);
   else qt_wsum_body(Wp, wsum_p, Hpp * F, Hq, wsn_p, Hpp, F, JT2, chunksp, b - nt - npk - nwl, gridDim.x - nt - npk - nwl);

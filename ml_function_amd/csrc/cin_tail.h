@@ -113,11 +113,13 @@ static __global__ __launch_bounds__(256) void cin_tail_wsum_kernel(const float* 
 static __global__ __launch_bounds__(256) void cin_fwd_prep_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K, int nt,
                                                            const float* __restrict__ W0, float* __restrict__ Wf, int H0, int JT2,
                                                            int chunks, int npk, const float* __restrict__ WL, float* __restrict__ bmT,
-                                                           int Hq, int HL, int nws, float4* __restrict__ zero, long nzero4) {
+                                                           int Hq, int HL, int nws, float4* __restrict__ zero, long nzero4,
+                                                           float* __restrict__ x2T, int XL, int xt_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < nt) {
-    cin_transpose_in_body(x, xT, F, K, b, smem);
+    if (xt_in) cin_wrap_rows_body(x, x2T, F, K, b, XL);
+    else cin_transpose_in_body(x, xT, F, K, b, smem, x2T, XL);
   } else if (b < nt + npk) {
     cin_pack_wf_sym_body(W0, Wf, F, H0, JT2, chunks, b - nt, npk);
   } else if (b < nt + npk + nws) {
