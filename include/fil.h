@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 208
+#define FIL_ABI_VERSION 209
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -112,6 +112,10 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *           pair-symmetric GEMM kernels -- F(F+1)/2 x H_1 products per row, half of the fused tail's, no column padding
  *           (csrc/cin_qtail.h).  Used above 16,384 rows (B*K; smaller batches are launch-latency bound and keep the fused tail,
  *           FIL_CIN_TAIL_ALWAYS lifts that rule).  This bit keeps three-layer nets on the F+1-column fused tail (tests / comparison).
+ *         + FIL_CIN_NOQMERGE (512): the quadratic tail's backward normally runs ONE weight-gradient GEMM with 256 output columns,
+ *           pairs(x)^T [G^1 | dP_L x^1], for the first layer and the quadratic form together (csrc/cin_qmerge.h: the generated operand
+ *           is paid once instead of twice and every wave of the grid carries the same number of steps); this bit keeps round 3's two
+ *           launches (tests / comparison).
  *         + FIL_CIN_NOKSPLIT (128): small batches (B*K <= 16,384 rows) give each block of 32 rows to the FOUR waves of a workgroup,
  *           which split the reduction between them (strong-scaling shards: without it the row-parallel kernels stop getting faster
  *           below one row block per SIMD); this bit keeps one wave per row block.  Same function up to summation order.
@@ -168,7 +172,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
 enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
-                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128, FIL_CIN_NOQTAIL = 256 };
+                         FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128, FIL_CIN_NOQTAIL = 256, FIL_CIN_NOQMERGE = 512 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);

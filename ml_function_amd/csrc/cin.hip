@@ -11,6 +11,7 @@
 #include "cin_tail.h"
 #include "cin_launch.h"
 #include "cin_qtail.h"
+#include "cin_qmerge.h"
 
 #include <stdlib.h>
 
@@ -57,14 +58,15 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_DW_MB, FIL_CIN_DW_SPLITS, FIL_CIN_DZ_MB   launch shape of the dW / dZ kernels
 //   FIL_CIN_TAIL_SPLITS   row splits of the fused tail's weight-gradient kernel
 //   FIL_CIN_KSPLIT=0|4    reduction split of the row-parallel kernels over the 4 waves of a workgroup (default: by M)
+//   FIL_CIN_QMERGE=0      quadratic tail: two weight- / data-gradient launches (first layer, quadratic form) instead of the merged ones
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -214,6 +216,10 @@ static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
   return tail_used(s, mode) && s.L == 3 && tune.sym && s.F >= 2 && s.F + 2 <= kQtConst && s.H[0] <= 128 && 3 * s.F + 1 <= s.HSmax() && (mode & FIL_CIN_NOQTAIL) == 0 &&
          knobs().qtail != 0;   // (3 F: its three [M][F] scratch arrays share one gradient buffer)
 }
+// ... with ONE weight-gradient and ONE data-gradient GEMM for the first layer and the quadratic form together (cin_qmerge.h)
+static bool qmerge_used(const CinShape& s, int mode, const CinTune& tune) {
+  return qtail_used(s, mode, tune) && 3 * s.F + 3 <= s.HSmax() && (mode & FIL_CIN_NOQMERGE) == 0 && knobs().qmerge != 0;   // (xe | gxR | dxR share one gradient buffer)
+}
 static size_t qtail_wz_floats(const CinShape& s) {      // T in the dZ kernel's slot order
   const int jts = cin_jt_sym(s.F);
   return ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
@@ -302,6 +308,7 @@ static size_t dw_part_floats(const CinShape& s) {
   const int csym = s.F * (s.F / 2 + 1);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym + s.F, s.H[0]).splits * (csym + s.F) * s.H[0]);   // quadratic tail: pairs + F single-field rows
+  if (s.L == 3) pmax = std::max(pmax, (size_t)cin_dwq_plan(s.M(), csym + s.F, cu_count()).splits * (csym + s.F) * 256);   // ... merged: 256 columns
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
   const TailGeom g = tail_geom(s);
@@ -362,13 +369,18 @@ extern "C" size_t fil_cin_bwd_workspace_bytes(int B, int F, int K, int L, const 
 extern "C" int fil_cin_grad_ready_points(int B, int F, int K, int L, const int* H, int mode, int* point) {
   CinShape s;
   if (int rc = check_shape("fil_cin_grad_ready_points", B, F, K, L, H, s)) return rc;
-  if (point == nullptr || mode < 0 || mode > 511) return fail(FIL_ERR_ARG, "fil_cin_grad_ready_points: point == NULL or mode %d out of range", mode);
+  if (point == nullptr || mode < 0 || mode > 1023) return fail(FIL_ERR_ARG, "fil_cin_grad_ready_points: point == NULL or mode %d out of range", mode);
   if (B == 0) {                                         // empty batch: zero gradients, every slot at once
     for (int i = 0; i <= L; ++i) point[i] = 0;
     return 1;
   }
   int pt = 0, l = L - 1;
   point[L] = pt++;                                      // the dense head
+  if (qmerge_used(s, mode, CinTune(mode))) {            // merged weight gradients: the first layer's come out first, then the top two layers'
+    point[0] = pt++;
+    point[1] = point[2] = pt++;
+    return pt;
+  }
   if (tail_used(s, mode)) {                             // fused tail: the two top layers' gradients come out of one group of launches
     point[L - 1] = point[L - 2] = pt++;
     l = L - 3;
@@ -383,8 +395,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 511)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL)", mode);
+  if (mode < 0 || mode > 1023)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE)", mode);
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
@@ -630,13 +642,14 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 511)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL)", mode);
+  if (mode < 0 || mode > 1023)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
   const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);
   const bool qtail = qtail_used(s, mode, tune);
+  const bool qmerge = qmerge_used(s, mode, tune);
   const TailGeom tg = tail_geom(s);
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
@@ -731,7 +744,94 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   bool dx_started = false;   // has dxT been initialised yet
   bool have_gx0 = false;     // did a general layer-1 kernel produce Gx^0
   bool wz_prepacked = false; // fused tail with L == 3: layer 0's dZ weights were packed by the tail's first launch
-  if (qtail) {
+  if (qmerge) {
+    // ---- quadratic tail with merged weight gradients (cin_qmerge.h): [dW1 | dT] = pairs(x)^T [G1 | dP_L x1] in ONE launch; the data
+    // gradients stay two launches of the pair-symmetric dZ kernel (G1 with W1, then the unscaled x1 with T, scaled by dP_L in the
+    // final transpose).  G1 = dP_p S + dP_1 + dP_L R and the shortcut's dX part come out of cin_last_bwd2_kernel.
+    const int p = tg.p, lL = L - 1, Hpp = tg.Hpp, Hq = tg.Hq, HS0 = s.HS(0);
+    FIL_CHECK_ARG(bias && W[0] && W[p] && W[lL] && bias[p] && dW[0] && dW[p] && dW[lL] && dbias[0] && dbias[p] && dbias[lL]);
+    const float* xpT = maps[p - 1];
+    const int xps = s.xps(p);
+    const float* dPp = dPsrc + (size_t)p * K;
+    const float* dPL = dPsrc + (size_t)lL * K;
+    const float* dPprev = dPsrc + (size_t)(p - 1) * K;
+    const double algo_tail = gemm_flops(M, Hpp, F, Hq) + gemm_flops(M, Hq, F, tg.HL);   // the top two layers of the reference graph
+    const double algo1 = gemm_flops(M, F, F, H[0]);
+    const int symD = F / 2 + 1, Cl = F * symD;
+    const int JTs = cin_jt_sym(F);
+    const int periods = cdiv(F, cin_dz_h_per_period(JTs));
+    const int tiles0 = periods * cin_dz_tiles_per_period(JTs) + 1;
+    // Gbuf[1] is free (the layer loop does not run): xe | gxR | dxR
+    const int XE = F + 3;
+    float* xe = Gbuf[1];                         // [M][F+3]: x | 1 | dP_L | dP_p
+    float* gxR = xe + (size_t)M * XE;
+    float* dxR = gxR + (size_t)M * F;
+    {
+      ProfScope ps("cin_tail_a", st, (double)M * (2 * F + 3) * sizeof(float));
+      const size_t sh = (size_t)256 * (F + 3) * sizeof(float);
+      allow_lds(cin_qtail_xe_kernel, sh);
+      const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + the head's partial sums
+      const int np = (int)std::min<long>(((long)tiles0 * 32 * HS0 + 255) / 256, 1024);   // + W1 in the dZ kernel's slot order
+      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + nh + np), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc, small,
+                         ddense_w, ddense_b, (int)LK, nblk, nh, W[0], Wz, H[0], JTs, HS0, tiles0);
+    }
+    FIL_CHECK_LAUNCH();
+    ready(L);
+    {
+      ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
+      cin_launch_last_bwd2(st, JT, xT, xpT, xps, qtWsumP, qtWsnP, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL, small);
+    }
+    FIL_CHECK_LAUNCH();
+    {
+      ProfScope ps("cin_bwd_dw_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
+      const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
+      hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth>), dim3((dp.wgs + 7) / 8 * 8), dim3(kCinThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD,
+                         dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
+    }
+    FIL_CHECK_LAUNCH();
+    {
+      // fixed-order sums of the partials -> dW1 (both rows of a pair), dT, v^T; + dbias1 from the column sums cin_last_bwd2_kernel left
+      ProfScope ps("cin_reduce_dw", st);
+      const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
+      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F) * 4 + cdiv(H[0], 64)), dim3(256), 0, st, part, dp.splits, F, symD, H[0], Hpp, dW[0], qt_dT,
+                         vlast, small, ncol, dbias[0]);
+    }
+    FIL_CHECK_LAUNCH();
+    ready(0);
+    {
+      ProfScope ps("cin_tail_params", st);
+      const size_t ldf = (((size_t)F + 3) & ~(size_t)3) + 4;
+      const size_t sh = std::max((F * ldf + std::max((size_t)Hq * ldf, (size_t)F * (Hq + 1))) * sizeof(float), (size_t)256 * sizeof(float));
+      allow_lds(cin_qtail_params_kernel, sh);
+      float* dcfin = qt_dcpart + (size_t)qt_ndc * kQtConst;
+      hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq, qt_dcpart, qt_ndc,
+                         dcfin);
+      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, dcfin, bias[p], qtWsumL, dW[lL], dbias[p], dbias[lL], F, Hq,
+                         tg.HL);
+    }
+    FIL_CHECK_LAUNCH();
+    ready(lL);
+    ready(p);
+    const int NHMAX = HS0 / 2;
+    const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
+    const int MBs = two_waves ? 1 : tune.mb_rows(M);
+    const int ks = MBs != 1 ? 1 : tune.ksplit(M);
+    const dim3 zgrid(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs));
+    {
+      ProfScope ps("cin_bwd_dz_tail", st, algo_tail, gemm_flops(M, 1, Cl, Hpp));   // (T in slot order: packed and saved by the forward)
+      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp, periods, false, ks);
+      // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
+    }
+    FIL_CHECK_LAUNCH();
+    {
+      ProfScope ps("cin_bwd_dz_l1", st, algo1, gemm_flops(M, 1, Cl, H[0]));
+      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, Gbuf[cur], HS0, Wz, xT, gx0T, dxT, 1, (int)M, F, H[0], periods, false, ks);
+    }
+    FIL_CHECK_LAUNCH();
+    have_gx0 = true;
+    dx_started = true;
+    ltop = -1;
+  } else if (qtail) {
     // ---- quadratic tail (cin_qtail.h).  pool_p goes back through the pooled-weights shortcut of layer p; pool_L = <x1, R> through the
     // first layer's pair-symmetric dW / dZ kernels with x1 (unscaled) as their "gradient" operand: dT = (pairs of x, one factor scaled
     // by dP_L)^T x1, the two halves of d<x1,R>/dx come out per row and are scaled by dP_L afterwards; G^{p-1} += dP_L R is elementwise.
@@ -785,7 +885,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     {
       ProfScope ps("cin_tail_params", st);
       const size_t ldf = (((size_t)F + 3) & ~(size_t)3) + 4;
-      const size_t sh = (F * ldf + std::max((size_t)Hq * ldf, (size_t)F * (Hq + 1))) * sizeof(float);
+      // (at least the 4 x 64 floats the extra workgroup folds the dc partials through: small F with a narrow layer needs less for the products)
+      const size_t sh = std::max((F * ldf + std::max((size_t)Hq * ldf, (size_t)F * (Hq + 1))) * sizeof(float), (size_t)256 * sizeof(float));
       allow_lds(cin_qtail_params_kernel, sh);
       float* dcfin = qt_dcpart + (size_t)qt_ndc * kQtConst;
       hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq, qt_dcpart, qt_ndc,
@@ -1021,7 +1122,10 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   }
   {
     ProfScope ps("cin_transpose_out", st, 2.0 * M * F * sizeof(float));
-    if (qtail)
+    if (qmerge)
+      hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K,
+                         Gbuf[1] + (size_t)M * (F + 3), Gbuf[1] + (size_t)M * (F + 3) + (size_t)M * F, qtCvec, dPsrc + (size_t)(L - 1) * K, (int)LK);
+    else if (qtail)
       hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K,
                          Gbuf[1] + (size_t)M * (F + 1), Gbuf[1] + (size_t)M * (F + 1) + (size_t)M * F, qtCvec, dPsrc + (size_t)(L - 1) * K, (int)LK);
     else

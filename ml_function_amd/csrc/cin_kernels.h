@@ -101,8 +101,8 @@ static __global__ __launch_bounds__(256) void cin_transpose_in_kernel(const floa
 }
 
 // dx [B,F,K] = dxT [M][F] (+ addT [M][F])
-// q1 != nullptr (quadratic tail): + scale[m] * (q1[m,f] + q2[m,f] + qc[f]), scale[m] = qs[b*ldq + k] -- the two halves of the
-// quadratic form's gradient and its linear term, computed on the unscaled x1
+// qc != nullptr (quadratic tail): + scale[m] * (q1[m,f] + q2[m,f] + qc[f]), scale[m] = qs[b*ldq + k] -- the two halves of the
+// quadratic form's gradient, computed on the unscaled x1 (q1 == nullptr: the merged form has them in dxT already), and its linear term
 static __global__ __launch_bounds__(256) void cin_transpose_out_kernel(const float* __restrict__ dxT, const float* __restrict__ addT,
                                                                 float* __restrict__ dx, int F, int K, const float* __restrict__ q1 = nullptr,
                                                                 const float* __restrict__ q2 = nullptr, const float* __restrict__ qc = nullptr,
@@ -111,12 +111,12 @@ static __global__ __launch_bounds__(256) void cin_transpose_out_kernel(const flo
   const long b = blockIdx.x;
   const float* src = dxT + b * K * F;
   const float* src2 = addT != nullptr ? addT + b * K * F : nullptr;
-  if (q1 != nullptr) {
-    const float* a1 = q1 + b * K * F;
-    const float* a2 = q2 + b * K * F;
+  if (qc != nullptr) {
+    const float* a1 = q1 != nullptr ? q1 + b * K * F : nullptr;
+    const float* a2 = q1 != nullptr ? q2 + b * K * F : nullptr;
     for (int i = threadIdx.x; i < F * K; i += 256) {
       const int k = i / F, f = i - k * F;
-      smem[k * (F + 1) + f] = (src[i] + (src2 ? src2[i] : 0.f)) + qs[b * ldq + k] * ((a1[i] + a2[i]) + qc[f]);
+      smem[k * (F + 1) + f] = (src[i] + (src2 ? src2[i] : 0.f)) + qs[b * ldq + k] * ((a1 ? a1[i] + a2[i] : 0.f) + qc[f]);
     }
   } else
   for (int i = threadIdx.x; i < F * K; i += 256) smem[(i / F) * (F + 1) + (i % F)] = src[i] + (src2 ? src2[i] : 0.f);
@@ -1192,7 +1192,13 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
 #pragma unroll
       for (int s4 = 0; s4 < NQ; ++s4) {
         const float4 w = q[s4];
+#if defined(FIL_ABL_DZ_NOW)
+        asm volatile("" : "+v"(q[s4].x), "+v"(q[s4].y), "+v"(q[s4].z), "+v"(q[s4].w));
+#elif defined(FIL_ABL_DZ_SAMEW)
+        q[s4] = wz[s4];
+#else
         q[s4] = wnext[s4];
+#endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           d[mb] = mfma32(w.x, greg[mb][4 * s4 + 0], d[mb]);
@@ -1201,7 +1207,11 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
           d[mb] = mfma32(w.w, greg[mb][4 * s4 + 3], d[mb]);
         }
         // previous tile's slots, spread over this tile's step groups (NQ is 16 or 32; 16 slots per tile)
+#ifdef FIL_ABL_DZ_NOSLOT
+        if (s4 < 1) {
+#else
         if (s4 < 16) {
+#endif
           if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, s4);
           else slot_apply(dprev, xcur, hbase, tp - 1, s4);
           if (s4 < 15) {

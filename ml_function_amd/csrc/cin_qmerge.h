@@ -1,272 +1,21 @@
-// Quadratic tail of a three-layer CIN, merged form (round 4): ONE data-gradient GEMM and ONE weight-gradient GEMM for the first layer
-// and the quadratic form together, instead of two launches each (cin_qtail.h explains the algebra; reference interactive_layer.py:310-327).
+// Quadratic tail of a three-layer CIN, merged weight gradients (round 4): ONE weight-gradient GEMM for the first layer and the quadratic
+// form together instead of two launches (cin_qtail.h explains the algebra; reference interactive_layer.py:310-327).
 //
 // With P[m,c] = x[m,h_c] x[m,f_c] over the unordered field pairs c (cin_pack_wf_sym_kernel's pair weights W1s, Ts):
 //   x1 = P W1s + b1,  R = P Ts,  pool_L = <x1, R> + ...                                   (forward: cin_fwd3_kernel, twice)
-//   dP  = G1 W1s^T + (dP_L x1) Ts^T      = [G1 | dP_L x1] [W1s ; Ts]^T                     -> cin_dzq_kernel: reduction length 256
 //   [dW1s | dTs] = P^T [G1 | dP_L x1]                                                       -> cin_dwq_kernel: 256 output columns
-// The f32 MFMA shares the vector ALU on gfx950, so every vector instruction beside the MFMAs is matrix time: the data-gradient kernel's
-// contraction of a dZ tile into dX (two FMAs, an LDS read and an LDS write per element) and the weight-gradient kernel's generated
-// operand (two gathers and a multiply per step) are paid once per 256 columns here instead of once per 128.
+// The generated operand (two gathers and a multiply per step) is paid once per 256 columns instead of once per 128, the channel
+// tiles are dealt so that every wave of the grid carries the same number of steps (the 128-column launches left 13 % of their wave
+// slots idle: 780 pair rows are 24.4 tiles of 32), and one reduction pass instead of two sums the row-split partials.
+// (The matching merge of the two data-gradient launches -- reduction length 256, [G1 | dP_L x1] [W1s ; Ts]^T -- was built and dropped:
+// the lane's two half rows then take 128 registers per 32 rows, which forces one wave per SIMD, and with 64 rows per wave the
+// compiler parks the B operands in accumulator registers and copies one back in front of every MFMA.)
 #pragma once
 #include "cin_kernels.h"
 #include "cin_launch.h"
 #include "cin_qtail.h"
 
 namespace fil {
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Data gradients.  Wave = 32*MB rows m (on the lanes), ONE wave per SIMD (the lane's two half rows of [G1 | dP_L x1] take
-// MB * 2 * 64 registers).  dZ^T tile = 32 slot rows (A operand: the slot-ordered pair weights, streamed through a 16-deep register
-// queue by scalar-offset buffer loads) x 32 rows m (B operand: the lane's half row), reduced over KH * 128 columns.
-// Slot (h, j) of lane half `half` is the unordered pair (h, f = (h + 2j + half) mod F) (cin_pack_wz_sym_kernel); accumulator
-// register rr of tile t is slot 16 t + rr, so with a compile-time JT the (tile, register) -> (h, j) pattern repeats every P tiles:
-//   dX[m,f] += dZ x[m,h]          LDS read-modify-write on the field's row
-//   gx      += dZ x[m,f]          -> dX[m,h] += gx when the h is complete (both lane halves, one LDS add)
-// x entry and dX accumulator of a field sit side by side in LDS, [f][mb][row 128][x | dX]: one 8-byte read per slot, a compare and a
-// select for the wrap of f, everything else compile-time offsets.  The 16 slots of tile t are contracted while the MFMA chain of tile
-// t+1 runs, their LDS operands fetched one step group earlier.
-constexpr int kDzqFieldStride = 128 * 2;   // floats per (field, mb): 128 rows x (x, dX)
-
-// Wzq[(t*KH + kh)][32 slot rows][128 columns]: the pair weights of W1 (kh = 0) and T (kh = 1) in slot order
-__device__ __forceinline__ void cin_pack_wzq_body(const float* __restrict__ W1, const float* __restrict__ T, float* __restrict__ Wzq, int F, int H1,
-                                                  int H2, int JT, int KH, int tiles, int bid, int nblocks) {
-  const long total = (long)tiles * KH * 32 * 128;
-  for (long idx = (long)bid * 256 + threadIdx.x; idx < total; idx += (long)nblocks * 256) {
-    const int col = (int)(idx & 127);
-    const long row = idx >> 7;
-    const int i = (int)(row & 31);
-    const long st = row >> 5;
-    const int kh = (int)(st % KH);
-    const long t = st / KH;
-    const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
-    const long slot = 16 * t + rr;
-    const int h = (int)(slot / JT), j = (int)(slot - (long)h * JT);
-    const int d = 2 * j + hf;
-    const float* W = kh == 0 ? W1 : T;
-    const int H = kh == 0 ? H1 : H2;
-    float v = 0.f;
-    if (h < F && d <= F / 2 && col < H) {
-      const int f = (h + d) % F;
-      if (d == 0) v = W[((long)h * F + h) * H + col];
-      else {
-        v = W[((long)h * F + f) * H + col] + W[((long)f * F + h) * H + col];
-        if (2 * d == F) v *= 0.5f;
-      }
-    }
-    Wzq[idx] = v;
-  }
-}
-
-template <int MB, int JT, int KH>
-__global__ __launch_bounds__(256, 1) void cin_dzq_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
-                                                         const float* __restrict__ dsc, int ldp, int K, const float* __restrict__ Wzq,
-                                                         const float* __restrict__ xT, float* __restrict__ dxT, int accumulate, int M, int F,
-                                                         int H1, int H2, int periods, int FR) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [FR][MB][128 rows][2]
-  constexpr int P = JT / gcd_c(16, JT);
-  constexpr int HPP = 16 * P / JT;
-  constexpr int NQ = 16;                               // float4 per sub-tile and lane (64 columns per wave half)
-  constexpr int FS = MB * kDzqFieldStride;             // floats per field
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-  const int wrow0 = (blockIdx.x * 4 + wave) * (32 * MB);
-  if (wrow0 >= M) return;   // (no workgroup barriers in this kernel)
-  float* lrow = smem + (wave * 32 + r) * 2;            // this lane's row: field f, block mb at lrow[f*FS + mb*kDzqFieldStride + {0: x, 1: dX}]
-  long mq[MB];
-  bool vq[MB];
-  float greg[MB][KH * 64];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = wrow0 + mb * 32 + r;
-    vq[mb] = m < M;
-    mq[mb] = vq[mb] ? m : M - 1;
-    // x entries (zero past F and for rows past M) and zeroed dX accumulators: eight loads per batch, then the LDS writes
-    for (int f0 = half; f0 < FR; f0 += 16) {
-      float xt[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) xt[u] = xT[mq[mb] * F + min(f0 + 2 * u, F - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = f0 + 2 * u;
-        if (f < FR) {
-          const int keep = (vq[mb] && f < F) ? -1 : 0;
-          *reinterpret_cast<float2*>(lrow + f * FS + mb * kDzqFieldStride) = make_float2(__builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep), 0.f);
-        }
-      }
-    }
-  }
-  // the lane's half rows: 16-byte loads, all in flight together
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-    for (int kh = 0; kh < KH; ++kh) {
-      const float4* grow4 = reinterpret_cast<const float4*>((kh == 0 ? g1T : g2T) + mq[mb] * HS + half * 64);
-      const int Hk = kh == 0 ? H1 : H2;
-      float sc = 1.f;
-      if (kh == 1) {
-        const long bb = mq[mb] / K;
-        sc = dsc[bb * ldp + (mq[mb] - bb * K)];
-      }
-#pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
-        const float4 g4 = grow4[s4];
-        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int keep = (vq[mb] && half * 64 + 4 * s4 + e < Hk) ? -1 : 0;
-          const float v = __builtin_bit_cast(float, __builtin_bit_cast(int, gv[e]) & keep);
-          greg[mb][kh * 64 + 4 * s4 + e] = kh == 1 ? v * sc : v;
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
-  // A operand stream: sub-tile st = tile*KH + kh is [32][128] floats; lane (r, half) reads row r, columns half*64 + 4*s4 .. +3
-  const long wbytes = ((long)periods * P + 1) * KH * 32 * 128 * 4;
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wzq, wbytes);
-  const int wo = (r * 128 + half * 64) * 4;
-  auto ldw = [&](int st, int s4) {
-    return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo + 16 * s4, st * (32 * 128 * 4), 0));
-  };
-  f32x4s q[NQ];
-#pragma unroll
-  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = ldw(0, s4);
-  float gx[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) gx[mb] = 0.f;
-  f32x16 dprev[MB];
-  float xprev[MB][HPP], xcur[MB][HPP];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dprev[mb][i] = 0.f;
-#pragma unroll
-    for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl] = 0.f;
-  }
-  int hprev = 0;   // h base of the period the previous tile belongs to (the fake tile before the first one: dZ = 0, any valid rows)
-  // A slot is contracted in two halves one step group apart (read, then FMA + write a group later): the LDS latency stays off the MFMA
-  // chain.  Within a group the apply (write) precedes the next fetch (read), so slots that alias one word stay ordered.
-  float2 lv[MB];
-  float* la = lrow;
-  float *abase = lrow, *awrap = lrow;
-  int symh = 0;
-  auto sym_period = [&](int hb) {
-    symh = hb + half;
-    abase = lrow + symh * FS;
-    awrap = abase - F * FS;
-  };
-  auto slot_fetch = [&](int tp, int rr) {
-    const int sp = 16 * tp + rr;
-    const int off = sp / JT + 2 * (sp % JT);   // compile-time after unrolling: f = (h + off + half) mod F, h + off + half < F + FR
-    la = (symh >= F - off ? awrap : abase) + off * FS;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) lv[mb] = *reinterpret_cast<const float2*>(la + mb * kDzqFieldStride);
-  };
-  auto slot_apply = [&](const f32x16 (&d)[MB], const float (&xpv)[MB][HPP], int hb, int tp, int rr) {
-    const int sp = 16 * tp + rr;
-    const int hl = sp / JT, j = sp % JT;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const float dz = d[mb][rr];
-      gx[mb] = fmaf(dz, lv[mb].x, gx[mb]);
-      la[mb * kDzqFieldStride + 1] = fmaf(dz, xpv[mb][hl], lv[mb].y);
-      if (j == JT - 1) {
-        // h = hb + hl is complete: dX[m,h] += sum over both lane halves (one LDS add by the lower half; the row's own words only)
-        const float t = lane_halves_sum(gx[mb]);
-        gx[mb] = 0.f;
-        if (half == 0) {
-          float* dst = lrow + (hb + hl) * FS + mb * kDzqFieldStride + 1;
-          __hip_atomic_fetch_add(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-      }
-    }
-  };
-  sym_period(hprev);
-  slot_fetch(P - 1, 0);
-#pragma unroll 1
-  for (int per = 0; per < periods; ++per) {
-    const int hbase = per * HPP;
-    // x[m, hbase + hl] from the LDS image (rows >= F hold zeros; FR >= periods * HPP)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int hl = 0; hl < HPP; ++hl) xcur[mb][hl] = lrow[(hbase + hl) * FS + mb * kDzqFieldStride];
-#pragma unroll
-    for (int tp = 0; tp < P; ++tp) {
-      f32x16 d[MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) d[mb][i] = 0.f;
-#pragma unroll
-      for (int kh = 0; kh < KH; ++kh) {
-        const int st = (per * P + tp) * KH + kh;
-#pragma unroll
-        for (int s4 = 0; s4 < NQ; ++s4) {
-          const f32x4s w = q[s4];
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            d[mb] = mfma32(w[0], greg[mb][kh * 64 + 4 * s4 + 0], d[mb]);
-            d[mb] = mfma32(w[1], greg[mb][kh * 64 + 4 * s4 + 1], d[mb]);
-            d[mb] = mfma32(w[2], greg[mb][kh * 64 + 4 * s4 + 2], d[mb]);
-            d[mb] = mfma32(w[3], greg[mb][kh * 64 + 4 * s4 + 3], d[mb]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          q[s4] = ldw(st + 1, s4);   // (the stream is allocated one tile past the last period)
-          // previous tile's slots, spread evenly over this tile's KH * 16 step groups
-          if ((kh * NQ + s4) % KH == 0) {
-            const int sl = (kh * NQ + s4) / KH;
-            if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, sl);
-            else slot_apply(dprev, xcur, hbase, tp - 1, sl);
-            if (sl < 15) {
-              slot_fetch(tp == 0 ? P - 1 : tp - 1, sl + 1);
-            } else {
-              if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
-              slot_fetch(tp, 0);                // first slot of this tile, applied in the first group of the next one
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) dprev[mb] = d[mb];
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int hl = 0; hl < HPP; ++hl) xprev[mb][hl] = xcur[mb][hl];
-    hprev = hbase;
-  }
-  // the last tile's slots
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    slot_apply(dprev, xprev, hprev, P - 1, rr);
-    if (rr < 15) slot_fetch(P - 1, rr + 1);
-  }
-  __builtin_amdgcn_wave_barrier();
-  // dX rows of the wave are contiguous in dxT ([32*MB rows][F]): written cooperatively from the LDS image, whole lines per store
-  const float* dsc_l = smem + wave * 32 * 2 + 1;
-#pragma unroll 1
-  for (int mb = 0; mb < MB; ++mb) {
-    const int row0 = wrow0 + mb * 32;
-    const int nrow = min(32, M - row0);
-    float* dst = dxT + (long)row0 * F;
-    for (int idx = lane; idx < nrow * F; idx += 64) {
-      const int rr = idx / F, f = idx - rr * F;
-      const float v = dsc_l[f * FS + mb * kDzqFieldStride + rr * 2];
-      dst[idx] = accumulate ? dst[idx] + v : v;
-    }
-  }
-}
-
-// LDS field rows of the image: the wrapped slot fields (cin_dz_sym_rows) and the x entries of every period's h values
-inline int cin_dzq_rows(int F, int JT) {
-  const int hpp = cin_dz_h_per_period(JT);
-  return std::max(cin_dz_sym_rows(F, JT), (F + hpp - 1) / hpp * hpp);
-}
-void cin_launch_dzq(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const float* Wzq,
-                    const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Weight gradients.  Wave = 32 channel rows (A-operand rows, on the lanes) x 256 columns [G1 | x1]; the reduction runs over the rows
@@ -465,16 +214,16 @@ static __global__ __launch_bounds__(256) void cin_reduce_expand_q_kernel(const f
 // xe[m][XE = F+3] = x[m,0..F-1] | 1 | dP_L[m] | dP_p[m]  (operand rows of cin_dwq_kernel), and per block of 256 rows the column sums
 // dcpart[blk][f] = sum_m dP_L[m] x[m,f] (-> dc[f] = d pool_L / d c[f]), dcpart[blk][F] = sum_m dP_L[m], dcpart[blk][F+1] = sum_m dP_p[m]
 // (cf. cin_qtail_scale_kernel).  Further workgroups: [nscale, +nhead) the dense head's partial sums -> ddense_w | ddense_b; the
-// rest: the slot-ordered pair weights of W1 and T for cin_dzq_kernel.   LDS: [256][F+3]
+// rest: the first layer's pair weights in the dZ kernel's slot order.   LDS: [256][F+3]
 static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
                                                                   const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xe,
                                                                   float* __restrict__ dcpart, int M, int F, int nscale,
                                                                   const float* __restrict__ hpart, float* __restrict__ ddw, float* __restrict__ ddb,
-                                                                  int LK, int nhp, int nhead, const float* __restrict__ W0, const float* __restrict__ T,
-                                                                  float* __restrict__ Wzq, int H0, int JTs, int tiles0) {
+                                                                  int LK, int nhp, int nhead, const float* __restrict__ W0, float* __restrict__ Wz,
+                                                                  int H0, int JTs, int HS0, int tiles0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x >= nscale + nhead) {
-    cin_pack_wzq_body(W0, T, Wzq, F, H0, H0, JTs, 2, tiles0, blockIdx.x - nscale - nhead, gridDim.x - nscale - nhead);
+  if ((int)blockIdx.x >= nscale + nhead) {   // the first layer's weights in the dZ kernel's slot order (nothing else uses that buffer here)
+    cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, blockIdx.x - nscale - nhead, gridDim.x - nscale - nhead);
     return;
   }
   if ((int)blockIdx.x >= nscale) {   // the dense head's partial sums -> ddense_w | ddense_b (fixed order)

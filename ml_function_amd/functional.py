@@ -146,6 +146,7 @@ def dcn_cross(x, w, b):
 CIN_X_TRANSPOSED = 16   # fil.h FIL_CIN_X_TRANSPOSED: x handed over as [B*K, F] (embed_gather(emit_xt=True))
 CIN_TAIL_ALWAYS = 64    # fil.h FIL_CIN_TAIL_ALWAYS: the tails wherever they are defined, whatever the batch size (tests, smoke)
 CIN_NOQTAIL = 256       # fil.h FIL_CIN_NOQTAIL: three-layer nets on the F+1-column fused tail instead of the quadratic tail
+CIN_NOQMERGE = 512      # fil.h FIL_CIN_NOQMERGE: the quadratic tail's weight gradients as two launches instead of the merged one
 
 
 def cin_grad_ready_points(B, F, K, H, mode=0):

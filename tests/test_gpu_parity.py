@@ -178,12 +178,14 @@ def test_cin_split_promotion_nonfinite(mode):
     assert torch.equal(out2[good], outg) and torch.equal(dx2[good], dxg)
 
 
-def test_cin_large_batch_rows_beyond_2_pow_21():
-    """B*K = 2.4 M rows (the dW kernel's buffer descriptors used to span the whole tensor: 2^21 rows at most).
-    Size-independent checks: the first samples equal a small run bit for bit (batch independence), and the weight
-    gradient equals the sum of the two half-batch gradients."""
+@pytest.mark.parametrize("conv", [[64, 32], [128, 128, 128]])
+def test_cin_large_batch_rows_beyond_2_pow_21(conv):
+    """B*K = 2.4 M rows (the dW kernel's buffer descriptors used to span the whole tensor: 2^21 rows at most).  [64, 32]: the general
+    kernels; 3x128: the headline path (quadratic tail, merged weight gradients) -- its buffers, descriptors and row splits past 2^21 rows.
+    Size-independent checks: the first samples equal a small run (batch independence), and the weight gradient equals the sum of
+    the two half-batch gradients."""
     from ml_function_amd import functional as Fn
-    B, F, K, conv = 150000, 39, 16, [64, 32]
+    B, F, K = 150000, 39, 16
     c = synth.cin_case(64, F, K, conv, dist="uniform")
     g = torch.Generator(device="cuda").manual_seed(1)
     x = (torch.rand((B, F, K), device="cuda", generator=g) - 0.5)
@@ -201,8 +203,15 @@ def test_cin_large_batch_rows_beyond_2_pow_21():
         return out.detach(), xs.grad, [w.grad for w in W2]
 
     out, dx, dW = run(x, gout)
-    out_s, dx_s, _ = run(x[:64], gout[:64], mode=128)   # (128: one wave per row block, the summation order of the large batch)
-    assert torch.equal(out[:64], out_s) and torch.equal(dx[:64], dx_s)
+    if len(conv) == 2:
+        out_s, dx_s, _ = run(x[:64], gout[:64], mode=128)   # (128: one wave per row block, the summation order of the large batch)
+        assert torch.equal(out[:64], out_s) and torch.equal(dx[:64], dx_s)
+    else:
+        # (the same tail at 64 rows: 64 = FIL_CIN_TAIL_ALWAYS, 128 = one wave per row block; the wave shape differs from the large
+        # batch's 64-row waves, so the sums are reassociated: equal to fp32 rounding, not bit for bit)
+        out_s, dx_s, _ = run(x[:64], gout[:64], mode=64 | 128)
+        check("large-batch out[:64]", out[:64], out_s.cpu().numpy())
+        check("large-batch dx[:64]", dx[:64], dx_s.cpu().numpy())
     h = B // 2
     _, _, dWa = run(x[:h], gout[:h])
     _, _, dWb = run(x[h:], gout[h:])
@@ -361,16 +370,12 @@ TAIL_SHAPES = [
     (6, 1, 4, [3, 2, 2]),            # one field
     (6, 2, 4, [3, 2, 4]),
     (300, 21, 8, [16, 16, 16]),      # several workgroups, several row splits of the weight-gradient kernel
+    (100, 5, 8, [6, 7, 5]),          # M = 800 rows: four 256-row blocks of dc partials on a net whose parameter kernel needs < 1 KB of LDS
 ]
+TAIL_VARIANT_SHAPES = [TAIL_SHAPES[i] for i in (0, 1, 3, 6, 14)]
 
 
-@pytest.mark.parametrize("B,F,K,conv", TAIL_SHAPES)
-# (| 4: the 64-row waves large batches get; | 128: one wave per row block instead of the small-batch reduction split;
-#  | 256: FIL_CIN_NOQTAIL -- three-layer nets take the quadratic tail (cin_qtail.h) by default, this bit keeps them on the F+1-column
-#  fused tail so that both stay covered; four-layer, wide-F and NOSYM cases run the fused tail either way)
-@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 4), (1, 64 | 128), (1, 64 | 256), (2, 64 | 256), (1, 64 | 256 | 4),
-                                             (1, 64 | 8)])
-def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
+def _tail_case(B, F, K, conv, output_dim, mode):
     from ml_function_amd import functional as Fn
     c = synth.cin_case(B, F, K, conv, dist="uniform", output_dim=output_dim)
     c["x"] = (c["x"] * 10).astype(np.float32)
@@ -390,6 +395,22 @@ def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
     if output_dim == 1:
         check("tail ddense_w", dw.grad, ddw)
         check("tail ddense_b", db.grad, ddb)
+
+
+@pytest.mark.parametrize("B,F,K,conv", TAIL_SHAPES)
+# 64: three-layer nets take the quadratic tail with merged weight gradients (cin_qtail.h, cin_qmerge.h), the others the fused tail;
+# | 512: FIL_CIN_NOQMERGE -- the quadratic tail with two weight-gradient launches; | 256: FIL_CIN_NOQTAIL -- the F+1-column fused tail
+@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 512), (1, 64 | 256), (2, 64 | 256)])
+def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
+    _tail_case(B, F, K, conv, output_dim, mode)
+
+
+@pytest.mark.parametrize("B,F,K,conv", TAIL_VARIANT_SHAPES)
+# launch-shape variants on a subset of the shapes: | 4 the 64-row waves large batches get, | 128 one wave per row block instead of the
+# small-batch reduction split, | 8 no pair-symmetric kernels (the fused tail with a general first layer)
+@pytest.mark.parametrize("mode", [64 | 4, 64 | 128, 64 | 256 | 4, 64 | 512 | 4, 64 | 8])
+def test_cin_fused_tail_launch_variants(B, F, K, conv, mode):
+    _tail_case(B, F, K, conv, 1, mode)
 
 
 # (2048: M = 32,768 rows -- above the quadratic tail's size rule, below the 64-row-wave threshold: its kernels at 32 rows per wave)
@@ -440,52 +461,105 @@ def test_cin_fused_tail_is_the_default_where_it_pays():
 _BENCH_ORACLE = {}
 
 
-def _bench_shape_oracle():
-    """fp64 oracle of the benchmark's own workload (B=4096, F=39, K=16, 3x128; bench.py's seeded inputs): the op-for-op
-    graph under autograd, 16 shards of 256 samples (rows are independent; parameter gradients add) -- ~25 s of CPU."""
-    if not _BENCH_ORACLE:
+def _bench_case(variant):
+    """variant "bench": bench.py's own seeded inputs.  "deep": the same net with the inputs x10 and biases of size 0.1, output_dim = 2
+    (the pooled blocks themselves are the output): layer 3's pool is then ~1e-2..1e-1 of layer 1's instead of ~5e-3, and every
+    block is checked on its own, so a forward error of the deep layers cannot hide behind the first layer's magnitude."""
+    B, F, K, conv = 4096, 39, 16, [128, 128, 128]
+    if variant == "bench":
+        return synth.cin_case(B, F, K, conv), 1
+    c = synth.cin_case(B, F, K, conv, output_dim=2)
+    c["x"] = (c["x"] * 10).astype(np.float32)
+    c["bs"] = [(0.1 * np.random.default_rng(l).standard_normal(b.shape)).astype(np.float32) for l, b in enumerate(c["bs"])]
+    return c, 2
+
+
+def _bench_shape_oracle(variant="bench"):
+    """fp64 oracle of the benchmark's workload (B=4096, F=39, K=16, 3x128): the op-for-op graph under autograd, 16 shards of 256
+    samples (rows are independent; parameter gradients add) -- ~25 s of CPU per variant, computed once per test session."""
+    if variant not in _BENCH_ORACLE:
         from oracle import graph
-        B, F, K, conv = 4096, 39, 16, [128, 128, 128]
-        c = synth.cin_case(B, F, K, conv)
+        c, output_dim = _bench_case(variant)
+        B = c["x"].shape[0]
         T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
         Ws, bs, dw, db = [T(w) for w in c["Ws"]], [T(b) for b in c["bs"]], T(c["dense_w"]), T(c["dense_b"])
-        params = Ws + bs + [dw, db]
+        params = Ws + bs + ([dw, db] if output_dim == 1 else [])
         for p in params:
             p.requires_grad_()
         outs, dxs = [], []
         for lo in range(0, B, 256):
             x = T(c["x"][lo:lo + 256]).requires_grad_()
-            out = graph.cin(x, Ws, bs, dw, db)
+            out = graph.cin(x, Ws, bs, dw, db, output_dim=output_dim)
             out.backward(T(c["g"][lo:lo + 256]))        # parameter .grad accumulates over the shards
             outs.append(out.detach().numpy())
             dxs.append(x.grad.numpy())
-        _BENCH_ORACLE.update(c=c, out=np.concatenate(outs), dx=np.concatenate(dxs), dW=[w.grad.numpy() for w in Ws],
-                             db=[b.grad.numpy() for b in bs], ddw=dw.grad.numpy(), ddb=db.grad.numpy())
-    return _BENCH_ORACLE
+        _BENCH_ORACLE[variant] = dict(c=c, out=np.concatenate(outs), dx=np.concatenate(dxs), dW=[w.grad.numpy() for w in Ws],
+                                      db=[b.grad.numpy() for b in bs], ddw=dw.grad.numpy() if output_dim == 1 else None,
+                                      ddb=db.grad.numpy() if output_dim == 1 else None)
+    return _BENCH_ORACLE[variant]
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 32, 256])
-def test_cin_at_the_benchmark_shape(mode):
-    """The launch configuration bench.py times (M = B*K = 65,536 rows: 64-row waves, the fused tail's forward / weight-gradient
-    split plan / data-gradient kernels, the dW split plan and XCD mapping of that size) against the fp64 oracle -- every output
-    and every gradient, all 4096 samples.  mode 0 = headline (fused tail), 32 = last-layer shortcut only (the round-2 headline),
-    1 = general kernels for every layer, 2 = the split-bf16 experiment."""
+def _run_bench_shape(c, output_dim, mode, reps=1):
+    """The HIP path on `reps` copies of the case's batch (copy i > 0 with the sample order reversed)."""
     from ml_function_amd import functional as Fn
-    o = _bench_shape_oracle()
-    c = o["c"]
-    x = dev(c["x"]).requires_grad_()
+    xs, gs = c["x"], c["g"]
+    if reps > 1:
+        xs = np.concatenate([xs if i % 2 == 0 else xs[::-1] for i in range(reps)])
+        gs = np.concatenate([gs if i % 2 == 0 else gs[::-1] for i in range(reps)])
+    x = dev(xs).requires_grad_()
     Ws = [dev(w).requires_grad_() for w in c["Ws"]]
     bs = [dev(b).requires_grad_() for b in c["bs"]]
     dw, db = dev(c["dense_w"]).requires_grad_(), dev(c["dense_b"]).requires_grad_()
-    out = Fn.cin(x, Ws, bs, dw, db, mode=mode)
+    out = Fn.cin(x, Ws, bs, dw, db, output_dim=output_dim, mode=mode)
+    out.backward(dev(gs))
+    return out, x.grad, [w.grad for w in Ws], [b.grad for b in bs], dw.grad, db.grad
+
+
+# 0 = headline (quadratic tail, merged weight gradients), 512 = quadratic tail with two weight-gradient launches, 256 = F+1-column
+# fused tail, 32 = last-layer shortcut only (the round-2 headline), 1 = general kernels for every layer, 2 = the split-bf16 experiment
+@pytest.mark.parametrize("mode", [0, 1, 2, 32, 256, 512])
+def test_cin_at_the_benchmark_shape(mode):
+    """The launch configuration bench.py times (M = B*K = 65,536 rows: 64-row waves, the weight-gradient split plans and XCD mapping
+    of that size, the tails' kernels) against the fp64 oracle -- every output and every gradient, all 4096 samples."""
+    o = _bench_shape_oracle()
+    out, dx, dW, dbias, ddw, ddb = _run_bench_shape(o["c"], 1, mode)
     check("bench-shape out", out, o["out"])
-    out.backward(dev(c["g"]))
-    check("bench-shape dx", x.grad, o["dx"], tol=2e-5)
+    check("bench-shape dx", dx, o["dx"], tol=2e-5)
     for l in range(3):
-        check("bench-shape dW%d" % l, Ws[l].grad, o["dW"][l], tol=2e-5)
-        check("bench-shape db%d" % l, bs[l].grad, o["db"][l], tol=2e-5)
-    check("bench-shape ddense_w", dw.grad, o["ddw"], tol=2e-5)
-    check("bench-shape ddense_b", db.grad, o["ddb"], tol=2e-5)
+        check("bench-shape dW%d" % l, dW[l], o["dW"][l], tol=2e-5)
+        check("bench-shape db%d" % l, dbias[l], o["db"][l], tol=2e-5)
+    check("bench-shape ddense_w", ddw, o["ddw"], tol=2e-5)
+    check("bench-shape ddense_b", ddb, o["ddb"], tol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 512, 256, 1])
+def test_cin_at_the_benchmark_shape_deep_layers(mode):
+    """B = 4096 with inputs x10, biases ~0.1 and output_dim = 2: each layer's pooled block [B, K] is compared with the fp64 oracle ON ITS
+    OWN NORM (a 0.1 % error in the third layer's forward is 1e-3 here, not 5e-6 of the whole output), and so is every gradient."""
+    o = _bench_shape_oracle("deep")
+    out, dx, dW, dbias, _, _ = _run_bench_shape(o["c"], 2, mode)
+    K = 16
+    for l in range(3):
+        check("deep pooled block %d" % l, out[:, l * K:(l + 1) * K], o["out"][:, l * K:(l + 1) * K])
+    check("deep dx", dx, o["dx"], tol=2e-5)
+    for l in range(3):
+        check("deep dW%d" % l, dW[l], o["dW"][l], tol=2e-5)
+        check("deep db%d" % l, dbias[l], o["db"][l], tol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 512])
+def test_cin_at_twice_the_benchmark_batch(mode):
+    """B = 8192 (131,072 rows: the next launch configuration up -- more row splits, two workgroup rounds) = the benchmark batch followed
+    by the same samples in reverse order, against the SAME fp64 oracle: outputs and dx repeat, parameter gradients double."""
+    o = _bench_shape_oracle()
+    out, dx, dW, dbias, ddw, ddb = _run_bench_shape(o["c"], 1, mode, reps=2)
+    check("2x out", out, np.concatenate([o["out"], o["out"][::-1]]))
+    check("2x dx", dx, np.concatenate([o["dx"], o["dx"][::-1]]), tol=2e-5)
+    for l in range(3):
+        check("2x dW%d" % l, dW[l], 2 * o["dW"][l], tol=2e-5)
+        check("2x db%d" % l, dbias[l], 2 * o["db"][l], tol=2e-5)
+    check("2x ddense_w", ddw, 2 * o["ddw"], tol=2e-5)
+    check("2x ddense_b", ddb, 2 * o["ddb"], tol=2e-5)
 
 
 @pytest.mark.parametrize("B,F,K,conv", [(64, 39, 16, [128, 128, 128]), (33, 38, 16, [64, 48, 8]), (9, 5, 8, [6, 7]), (16, 26, 16, [200, 200])])
