@@ -4,7 +4,10 @@ example/ctr_example/un_seq.py (Adam + binary cross-entropy + AUC, :55-66), on th
   python examples/train_ctr.py --model XDeepFM --steps 200
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ctr.py --model XDeepFM
 
-The input side is the reference's too (kon/utils/data_prepare.py:335-337): the synthetic table is sliced, shuffled with a
+The input side is the reference's too: the raw click log is a CSV-shaped pandas frame (string categories with missing values, dense
+columns with NaNs) that goes through the field-index front end ml_function_amd.data_prepare (sparse_fea_deal: fillna('-1') ->
+astype(str) -> label encoding, one sparseFea per column; dense_fea_deal: fillna(mode) -> min-max scaling; kon/utils/data_prepare.py:
+85-100, 294-301); then (:335-337) the encoded table is sliced, shuffled with a
 2048-element buffer, repeated, batched and prefetched by ml_function_amd.data.data_pipeline (host -> device copies on a
 side stream); the loss is Keras' compiled loss: binary cross-entropy + the layers' regularisation terms (the l2(emb_reg)
 of every embedding table, interactive_layer.py:217); the optimiser is Keras' 'adam' (lr 1e-3, epsilon 1e-7).
@@ -21,17 +24,23 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pandas as pd  # noqa: E402
+
 from ml_function_amd import data, dp, metrics, models  # noqa: E402
+from ml_function_amd.data_prepare import data_prepare  # noqa: E402
 from ml_function_amd.layers.base import collect_regularization_loss  # noqa: E402
 
 
-def make_table(rng, vocab, n_dense, rows, teacher):
-    """A synthetic click log as host arrays: (dense [rows, n_dense], sparse ids [rows, F], label [rows])."""
+def make_raw_log(rng, vocab, n_dense, rows, teacher):
+    """A synthetic click log as it would come out of a CSV: (sparse frame of STRING categories with ~2 % missing values, dense frame
+    of floats with ~2 % NaNs, label [rows]).  The labels follow a fixed random teacher on the raw values."""
     idx = np.stack([np.minimum(rng.zipf(1.3, rows) - 1, v - 1) for v in vocab], 1)
-    dense = rng.random((rows, n_dense), dtype=np.float32)
-    logit = sum(teacher[f][idx[:, f]] for f in range(len(vocab))) + dense @ teacher["dense"]
+    dense = rng.random((rows, n_dense)) * 100.0
+    logit = sum(teacher[f][idx[:, f]] for f in range(len(vocab))) + (dense / 100.0) @ teacher["dense"]
     y = (rng.random(rows) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
-    return dense, idx, y
+    sparse = pd.DataFrame({"C%d" % (f + 1): np.where(rng.random(rows) < 0.02, None, np.char.add("v", idx[:, f].astype("U"))) for f in range(len(vocab))})
+    dense_df = pd.DataFrame({"I%d" % (i + 1): np.where(rng.random(rows) < 0.02, np.nan, dense[:, i]) for i in range(n_dense)})
+    return sparse, dense_df, y
 
 
 def main():
@@ -58,7 +67,17 @@ def main():
     vocab = [int(v) for v in np.exp(rng0.uniform(np.log(10), np.log(2e5), args.fields))]
     teacher = {f: rng0.normal(0, 0.5, v).astype(np.float32) for f, v in enumerate(vocab)}
     teacher["dense"] = rng0.normal(0, 0.5, args.dense).astype(np.float32)
-    info = models.make_sparse_info(vocab, embed_dim=args.embed_dim)
+    # raw log -> field-index front end -> ids + descriptors (every rank encodes the same vocabulary: the log's categories are drawn
+    # from one seeded stream per rank, so the front end sees this rank's shard; word sizes are taken from the full value range)
+    rng = np.random.default_rng(1000 + rank)
+    raw_sparse, raw_dense, labels = make_raw_log(rng, vocab, args.dense, args.steps * args.batch // 2, teacher)      # repeat(2) makes `steps` batches
+    prep = data_prepare(batch_size=args.batch)
+    ids_df, info = prep.sparse_fea_deal(raw_sparse, embed_dim=args.embed_dim)
+    dense_df, _ = prep.dense_fea_deal(raw_dense)
+    if world > 1:   # replicas must agree on the table shapes: the largest vocabulary any rank saw
+        sizes = torch.tensor([f.word_size for f in info], device=device)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
+        info = [f._replace(word_size=int(v)) for f, v in zip(info, sizes.tolist())]
     single = args.model == "XDeepFM"
     fi = models.FeatureInput(sparseInfo=info, useLinear=args.model != "DCN" and args.model != "AutoInt", useAddLinear=single,
                              useFlattenLinear=True)
@@ -66,8 +85,7 @@ def main():
             "AFM": models.AFM, "XDeepFM": lambda: models.XDeepFM(conv_size=[128, 128, 128])}[args.model]()
     torch.manual_seed(0)  # identical replicas
     model = models.CTRModel(fi, body).to(device)
-    rng = np.random.default_rng(1000 + rank)
-    table = make_table(rng, vocab, args.dense, args.steps * args.batch // 2, teacher)      # repeat(2) makes `steps` batches
+    table = (dense_df.to_numpy(np.float32), ids_df.to_numpy(np.int64), labels)
     use_dense = args.model not in ("FM", "AutoInt", "AFM")
     model(torch.tensor(table[0][:args.batch], device=device) if use_dense else None,
           torch.tensor(table[1][:args.batch], device=device))  # builds the lazily created weights
@@ -112,12 +130,20 @@ def main():
                 static = [torch.empty_like(dense), torch.empty_like(idx), torch.empty_like(y)]
                 for dst, src in zip(static, (dense, idx, y)):
                     dst.copy_(src)
+                # (the warm-up steps are real optimizer steps: model and Adam state are put back afterwards, so the captured run follows
+                # the eager one step for step)
+                saved_model = {k: v.clone() for k, v in model.state_dict().items()}
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(3):
                         train_step(*static)
                 torch.cuda.current_stream().wait_stream(side)
+                model.load_state_dict(saved_model)
+                for st_ in opt.state.values():      # Adam's moments and step count back to "never stepped" (in place: the capture keeps these tensors)
+                    for v in st_.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
                 graph = torch.cuda.CUDAGraph()
                 opt.zero_grad(set_to_none=True)
                 with torch.cuda.graph(graph):

@@ -58,15 +58,16 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_DW_MB, FIL_CIN_DW_SPLITS, FIL_CIN_DZ_MB   launch shape of the dW / dZ kernels
 //   FIL_CIN_TAIL_SPLITS   row splits of the fused tail's weight-gradient kernel
 //   FIL_CIN_KSPLIT=0|4    reduction split of the row-parallel kernels over the 4 waves of a workgroup (default: by M)
-//   FIL_CIN_QMERGE=0      quadratic tail: two weight- / data-gradient launches (first layer, quadratic form) instead of the merged ones
+//   FIL_CIN_QMERGE=0      quadratic tail: two weight-gradient launches (first layer, quadratic form) instead of the merged one
+//   FIL_CIN_DZ2=0         ... its two data-gradient passes as two launches of the pair-symmetric dZ kernel instead of one two-pass launch
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -744,6 +745,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   bool dx_started = false;   // has dxT been initialised yet
   bool have_gx0 = false;     // did a general layer-1 kernel produce Gx^0
   bool wz_prepacked = false; // fused tail with L == 3: layer 0's dZ weights were packed by the tail's first launch
+  bool qm_joined = false;    // merged quadratic tail: the two-pass dZ launch left nothing but the linear term for the final transpose
   if (qmerge) {
     // ---- quadratic tail with merged weight gradients (cin_qmerge.h): [dW1 | dT] = pairs(x)^T [G1 | dP_L x1] in ONE launch; the data
     // gradients stay two launches of the pair-symmetric dZ kernel (G1 with W1, then the unscaled x1 with T, scaled by dP_L in the
@@ -813,22 +815,29 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ready(lL);
     ready(p);
     const int NHMAX = HS0 / 2;
-    const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
-    const int MBs = two_waves ? 1 : tune.mb_rows(M);
-    const int ks = MBs != 1 ? 1 : tune.ksplit(M);
-    const dim3 zgrid(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs));
-    {
-      ProfScope ps("cin_bwd_dz_tail", st, algo_tail, gemm_flops(M, 1, Cl, Hpp));   // (T in slot order: packed and saved by the forward)
-      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp, periods, false, ks);
-      // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
+    if (NHMAX == 64 && knobs().dz2 != 0) {
+      // both data-gradient passes in one launch (cin_dz2_kernel): G1 with W1, then dP_L x1 with T, into one dX image
+      ProfScope ps("cin_bwd_dz_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
+      cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods);
+      qm_joined = true;
+    } else {
+      const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
+      const int MBs = two_waves ? 1 : tune.mb_rows(M);
+      const int ks = MBs != 1 ? 1 : tune.ksplit(M);
+      const dim3 zgrid(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs));
+      {
+        ProfScope ps("cin_bwd_dz_tail", st, algo_tail, gemm_flops(M, 1, Cl, Hpp));   // (T in slot order: packed and saved by the forward)
+        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp, periods, false, ks);
+        // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
+      }
+      FIL_CHECK_LAUNCH();
+      {
+        ProfScope ps("cin_bwd_dz_l1", st, algo1, gemm_flops(M, 1, Cl, H[0]));
+        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, Gbuf[cur], HS0, Wz, xT, gx0T, dxT, 1, (int)M, F, H[0], periods, false, ks);
+      }
+      have_gx0 = true;
     }
     FIL_CHECK_LAUNCH();
-    {
-      ProfScope ps("cin_bwd_dz_l1", st, algo1, gemm_flops(M, 1, Cl, H[0]));
-      cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, Gbuf[cur], HS0, Wz, xT, gx0T, dxT, 1, (int)M, F, H[0], periods, false, ks);
-    }
-    FIL_CHECK_LAUNCH();
-    have_gx0 = true;
     dx_started = true;
     ltop = -1;
   } else if (qtail) {
@@ -1122,7 +1131,10 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   }
   {
     ProfScope ps("cin_transpose_out", st, 2.0 * M * F * sizeof(float));
-    if (qmerge)
+    if (qm_joined)
+      hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, nullptr, dx, F, K, nullptr, nullptr, qtCvec,
+                         dPsrc + (size_t)(L - 1) * K, (int)LK);
+    else if (qmerge)
       hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K,
                          Gbuf[1] + (size_t)M * (F + 3), Gbuf[1] + (size_t)M * (F + 3) + (size_t)M * F, qtCvec, dPsrc + (size_t)(L - 1) * K, (int)LK);
     else if (qtail)

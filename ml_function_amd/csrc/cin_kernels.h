@@ -587,7 +587,9 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
         const f32x4s w = q[j % DEPTH];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) an[mb] = j + 1 < JT ? pc[mb] * xc[mb][j + 1 < JT ? j + 1 : 0] : pn[mb] * xn_[mb][0];
+#ifndef FIL_ABL_FWD_NOSB
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const float a = ac[mb];
@@ -598,11 +600,15 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) ac[mb] = an[mb];
+#ifndef FIL_ABL_FWD_NOSB
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef FIL_ABL_NOWLOAD
         q[j % DEPTH] = ldw(sb + j + DEPTH);   // (after the step's MFMAs: it may land in the registers it replaces)
 #endif
+#ifndef FIL_ABL_FWD_NOSB
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     };
     int h = h_lo;

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict
       const f32x4s g4 = qg[d], x4 = q1[d];
       an = qh[(d + 1) % DEPTH] * qf[(d + 1) % DEPTH];   // (slot 0 of the next group was refilled a group ago)
       an2 = an * qs[(d + 1) % DEPTH];
+#ifndef FIL_ABL_DWQ_NOSB
       __builtin_amdgcn_sched_barrier(0);
+#endif
       acc[0] = mfma32(ac, g4[0], acc[0]);
       acc[1] = mfma32(ac, g4[1], acc[1]);
       acc[2] = mfma32(ac, g4[2], acc[2]);
@@ -143,9 +145,13 @@ __global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict
       acc[7] = mfma32(ac2, x4[3], acc[7]);
       ac = an;
       ac2 = an2;
+#ifndef FIL_ABL_DWQ_NOSB
       __builtin_amdgcn_sched_barrier(0);
+#endif
       fetch(g * DEPTH + d + DEPTH, d);   // after the step's MFMAs: the refill may land in the registers it replaces
+#ifndef FIL_ABL_DWQ_NOSB
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
   float* pout = part + (long)split * C * 256;
@@ -266,5 +272,193 @@ static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* _
   __syncthreads();
   if (threadIdx.x < F + 2) dcpart[(long)blockIdx.x * kQtConst + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Data gradients of the first layer and of the quadratic form in ONE launch, as two passes of one wave over its 32 rows:
+//   pass 0:  dZ^T = W1s G1^T           pass 1:  dZ^T = Ts (dP_L x1)^T        (the lane's half row scaled by dP_L[m] on load)
+// both contracted into the SAME dX image in LDS (cin_dz3_kernel<.., SYM> explains the slot machinery; this is its exact pair-symmetric
+// 32-row form, two waves per SIMD, stripped of the other modes).  Against two launches of that kernel: one launch, one staging of x,
+// one pass over dxT, no separate [M][F] arrays for the quadratic form's two gradient halves (nothing is left for the final transpose
+// to scale and join), and the Gx term -- sum_f dZ x[m,f], which is dX[m,h] for a pair-symmetric layer -- is added to the dX image
+// when its h completes instead of travelling through its own [M][F] array.  The second wave of a SIMD is no longer in lockstep with
+// the first after the pass boundary, so each covers the other's operand reload.
+//   x entry and dX accumulator of a field sit side by side in LDS, [f][row 128][x | dX]: one 8-byte read per slot, a compare and a select
+//   for the wrap of f, everything else compile-time offsets of the LDS instructions; the weights stream through a 16-deep register queue
+//   by scalar-offset buffer loads; x[m,h] of a period comes from the LDS image.
+constexpr int kDz2FieldStride = 128 * 2;   // floats per field: 128 rows x (x, dX)
+inline int cin_dz2_rows(int F, int JT) {   // LDS field rows: the wrapped slot fields (cin_dz_sym_rows) and the x entries of every period's h values
+  const int hpp = cin_dz_h_per_period(JT);
+  return std::max(cin_dz_sym_rows(F, JT), (F + hpp - 1) / hpp * hpp);
+}
+
+template <int JT>
+__global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
+                                                         const float* __restrict__ dsc, int ldp, int K, const float* __restrict__ Wz1,
+                                                         const float* __restrict__ Wz2, const float* __restrict__ xT, float* __restrict__ dxT,
+                                                         int accumulate, int M, int F, int H1, int H2, int periods, int FR) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [FR][128 rows][2]
+  constexpr int P = JT / gcd_c(16, JT);
+  constexpr int HPP = 16 * P / JT;
+  constexpr int NQ = 16;                               // float4 per tile and lane (64 columns per wave half)
+  constexpr int FS = kDz2FieldStride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
+  if (wrow0 >= M) return;   // (no workgroup barriers in this kernel)
+  float* lrow = smem + (wave * 32 + r) * 2;            // this lane's row: field f at lrow[f*FS + {0: x, 1: dX}]
+  const int m = wrow0 + r;
+  const bool vq = m < M;
+  const long mq = vq ? m : M - 1;
+  // x entries (zero past F and for rows past M) and zeroed dX accumulators: eight loads per batch, then the LDS writes
+  for (int f0 = half; f0 < FR; f0 += 16) {
+    float xt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xt[u] = xT[mq * F + min(f0 + 2 * u, F - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + 2 * u;
+      if (f < FR) {
+        const int keep = (vq && f < F) ? -1 : 0;
+        *reinterpret_cast<float2*>(lrow + f * FS) = make_float2(__builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep), 0.f);
+      }
+    }
+  }
+  float dpl;
+  {
+    const long bb = mq / K;
+    dpl = dsc[bb * ldp + (mq - bb * K)];
+  }
+  __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
+  const long wbytes = ((long)periods * P + 1) * 32 * 128 * 4;
+  const int wo = (r * 128 + half * 64) * 4;
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* gT = pass == 0 ? g1T : g2T;
+    const int Hk = pass == 0 ? H1 : H2;
+    const float sc = pass == 0 ? 1.f : dpl;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(pass == 0 ? Wz1 : Wz2, wbytes);
+    auto ldw = [&](int t, int s4) {   // tile t is [32 slot rows][128]; lane (r, half) reads row r, columns half*64 + 4*s4 .. +3
+      return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo + 16 * s4, t * (32 * 128 * 4), 0));
+    };
+    f32x4s q[NQ];
+#pragma unroll
+    for (int s4 = 0; s4 < NQ; ++s4) q[s4] = ldw(0, s4);
+    // the lane's half row: 16-byte loads, all in flight together
+    float greg[64];
+    {
+      const f32x4s* grow4 = reinterpret_cast<const f32x4s*>(gT + mq * HS + half * 64);
+      f32x4s gq[16];
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) gq[s4] = grow4[s4];
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int keep = (vq && half * 64 + 4 * s4 + e < Hk) ? -1 : 0;
+          const float gv = gq[s4][e];   // (a copy: __builtin_bit_cast applied to the vector ELEMENT expression reads element 0 for every e)
+          greg[4 * s4 + e] = __builtin_bit_cast(float, __builtin_bit_cast(int, gv) & keep) * sc;
+        }
+    }
+    float gx = 0.f;
+    f32x16 dprev;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dprev[i] = 0.f;
+    float xprev[HPP], xcur[HPP];
+#pragma unroll
+    for (int hl = 0; hl < HPP; ++hl) xprev[hl] = xcur[hl] = 0.f;
+    int hprev = 0;   // h base of the period the previous tile belongs to (the fake tile before the first one: dZ = 0, any valid rows)
+    // A slot is contracted in two halves one step group apart (read, then FMA + write a group later): the LDS latency stays off the
+    // MFMA chain.  Within a group the apply (write) precedes the next fetch (read), so slots that alias one word stay ordered.
+    float2 lv = make_float2(0.f, 0.f);
+    float* la = lrow;
+    float *abase = lrow, *awrap = lrow;
+    int symh = 0;
+    auto sym_period = [&](int hb) {
+      symh = hb + half;
+      abase = lrow + symh * FS;
+      awrap = abase - F * FS;
+    };
+    auto slot_fetch = [&](int tp, int rr) {
+      const int sp = 16 * tp + rr;
+      const int off = sp / JT + 2 * (sp % JT);   // compile-time after unrolling: f = (h + off + half) mod F, h + off + half < F + FR
+      la = (symh >= F - off ? awrap : abase) + off * FS;
+      lv = *reinterpret_cast<const float2*>(la);
+    };
+    auto slot_apply = [&](const f32x16& d, const float (&xpv)[HPP], int hb, int tp, int rr) {
+      const int sp = 16 * tp + rr;
+      const int hl = sp / JT, j = sp % JT;
+      const float dz = d[rr];
+      gx = fmaf(dz, lv.x, gx);
+      la[1] = fmaf(dz, xpv[hl], lv.y);
+      if (j == JT - 1) {
+        // h = hb + hl is complete: dX[m,h] += sum over both lane halves (one LDS add by the lower half; the row's own words only)
+        const float t = lane_halves_sum(gx);
+        gx = 0.f;
+        if (half == 0) __hip_atomic_fetch_add(lrow + (hb + hl) * FS + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    };
+    sym_period(hprev);
+    slot_fetch(P - 1, 0);
+#pragma unroll 1
+    for (int per = 0; per < periods; ++per) {
+      const int hbase = per * HPP;
+      // x[m, hbase + hl] from the LDS image (rows >= F hold zeros; FR >= periods * HPP)
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xcur[hl] = lrow[(hbase + hl) * FS];
+#pragma unroll
+      for (int tp = 0; tp < P; ++tp) {
+        const int t = per * P + tp;
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < NQ; ++s4) {
+          const f32x4s w = q[s4];
+          d = mfma32(w[0], greg[4 * s4 + 0], d);
+          d = mfma32(w[1], greg[4 * s4 + 1], d);
+          d = mfma32(w[2], greg[4 * s4 + 2], d);
+          d = mfma32(w[3], greg[4 * s4 + 3], d);
+          q[s4] = ldw(t + 1, s4);   // (the stream is allocated one tile past the last period)
+          // the previous tile's slots, one per step group in program order -- and NO scheduling barrier between the groups: the compiler
+          // then runs the MFMAs in long back-to-back bursts with the slot work in blocks between them, 0.250 ms; with every group
+          // pinned in place (a barrier here, as cin_dz3_kernel has it) 0.280; with each tile's 64 MFMAs and its 16 slots as two
+          // explicit blocks 0.268
+          if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, s4);
+          else slot_apply(dprev, xcur, hbase, tp - 1, s4);
+          if (s4 < 15) {
+            slot_fetch(tp == 0 ? P - 1 : tp - 1, s4 + 1);
+          } else {
+            if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
+            slot_fetch(tp, 0);                // first slot of this tile, applied in the first group of the next one
+          }
+        }
+        dprev = d;
+      }
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xprev[hl] = xcur[hl];
+      hprev = hbase;
+    }
+    // the last tile's slots
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      slot_apply(dprev, xprev, hprev, P - 1, rr);
+      if (rr < 15) slot_fetch(P - 1, rr + 1);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // dX rows of the wave are contiguous in dxT ([32 rows][F]): written cooperatively from the LDS image, whole lines per store
+  const float* img = smem + wave * 32 * 2 + 1;
+  const int nrow = min(32, M - wrow0);
+  float* dst = dxT + (long)wrow0 * F;
+  for (int idx = lane; idx < nrow * F; idx += 64) {
+    const int rr = idx / F, f = idx - rr * F;
+    const float v = img[f * FS + rr * 2];
+    dst[idx] = accumulate ? dst[idx] + v : v;
+  }
+}
+
+void cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const float* Wz1,
+                    const float* Wz2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods);
 
 }  // namespace fil

@@ -150,7 +150,8 @@ def merge_segments_by_point(segments, points):
 
     segments[i] belongs to layer L-1-i (segment 0 also holds the head); points = functional.cin_grad_ready_points(...) (L+1
     ordinals, [l] per layer).  Returns (merged segments, layer_of_event): merged segment j is reduced behind the grad_ready slot
-    of layer layer_of_event[j] -- the lowest layer of its group, whose slot is recorded when the whole group is final.  Every
+    of layer layer_of_event[j] -- the lowest layer of its group, whose slot is recorded when the whole group is final -- and the
+    merged segments come in the order their events fire.  Every
     collective costs tens of microseconds of stream plumbing whatever its size: with the fused tail the two top layers finish
     together and share one."""
     L = len(segments)
@@ -163,7 +164,10 @@ def merge_segments_by_point(segments, points):
         else:
             merged.append((lo, hi))
             layer_of_event.append(l)
-    return merged, layer_of_event
+    # issue order = readiness order: the merged quadratic tail finishes the FIRST layer's gradients before the top two layers'
+    # (points [1, 2, 2, 0]); a collective queued behind a later event would wait for it although its own data is final
+    order = sorted(range(len(merged)), key=lambda i: points[layer_of_event[i]])
+    return [merged[i] for i in order], [layer_of_event[i] for i in order]
 
 
 def allreduce_module_grads(module, group=None):

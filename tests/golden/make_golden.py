@@ -96,26 +96,53 @@ def attn_stack(tag, B, F, K, H, A, L, beta_shift=0.0):
 
 
 def label_encode():
+    """Index goldens from the REAL scikit-learn / pandas (the third-party code the reference calls, data_prepare.py:85-100): raw columns
+    as the product's front end receives them (raw_*: object arrays, None = missing), their str form, the encoded ids, vocabulary sizes."""
     import pandas as pd
     from sklearn.preprocessing import LabelEncoder
     rng = np.random.default_rng(synth.SEED)
-    cols, enc = {}, {}
+    cols, enc, rawout = {}, {}, {}
     raw = {
         "C1": rng.integers(0, 30, 64).astype(object),               # ints: '10' sorts before '2'
         "C2": rng.choice(["a", "B", "ab", "", "zz", "Ab"], 64).astype(object),
         "C3": np.where(rng.random(64) < 0.25, None, rng.integers(100, 120, 64).astype(object)),  # missing -> '-1'
+        "C4": np.where(rng.random(64) < 0.3, np.nan, rng.integers(0, 12, 64).astype(np.float64)),   # float column with NaN: '3.0', '10.0' < '2.0'
+        "C5": np.asarray([[7, "7", 7.5, None, "x", -1, "-1", True][i % 8] for i in rng.integers(0, 8, 64)], dtype=object),  # mixed types
     }
     for name, col in raw.items():
         s = pd.Series(col).fillna("-1").astype("str")       # data_prepare.py:91-92
         le = LabelEncoder()
         enc[name] = le.fit_transform(s).astype(np.int64)     # :93
         cols[name] = s.to_numpy().astype("U")
+        # the raw column in a form np.savez can hold without pickling: its repr tokens (n = None, f:<float>, i:<int>, b:<bool>, s:<str>)
+        rawout[name] = np.asarray(["n" if v is None else ("f:%r" % float(v) if isinstance(v, float) else ("b:%d" % v if isinstance(v, bool) else
+                                   ("i:%d" % v if isinstance(v, (int, np.integer)) else "s:" + str(v)))) for v in col]).astype("U")
     vocab = [int(enc[n].max()) + 1 for n in raw]
     tables = [rng.standard_normal((v, 8)).astype(np.float32) for v in vocab]
     idx = np.stack([enc[n] for n in raw], 1)
     gathered = np.stack([tables[f][idx[:, f]] for f in range(len(vocab))], 1)
-    save("label_encode.npz", idx=idx, gathered=gathered, vocab=np.asarray(vocab),
-         table=np.concatenate(tables, 0), **{"col_" + n: cols[n] for n in raw})
+    save("label_encode.npz", idx=idx, gathered=gathered, vocab=np.asarray(vocab), names=np.asarray(list(raw)).astype("U"),
+         table=np.concatenate(tables, 0), **{"col_" + n: cols[n] for n in raw}, **{"raw_" + n: rawout[n] for n in raw})
+
+
+def dense_minmax():
+    """Dense-column goldens from the real pandas / scikit-learn (data_prepare.py:294-301): fillna(mode) then MinMaxScaler(0, 1)."""
+    import pandas as pd
+    from sklearn.preprocessing import MinMaxScaler
+    rng = np.random.default_rng(synth.SEED + 1)
+    n = 48
+    df = pd.DataFrame({
+        "I1": rng.integers(0, 50, n).astype(np.float64),
+        "I2": rng.standard_normal(n) * 1e3 + 5e4,
+        "I3": np.full(n, 3.25),                                               # constant column: scale 1
+        "I4": np.where(rng.random(n) < 0.2, np.nan, rng.integers(0, 6, n).astype(np.float64)),   # missing -> the (smallest) mode
+        "I5": rng.integers(-5, 5, n).astype(np.float64) * 1e-9,
+    })
+    filled = pd.DataFrame({fea: df[fea].fillna(df[fea].mode()[0]) for fea in df})
+    out = MinMaxScaler(feature_range=(0, 1)).fit_transform(filled)
+    # (float64 kept: this fixture is compared bit for bit, not to a tolerance)
+    np.savez_compressed(os.path.join(OUT, "dense_minmax.npz"), raw=df.to_numpy(np.float64), names=np.asarray(list(df)).astype("U"),
+                        out=np.asarray(out, np.float64))
 
 
 if __name__ == "__main__":
@@ -130,3 +157,4 @@ if __name__ == "__main__":
     attn_stack("c5_small", 2, 200, 16, 4, 16, 3)   # config 5: 3 layers, 4 heads, F=200, K=16, A=16, small batch
     attn_stack("c5_nokink", 2, 200, 16, 4, 16, 3, beta_shift=4.0)   # ... with every output away from the ReLU kink
     label_encode()
+    dense_minmax()
