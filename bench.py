@@ -368,7 +368,7 @@ def pmc_traffic(scope):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
-    m = re.match(r"cin_(fwd|bwd_dz|bwd_dw)_(l\d|tail)$", scope)
+    m = re.match(r"cin_(fwd|bwd_dz|bwd_dw)_(l\d|tail|q)$", scope)
     if not files or not m:
         return None, None
     with open(files[-1]) as fh:
@@ -383,6 +383,10 @@ def _gemm_launch_of(per, kind, layer):
     GEMMs in a fixed order: forward l1, l2, .., tail; backward tail, .., l2, l1 -- and a kernel launched several times per step appears
     as '<name> #slot' entries.  The quadratic tail runs the FIRST layer's kernels a second time (forward: second launch; backward:
     first), the fused tail has kernels of its own (cin_tail_*)."""
+    if layer == "q":   # merged quadratic tail (cin_qmerge.h): one weight-gradient / one data-gradient launch for layer 1 + the quadratic form
+        name = {"bwd_dw": "cin_dwq_kernel", "bwd_dz": "cin_dz2_kernel"}.get(kind)
+        hits = sorted(k for k in per if name is not None and k.startswith(name))
+        return hits[0] if hits else None
     prefixes = {"fwd": ("cin_fwd3_kernel", "cin_tail_fwd_kernel"), "bwd_dz": ("cin_dz3_kernel", "cin_tail_dz_kernel"),
                 "bwd_dw": ("cin_dw3_kernel", "cin_tail_dw_kernel")}[kind]
     hits = sorted((v["first_dispatch"], k) for k, v in per.items() if k.startswith(prefixes) and not _split_instance(k))
@@ -580,7 +584,7 @@ def main():
     prof_on = ns["profile"]
     if prof_on:
         from ml_function_amd import _lib
-    GEMMS = "cin_fwd_,cin_bwd_dw_,cin_bwd_dz_"     # the MFMA GEMM scopes: _l1 (pair-symmetric first layer), _l2.., _tail (fused tail)
+    GEMMS = "cin_fwd_,cin_bwd_dw_,cin_bwd_dz_"     # the MFMA GEMM scopes: _l1 (pair-symmetric first layer), _l2.., _tail, _q (merged quadratic tail)
     for _ in range(args.warmup):
         step()
     # An event pair costs ~5-10 us of stream time (all six GEMM scopes: the step is 5 % slower, all 15 scopes: 7 %), so the timed
@@ -666,6 +670,31 @@ def main():
         fence()
         prof_all = _lib.profile_end()
 
+    # the same step replayed from a HIP graph (the C ABI neither allocates nor synchronises: capturable as it stands).  Reported beside
+    # the headline, never as it: `value` stays the eagerly launched step.
+    graph_ms = None
+    if device.type == "cuda" and not use_dist and not args.stub:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    compute(args.cin_mode)
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                compute(args.cin_mode)
+            for _ in range(max(2, args.warmup)):
+                gr.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                gr.replay()
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        except Exception as e:   # (a capture problem must not take the headline line down with it)
+            print("bench.py: HIP-graph replay of the headline step failed: %r" % (e,), file=sys.stderr)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         global_batch = world * shape["batch"] if args.scaling == "weak" else ns["shape"]["batch"]
@@ -721,6 +750,8 @@ def main():
             res["executed_flops_per_step"] = exe_step
             res["algorithmic_flops_per_step"] = algo_step
             res["executed_frac"] = exe_step / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        if graph_ms is not None:
+            res["hipgraph_replay_ms_per_step"] = graph_ms
         if rccl is not None:
             res["rccl"] = rccl
         if split is not None:

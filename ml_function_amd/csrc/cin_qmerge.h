@@ -341,9 +341,16 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     auto ldw = [&](int t, int s4) {   // tile t is [32 slot rows][128]; lane (r, half) reads row r, columns half*64 + 4*s4 .. +3
       return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo + 16 * s4, t * (32 * 128 * 4), 0));
     };
-    f32x4s q[NQ];
+    // queue depth in step groups (half a tile ahead: 8 x 256 cycles covers the L2 latency; the full tile, 16, measured 7 us slower --
+    // 32 more registers at the 256-register limit of two waves per SIMD)
+#ifdef FIL_ABL_DZ2_QD
+    constexpr int QD = FIL_ABL_DZ2_QD;
+#else
+    constexpr int QD = 8;
+#endif
+    f32x4s q[QD];
 #pragma unroll
-    for (int s4 = 0; s4 < NQ; ++s4) q[s4] = ldw(0, s4);
+    for (int s4 = 0; s4 < QD; ++s4) q[s4] = ldw(0, s4);
     // the lane's half row: 16-byte loads, all in flight together
     float greg[64];
     {
@@ -414,12 +421,12 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
         for (int i = 0; i < 16; ++i) d[i] = 0.f;
 #pragma unroll
         for (int s4 = 0; s4 < NQ; ++s4) {
-          const f32x4s w = q[s4];
+          const f32x4s w = q[s4 % QD];
           d = mfma32(w[0], greg[4 * s4 + 0], d);
           d = mfma32(w[1], greg[4 * s4 + 1], d);
           d = mfma32(w[2], greg[4 * s4 + 2], d);
           d = mfma32(w[3], greg[4 * s4 + 3], d);
-          q[s4] = ldw(t + 1, s4);   // (the stream is allocated one tile past the last period)
+          q[s4 % QD] = s4 + QD < NQ ? ldw(t, s4 + QD) : ldw(t + 1, s4 + QD - NQ);   // (the stream is allocated one tile past the last period)
           // the previous tile's slots, one per step group in program order -- and NO scheduling barrier between the groups: the compiler
           // then runs the MFMAs in long back-to-back bursts with the slot work in blocks between them, 0.250 ms; with every group
           // pinned in place (a barrier here, as cin_dz3_kernel has it) 0.280; with each tile's 64 MFMAs and its 16 slots as two
