@@ -32,9 +32,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256
 PEAK_F16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md dense fp16/bf16 MFMA peak (16x the fp32 matrix rate)
 
 
-def make_inputs(rank, device, batch=B_PER_GPU, conv=CONV, fields=F, embed=K):
+def make_inputs(rank, device, batch=B_PER_GPU, conv=CONV, fields=F, embed=K, param_batch=None):
     from ml_function_amd import synth
-    c = synth.cin_case(batch, fields, embed, conv, seed=synth.SEED)            # parameters: identical on every rank
+    # parameters: identical on every rank -- drawn for `param_batch` samples (the generator draws the inputs first, so the weights
+    # depend on the batch size: with uneven strong-scaling shards every rank must ask for the same one, the global batch)
+    c = synth.cin_case(param_batch or batch, fields, embed, conv, seed=synth.SEED)
     d = synth.cin_case(batch, fields, embed, conv, seed=synth.SEED + 1 + rank)  # data shard: per rank
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
     return dict(x=t(d["x"]), g=t(d["g"][:, 0]), Ws=[t(w) for w in c["Ws"]], bs=[t(b) for b in c["bs"]],
@@ -217,12 +219,17 @@ def side_benchmark(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    _lib.profile_begin()
+    # the timed loop carries no profiler events (an event pair is 5-10 us of stream time per kernel: for these two-kernel steps that
+    # was a third of the "eager" time); the per-kernel table comes from a second, untimed pass
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    _lib.profile_begin()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
     prof = _lib.profile_end()
     graph_ms = None
     if args.graph:
@@ -308,6 +315,10 @@ def side_workloads(args):
         a.steps, a.warmup, a.batch = 10, 3, 0
         for k, v in kw.items():
             setattr(a, k, v)
+        if a.workload in ("dcn", "fm"):      # launch-bound (0.05 ms of kernels per step): the eager time is host time, which needs
+            a.steps, a.warmup = 200, 50      # more than ten steps to settle (10 steps read 0.06-0.33 ms on one box)
+        elif a.workload in ("deepfm", "xdeepfm"):
+            a.steps, a.warmup = 30, 10
         try:
             r = deepfm_benchmark(a) if a.workload in ("deepfm", "xdeepfm") else side_benchmark(a)
             e = {"workload": r["config"]["workload"], "ms_per_step": round(r["ms_per_step"], 4), "samples_per_s": round(r["value"], 1),
@@ -483,7 +494,10 @@ def main():
     ap.add_argument("--layers", type=int, default=3, help="AutoInt side benchmark: stacked interacting layers (config 5: 3)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: B=4096 per GPU (default); strong: global B=4096 split over the GPUs")
-    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole bucket after the backward")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole bucket after the backward (= --overlap off)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="layer-wise all-reduce on a side stream behind the backward's grad-ready events: on / off / auto = on when "
+                         "there is a second rank to exchange with (on one rank the two stream hops cost ~0.02 ms and hide nothing)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group and run the collectives even at world size 1 (plumbing check on one GPU)")
     ap.add_argument("--stub", default="", help=argparse.SUPPRESS)   # tests: module with install(namespace) -> CPU/gloo stand-ins
@@ -502,6 +516,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.overlap == "off" or (args.overlap == "auto" and world == 1):
+        args.no_overlap = True
     import torch.distributed as dist
     from ml_function_amd import dp
     ns = dict(backend="nccl", device=None, Fn=None, profile=True, shape=dict(batch=B_PER_GPU, conv=CONV, fields=F, embed=K))
@@ -524,12 +540,14 @@ def main():
         with stdout_to_stderr():
             dist.init_process_group(ns["backend"], rank=rank, world_size=world, **kw)
             dist.barrier()      # first collective: the communicator (and RCCL's banner) comes up here
+        if dist.get_world_size() != args.gpus:   # the line below claims n_gpus = --gpus: never print it for another group size
+            sys.exit("bench.py --gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
 
     shape = dict(ns["shape"])
     if args.scaling == "strong":
         lo, hi = dp.shard_bounds(shape["batch"], rank, world)
         shape["batch"] = hi - lo
-    inp = make_inputs(rank, device, **shape)
+    inp = make_inputs(rank, device, param_batch=ns["shape"]["batch"], **shape)
     flat, grads, segments = make_bucket(inp, device)
     L = len(inp["Ws"])
     # one collective per POINT of the backward at which gradients become final (fil.h fil_cin_grad_ready_points: with the fused

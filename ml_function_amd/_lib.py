@@ -117,8 +117,10 @@ def ptr(t):
 
 
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device, as an integer (the raw getter: no Stream object is built --
+    this runs once per C-ABI call)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def int_array(vals):

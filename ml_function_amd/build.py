@@ -33,7 +33,8 @@ def _deps_mtime():
 def _flags_changed(obj_dir, flags):
     """The object cache is keyed on source mtimes; the compiler flags (FIL_HIPCC_FLAGS changes codegen) are remembered in a
     stamp file next to the objects, and a mismatch rebuilds everything -- a diagnostic build (e.g. -DFIL_ATTN_STAMPS) can then
-    never linger in libfil_hip.so under a later plain build."""
+    never linger in libfil_hip.so under a later plain build.  Returns (changed, stamp path, wanted contents); build() writes the
+    stamp once the rebuild has succeeded."""
     stamp = os.path.join(obj_dir, "flags.stamp")
     want = " ".join(flags)
     try:
@@ -41,15 +42,21 @@ def _flags_changed(obj_dir, flags):
             same = fh.read() == want
     except OSError:
         same = not any(f.endswith(".o") for f in os.listdir(obj_dir))   # fresh directory: nothing stale to distrust
-    if not same:
-        with open(stamp, "w") as fh:
-            fh.write(want)
-    return not same
+    return (not same), stamp, want
 
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    force = force or _flags_changed(OBJ, FLAGS + [k + "=" + " ".join(v) for k, v in sorted(FILE_FLAGS.items())])
+    changed, stamp, want = _flags_changed(OBJ, FLAGS + [k + "=" + " ".join(v) for k, v in sorted(FILE_FLAGS.items())])
+    if changed:
+        # objects built with other flags are removed BEFORE anything is recompiled and the stamp is written only after every compile
+        # job has succeeded: an interrupted forced rebuild can then never leave old-flag objects behind a matching stamp
+        force = True
+        for f in os.listdir(OBJ):
+            if f.endswith(".o"):
+                os.remove(os.path.join(OBJ, f))
+        if os.path.exists(stamp):
+            os.remove(stamp)
     hdr_m = _deps_mtime()
     jobs = []
     objs = []
@@ -73,6 +80,9 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
+    if changed or not os.path.exists(stamp):
+        with open(stamp, "w") as fh:
+            fh.write(want)
     if jobs or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -108,7 +108,7 @@ class data_pipeline:
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
         # (the copy stream must not share a hardware queue with the compute stream, or the copies queue up behind its kernels)
-        stream = independent_stream(self.device) if self.device is not None and self.device.type == "cuda" else None
+        stream = independent_stream(self.device, tag="data_pipeline") if self.device is not None and self.device.type == "cuda" else None
 
         def produce():
             try:

@@ -85,7 +85,7 @@ class LayerwiseAllReduce:
         self.cuda = flat.is_cuda
         self.events = [torch.cuda.Event() for _ in self.segments] if self.cuda else [None] * len(self.segments)
         # (a stream that really runs beside the compute stream: one sharing its hardware queue would stall it at every wait)
-        self.side = independent_stream(flat.device) if self.cuda else None
+        self.side = independent_stream(flat.device, tag="grad_allreduce") if self.cuda else None
         self._works = []
 
     def active(self):

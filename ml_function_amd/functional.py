@@ -32,6 +32,29 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# Scratch workspaces (NOT the `saved` buffers, which live until the backward) are kept per (device, stream, call site) and only ever
+# grow: consecutive calls on one stream are ordered by the stream, so they can share the bytes, and a layer call no longer pays an
+# allocator round trip per direction.  Under stream capture the cache is left alone (a block allocated there belongs to the graph's
+# private pool): the call allocates as before.
+_WS_CACHE = {}
+
+
+def _scratch(nbytes, device, tag):
+    nbytes = max(int(nbytes), 256)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (device, stream_ptr(), tag)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS_CACHE[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def release_scratch():
+    """Drop every cached scratch workspace (they are re-created on demand)."""
+    _WS_CACHE.clear()
+
+
 # --------------------------------------------------------------------------------------------- A1  FM
 class _FmFn(torch.autograd.Function):
     @staticmethod
@@ -131,7 +154,7 @@ class _DcnFn(torch.autograd.Function):
         dw = torch.empty_like(w)
         db = torch.empty_like(b)
         nws = lib.fil_dcn_bwd_workspace_bytes(B, D, L)
-        ws = _workspace(nws, x.device)
+        ws = _scratch(nws, x.device, "dcn_bwd")
         check(lib.fil_dcn_bwd(ptr(x), ptr(w), ptr(b), ptr(s), ptr(g), ptr(dx), ptr(dw), ptr(db), B, D, L, ptr(ws), nws,
                               stream_ptr()), "fil_dcn_bwd")
         return dx, dw, db
@@ -182,7 +205,7 @@ def cin_forward_raw(x, Ws, bs, dense_w, dense_b, output_dim=1, mode=0, xt=None):
     nws = lib.fil_cin_fwd_workspace_bytes(B, F, K, L, Harr)
     if nws == 0 and B > 0:
         raise FilError("cin: %s" % lib.fil_last_error().decode())
-    ws = _workspace(nws, x.device)
+    ws = _scratch(nws, x.device, "cin_fwd")
     pooled = torch.empty((B, L * K), dtype=torch.float32, device=x.device)
     out = torch.empty((B, 1), dtype=torch.float32, device=x.device) if output_dim == 1 else None
     check(lib.fil_cin_fwd(ptr(xt if xt is not None else x), ptr_array(Ws), ptr_array(bs), ptr(dense_w), ptr(dense_b), ptr(out),
@@ -205,7 +228,7 @@ def cin_backward_raw(x, Ws, bs, dense_w, pooled, saved, g, output_dim=1, mode=0,
                      ddw=torch.empty((L * K, 1), dtype=torch.float32, device=x.device) if output_dim == 1 else None,
                      ddb=torch.empty((1,), dtype=torch.float32, device=x.device) if output_dim == 1 else None)
     nws = lib.fil_cin_bwd_workspace_bytes(B, F, K, L, Harr)
-    ws = _workspace(nws, x.device)
+    ws = _scratch(nws, x.device, "cin_bwd")
     evs = None
     if ready_events is not None:
         if len(ready_events) != L + 1:
@@ -326,7 +349,7 @@ class _AttnFn(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if has_ln else None
         have_saved = int((not has_ln or av_saved is not None) and (not fuse_relu or y_saved is not None))
         nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A, have_saved)
-        ws = _workspace(nws, x.device)
+        ws = _scratch(nws, x.device, "attn_bwd")
         check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(y_saved),
                                ptr(av_saved), ptr(dx),
                                ptr(dWq), ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps,
@@ -460,7 +483,9 @@ def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None):
     row_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
     check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
     # (n_rows = rows of the concatenated table: when the global row ids fit 31 bits, 32-bit keys halve the radix passes of the sort)
-    if n_rows is not None and n_rows < 2 ** 31 and row_ids.numel() > 0:
+    # -- only with a range check: `sizes` guarantees every id in [-1, n_rows); unchecked ids could fall outside 32 bits, wrap in the
+    # cast, sort out of place and merge with valid rows)
+    if sizes is not None and n_rows is not None and n_rows < 2 ** 31 and row_ids.numel() > 0:
         s32, perm = torch.sort(row_ids.to(torch.int32), stable=True)
         out = (s32.to(torch.int64), perm)
     else:

@@ -1,3 +1,4 @@
+from ..capture import capture_step
 from .base import Layer
 from .behavior_layer import MultHeadAttentionLayer, ProductAttentionLayer
 from .core_layer import (AlignLayer, Dense, DnnLayer, HiddenLayer, IntraViewPoolingLayer, MergeScoreLayer, ResActivateLayer, ScoreLayer,
@@ -5,7 +6,7 @@ from .core_layer import (AlignLayer, Dense, DnnLayer, HiddenLayer, IntraViewPool
 from .interactive_layer import (CIN, AttentionBaseLayer, CrossLayer, ExtractLayer, FmLayer, InnerLayer, IPnnLayer, LinearLayer,
                                 OPnnLayer, SparseEmbed)
 
-__all__ = ["Layer", "InnerLayer", "FmLayer", "CrossLayer", "CIN", "SparseEmbed", "ProductAttentionLayer",
+__all__ = ["capture_step", "Layer", "InnerLayer", "FmLayer", "CrossLayer", "CIN", "SparseEmbed", "ProductAttentionLayer",
            "MultHeadAttentionLayer", "StackLayer", "ScoreLayer", "MergeScoreLayer", "HiddenLayer", "ResActivateLayer",
            "DnnLayer", "Dense", "IPnnLayer", "OPnnLayer", "LinearLayer", "AttentionBaseLayer", "ExtractLayer",
            "IntraViewPoolingLayer", "AlignLayer"]

@@ -33,14 +33,28 @@ def shares_queue_with_current(stream, device=None):
     return not alone
 
 
-def independent_stream(device=None, tries=8, priority=0):
-    """A new stream on `device` that does not share a hardware queue with the current stream (the first of `tries` candidates
-    that passes shares_queue_with_current; the last candidate if none does -- correctness never depends on it)."""
+_INDEPENDENT = {}   # (device index, priority, current stream, tag) -> the stream found by the probe: the answer cannot change
+
+
+def independent_stream(device=None, tries=8, priority=0, tag=None):
+    """A stream on `device` that does not share a hardware queue with the current stream (the first of `tries` candidates that
+    passes shares_queue_with_current; the last candidate if none does -- correctness never depends on it).  The probe drains the
+    device (a >= 2 ms sleep kernel per candidate), so its result is kept per (device, current stream, tag): a caller that asks again
+    -- every epoch's data iterator, every reducer -- gets its stream back; different tags get different streams.  Under stream
+    capture no probe can run: a plain new stream is returned."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, priority, torch.cuda.current_stream(dev).cuda_stream, tag)
+    if key in _INDEPENDENT:
+        return _INDEPENDENT[key]
+    if torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=dev, priority=priority)
     cand = None
     with torch.cuda.device(dev):
         for _ in range(max(1, tries)):
             cand = torch.cuda.Stream(device=dev, priority=priority)
-            if not shares_queue_with_current(cand, dev):
-                return cand
+            if cand not in _INDEPENDENT.values() and not shares_queue_with_current(cand, dev):
+                break
+    _INDEPENDENT[key] = cand
     return cand

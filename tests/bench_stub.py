@@ -39,4 +39,7 @@ def _on_done(flat, rank, world):
 
 
 def install(ns):
-    ns.update(backend="gloo", device=torch.device("cpu"), Fn=StubFn, profile=False, shape=dict(SHAPE), on_done=_on_done)
+    shape = dict(SHAPE)
+    if os.environ.get("FIL_STUB_BATCH"):       # tests: a global batch that the ranks cannot share evenly
+        shape["batch"] = int(os.environ["FIL_STUB_BATCH"])
+    ns.update(backend="gloo", device=torch.device("cpu"), Fn=StubFn, profile=False, shape=shape, on_done=_on_done)

@@ -184,6 +184,39 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert r.returncode != 0
 
 
+def test_bench_strong_scaling_with_an_uneven_shard(tmp_path):
+    """`bench.py --gpus 2 --scaling strong` on a global batch of 13: the ranks take 7 and 6 samples (dp.shard_bounds), the line reports
+    the GLOBAL batch once (not 2 x 13), per-rank times for both ranks, the exposed all-reduce time, and the reduced bucket is the sum of
+    the two uneven shards' gradients on both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FIL_STUB_OUT=str(tmp_path), FIL_STUB_BATCH="13", PYTHONPATH=root + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", "strong",
+                        "--stub", "tests.bench_stub"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["global_batch"] == 13
+    assert res["value"] == pytest.approx(13 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"]), rel=1e-6)
+    rc = res["rccl"]
+    assert rc["world_size_seen"] == 2 and len(rc["ms_per_step_per_rank"]) == 2
+    assert rc["ms_per_step_min_rank"] <= rc["ms_per_step_max_rank"] and "exposed_allreduce_ms" in rc and rc["allreduce_alone_ms"] > 0
+    from tests import bench_stub
+    f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
+    assert np.array_equal(f0, f1)
+    sh = bench_stub.SHAPE
+    par = synth.cin_case(13, sh["fields"], sh["embed"], sh["conv"], seed=synth.SEED)
+    want = None
+    for rank, nb in enumerate((7, 6)):
+        d = synth.cin_case(nb, sh["fields"], sh["embed"], sh["conv"], seed=synth.SEED + 1 + rank)
+        _, dWs, dbs, ddw, ddb = closed.cin_bwd(d["x"], par["Ws"], par["bs"], par["dense_w"], d["g"][:, :1])
+        v = np.concatenate([ddw.reshape(-1), ddb.reshape(-1)] + [np.concatenate([dWs[l].reshape(-1), dbs[l].reshape(-1)]) for l in (1, 0)])
+        want = v if want is None else want + v
+    assert np.abs(f0 - want).max() / np.abs(want).max() < 1e-5
+
+
 def _sparse_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

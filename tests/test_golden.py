@@ -254,10 +254,11 @@ def test_gpu_sparse_embed_bit_exact():
     emb = SparseEmbed(infos, use_flatten=False)
     idx = torch.tensor(g["idx"], device="cuda")
     emb._build_device = idx.device
-    emb.build([(64, 1)] * 3)
+    nf = len(g["vocab"])
+    emb.build([(64, 1)] * nf)
     emb.built = True
     with torch.no_grad():
         emb.embeddings.copy_(dev(g["table"]))
-    outs = emb([idx[:, f:f + 1] for f in range(3)])
-    assert len(outs) == 3 and outs[0].shape == (64, 1, 8)
+    outs = emb([idx[:, f:f + 1] for f in range(nf)])
+    assert len(outs) == nf and outs[0].shape == (64, 1, 8)
     assert np.array_equal(torch.cat(outs, 1).detach().cpu().numpy(), g["gathered"])
