@@ -309,7 +309,7 @@ static size_t dw_part_floats(const CinShape& s) {
   const int csym = s.F * (s.F / 2 + 1);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym + s.F, s.H[0]).splits * (csym + s.F) * s.H[0]);   // quadratic tail: pairs + F single-field rows
-  if (s.L == 3) pmax = std::max(pmax, (size_t)cin_dwq_plan(s.M(), csym + s.F, cu_count()).splits * (csym + s.F) * 256);   // ... merged: 256 columns
+  if (s.L == 3) pmax = std::max(pmax, (size_t)cin_dwq_plan(s.M(), csym + s.F, cu_count()).pairs * (csym + s.F) * 256);   // ... merged: 256 columns
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
   const TailGeom g = tail_geom(s);
@@ -787,7 +787,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     {
       ProfScope ps("cin_bwd_dw_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
       const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
-      hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth>), dim3((dp.wgs + 7) / 8 * 8), dim3(kCinThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD,
+      hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth>), dim3((dp.wgs + 7) / 8 * 8), dim3(kDwqThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD,
                          dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
     }
     FIL_CHECK_LAUNCH();
@@ -795,7 +795,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       // fixed-order sums of the partials -> dW1 (both rows of a pair), dT, v^T; + dbias1 from the column sums cin_last_bwd2_kernel left
       ProfScope ps("cin_reduce_dw", st);
       const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
-      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F) * 4 + cdiv(H[0], 64)), dim3(256), 0, st, part, dp.splits, F, symD, H[0], Hpp, dW[0], qt_dT,
+      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F) * 4 + cdiv(H[0], 64)), dim3(256), 0, st, part, dp.pairs, F, symD, H[0], Hpp, dW[0], qt_dT,
                          vlast, small, ncol, dbias[0]);
     }
     FIL_CHECK_LAUNCH();

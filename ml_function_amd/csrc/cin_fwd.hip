@@ -62,7 +62,7 @@ template <int JT>
 static void last_bwd2(hipStream_t st, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn, const float* dP,
                       int ldp, const float* dPprev, float* GprevT, int HSp, float* dxT, int M, int F, int K, int Hp, const float* Radd, int HSr,
                       const float* dPadd, float* colpart) {
-  const size_t sh = (size_t)Hp * F * sizeof(float);
+  const size_t sh = ((size_t)((Hp * F + 3) & ~3) + 4 * kLast2Stage) * sizeof(float);   // wsum | four waves' staging areas
   if (sh > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_last_bwd2_kernel<JT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   hipLaunchKernelGGL((cin_last_bwd2_kernel<JT>), dim3((M + 127) / 128), dim3(kCinThreads), sh, st, xT, xpT, xps, wsum, wsn, dP, ldp, dPprev,

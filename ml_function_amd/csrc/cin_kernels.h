@@ -1923,6 +1923,8 @@ static __global__ __launch_bounds__(256) void cin_fill_rows_kernel(const float* 
 // Wave = 32 rows.  wsn is wsum in the forward kernel's operand layout (cin_wsum_wsn_kernel) so lane r owns columns
 // 4r..4r+3 of a chunk and G^{L-1} leaves as 16-byte stores; for u the reduction order is permuted (free in a GEMM)
 // so that wave half `half` takes h = 4q + 2*half + {0,1}: one 8-byte load of its own row per two steps.
+constexpr int kLast2Ld = 66;                  // floats between staged rows of x^{L-1} (64 columns + 2)
+constexpr int kLast2Stage = 32 * kLast2Ld;    // per-wave staging floats: 32 rows x 64 columns of x^{L-1}, or the 32 rows of x (F <= 64)
 template <int JT>
 __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                             const float* __restrict__ wsum, const float* __restrict__ wsn,
@@ -1934,7 +1936,7 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
   // colpart != nullptr: colpart[blockIdx][n < Hp] = sum over this workgroup's 128 rows of the G^{L-1} it writes (the partial
   // column sums of the next layer's dbias: cin_colsum3_kernel's output without its pass over G)
   __shared__ float colred[4][128];
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // wsum [Hp][F]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // wsum [Hp][F] | per wave: staging [kLast2Stage]
   for (int i = threadIdx.x; i < Hp * F; i += 256) smem[i] = wsum[i];
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1942,11 +1944,26 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
   const int wrow0 = (blockIdx.x * 4 + wave) * 32;
   if (wrow0 >= M && colpart == nullptr) return;   // (with column sums every wave stays for the workgroup barriers; its rows are masked)
   const long mq = min(wrow0 + r, M - 1);
+  // A lane needs ITS ROW of x (and, below, of x^{L-1}): read straight from memory that is one load instruction per element with 64
+  // lanes in 64 different lines (20 + 32 such loads per wave kept the vector memory pipeline busier than the bytes they moved).
+  // The wave's 32 rows are contiguous in memory: they come in through LDS by coalesced 16-byte loads, the lanes read their rows there.
+  float* stg = smem + ((Hp * F + 3) & ~3) + wave * kLast2Stage;
+  const int nrow = min(32, M - wrow0);   // (<= 0: a wave past the end that only stays for the workgroup barriers)
+  if (nrow > 0) {
+    const float4* src = reinterpret_cast<const float4*>(xT + (long)wrow0 * F);   // 32 rows x F floats = a multiple of 16 bytes from an aligned start
+    const int n4 = nrow * F / 4, tail = nrow * F - 4 * n4;
+    for (int i = lane; i < n4; i += 64) *reinterpret_cast<float4*>(stg + 4 * i) = src[i];
+    if (lane < tail) stg[4 * n4 + lane] = xT[(long)wrow0 * F + 4 * n4 + lane];
+  }
+  __builtin_amdgcn_wave_barrier();
   float xr[JT];
+  {
+    const float* xrow = stg + min(r, max(nrow, 1) - 1) * F;
 #pragma unroll
-  for (int j = 0; j < JT; ++j) {
-    const int f = 2 * j + half;
-    xr[j] = f < F ? xT[mq * F + f] : 0.f;
+    for (int j = 0; j < JT; ++j) {
+      const int f = 2 * j + half;
+      xr[j] = (f < F && nrow > 0) ? xrow[min(f, F - 1)] : 0.f;
+    }
   }
   float dpr[16], dppr[16], dpa[16];
 #pragma unroll
@@ -2029,15 +2046,34 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
   f32x16 u0, u1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) u0[i] = u1[i] = 0.f;
-  const float* xprow = xpT + mq * xps + 2 * half;   // columns >= Hp of a feature map are zero (and xps >= Hp + pad)
   const bool two = F > 32;
   const int quads = (Hp + 3) >> 2;
 #pragma unroll 1
   for (int q0 = 0; q0 < quads; q0 += 16) {
-    // the lane's row segment first (16 independent 8-byte loads in flight), then the MFMA steps
-    float2 av[16];
+    // 64 columns of the wave's 32 rows of x^{L-1} through LDS: eight coalesced 16-byte loads per lane (a quarter row per 16 lanes),
+    // rows kLast2Ld floats apart (8-byte aligned, conflict-free for the 8-byte row reads); columns >= Hp of a feature map are zero
+    __builtin_amdgcn_wave_barrier();   // (the previous reads of the staging area are done)
+    {
+      float4 v[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) av[i] = q0 + i < quads ? *reinterpret_cast<const float2*>(xprow + 4 * (q0 + i)) : make_float2(0.f, 0.f);
+      for (int i = 0; i < 8; ++i) {
+        const int row = (lane >> 4) + 4 * i, c4 = lane & 15;
+        const long mm = min(wrow0 + row, M - 1);
+        v[i] = 4 * q0 + 4 * c4 < xps ? *reinterpret_cast<const float4*>(xpT + mm * xps + 4 * q0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (lane >> 4) + 4 * i, c4 = lane & 15;
+        float* d = stg + row * kLast2Ld + 4 * c4;
+        *reinterpret_cast<float2*>(d) = make_float2(v[i].x, v[i].y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v[i].z, v[i].w);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float2 av[16];
+    const float* xprow = stg + r * kLast2Ld + 2 * half;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) av[i] = q0 + i < quads ? *reinterpret_cast<const float2*>(xprow + 4 * i) : make_float2(0.f, 0.f);
     // B operands (LDS) four steps at a time ahead of their MFMAs; out-of-range rows / fields read a clamped word and are
     // masked with an AND (read -> wait -> MFMA per step exposed the LDS latency at every step)
 #pragma unroll

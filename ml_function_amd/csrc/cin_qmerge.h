@@ -26,69 +26,87 @@ namespace fil {
 //   A [c][m] = xe[m,h_c] xe[m,f_c]  (h_c = F, the ones column, for the single-field rows)      -> columns   0..127 (x G1):  dW1 pairs
 //   A'[c][m] = A[c][m] * (c < Cp ? dP_L[m] : dP_p[m])                                          -> columns 128..255 (x x1):  dT pairs | v^T
 // i.e. the scale of the quadratic form sits on the generated operand (one more gathered dword and multiply per step), nothing of
-// size [M, 128] is written for it.  Work: a workgroup = 4 channel tiles of one row split (its waves share the B rows through L1);
-// the tiles left over after the last full group of four (26 tiles at F = 39: 2) form workgroups of their own in which the spare
-// waves take further row splits, so every wave of the grid carries the same number of steps.
+// size [M, 128] is written for it.  Work: a workgroup = 8 waves = 4 channel tiles x the two row splits of a pair (the four waves of
+// a split share its B rows through L1; the two waves of a tile fold their accumulators through LDS into ONE partial); the tiles left
+// over after the last full group of four (26 tiles at F = 39: 2) form workgroups of their own in which the spare waves take further
+// pairs, so every wave of the grid carries the same number of steps.
 constexpr int kDwqDepth = 6;
+constexpr int kDwqThreads = 512;   // 8 waves: 4 channel tiles x 2 row splits
 struct DwqPlan {
-  int tiles, ncol_full, rem, splits, rows_per_split, wgs_full, wgs;
+  int tiles, ncol_full, rem, splits, pairs, rows_per_split, wgs_full, wgs;
 };
-inline int cin_dwq_rem_wgs(int rem, int splits) { return rem == 0 ? 0 : (rem == 1 ? (splits + 3) / 4 : (rem == 2 ? (splits + 1) / 2 : splits)); }
+// leftover workgroups for `pairs` pairs of row splits: rem = 1 tile: 4 pairs per workgroup, 2 tiles: 2 pairs, 3 tiles: 1 pair (2 idle waves)
+inline int cin_dwq_rem_wgs(int rem, int pairs) { return rem == 0 ? 0 : (rem == 1 ? (pairs + 3) / 4 : (rem == 2 ? (pairs + 1) / 2 : pairs)); }
 inline DwqPlan cin_dwq_plan(long M, int C, int cus) {
   DwqPlan p;
   p.tiles = (C + 31) / 32;
   p.ncol_full = p.tiles / 4;
   p.rem = p.tiles % 4;
   const long unit = 2 * kDwqDepth;
-  const long slots = 2L * cus;                           // two workgroups (two waves per SIMD) per CU, all resident at once
+  const long slots = cus;                                // one 8-wave workgroup (two waves per SIMD) per CU, all resident at once
   int best = 1;
-  for (int s = 1; s <= 1024; ++s) {
+  for (int s = 1; s <= 512; ++s) {
     if ((long)p.ncol_full * s + cin_dwq_rem_wgs(p.rem, s) > slots) break;
     best = s;
   }
-  long want = std::max<long>(best, (M + (1L << 20) - 1) >> 20);    // byte offsets inside a split (rows * 1 KiB) stay below 2^31
+  long want = std::max<long>(2L * best, (M + (1L << 20) - 1) >> 20);    // byte offsets inside a split (rows * 1 KiB) stay below 2^31
   long rows = std::max(unit, ((M + want - 1) / want + unit - 1) / unit * unit);
   p.rows_per_split = (int)rows;
   p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
-  p.wgs_full = p.ncol_full * p.splits;
-  p.wgs = p.wgs_full + cin_dwq_rem_wgs(p.rem, p.splits);
+  p.pairs = (p.splits + 1) / 2;
+  p.wgs_full = p.ncol_full * p.pairs;
+  p.wgs = p.wgs_full + cin_dwq_rem_wgs(p.rem, p.pairs);
   return p;
 }
 
 template <int DEPTH = kDwqDepth>
-__global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
-                                                         int XE, float* __restrict__ part, int M, int F, int symD, int rows_per_split, int splits,
-                                                         int ncol_full, int rem, int wgs_full, int wgs) {
+__global__ __launch_bounds__(kDwqThreads, 2) void cin_dwq_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
+                                                                int XE, float* __restrict__ part, int M, int F, int symD, int rows_per_split, int splits,
+                                                                int ncol_full, int rem, int wgs_full, int wgs) {
+  // waves w and w + 4 of a workgroup take the same channel tile and the two row splits of one PAIR; the upper one hands its
+  // accumulators over through LDS and the lower one stores the sum: one partial per pair of splits (half the partial-sum traffic of
+  // the reduction pass, in a fixed order: lower split + upper split)
+  __shared__ float fold[4][128][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int Cp = F * symD, C = Cp + F;
   // XCD-aware work mapping (as cin_dw3_kernel): workgroup i of XCD i%8 takes item (i%8)*(grid/8) + i/8 of the split-major list
   const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (item >= wgs) return;
-  int tile, split;
+  if (item >= wgs) return;   // (whole workgroup)
+  const int wl = wave & 3, up = wave >> 2;
+  int tile, pair;
+  bool idle = false;
   if (item < wgs_full) {
-    tile = (item % ncol_full) * 4 + wave;
-    split = item / ncol_full;
+    tile = (item % ncol_full) * 4 + wl;
+    pair = item / ncol_full;
   } else {
     const int j = item - wgs_full;
-    const int per = rem == 1 ? 4 : (rem == 2 ? 2 : 1);   // row splits per leftover workgroup
-    const int tw = rem == 3 ? wave : wave % rem;
-    if (rem == 3 && wave == 3) return;
-    tile = ncol_full * 4 + tw;
-    split = j * per + (rem == 3 ? 0 : wave / rem);
+    if (rem == 1) {
+      tile = ncol_full * 4;
+      pair = 4 * j + wl;
+    } else if (rem == 2) {
+      tile = ncol_full * 4 + (wl & 1);
+      pair = 2 * j + (wl >> 1);
+    } else {
+      tile = ncol_full * 4 + wl;
+      pair = j;
+      idle = wl == 3;
+    }
   }
   tile = __builtin_amdgcn_readfirstlane(tile);
-  split = __builtin_amdgcn_readfirstlane(split);
-  if (split >= splits) return;
+  pair = __builtin_amdgcn_readfirstlane(pair);
+  const int split = 2 * pair + up;
+  const int npairs = (splits + 1) >> 1;
   const int c0 = tile * 32;
   const int m_lo = split * rows_per_split;
   const int m_hi = min(M, m_lo + rows_per_split);
-  if (m_lo >= m_hi) return;
+  const bool work = !idle && pair < npairs && split < splits && m_lo < m_hi;   // (a wave without rows still takes part in the hand-over)
   // the descriptors cover exactly the split's rows: the last step's spare row and the prefetch past the end read zeros
-  const long mrem = (long)m_hi - m_lo;
-  const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(gT + (long)m_lo * HS, mrem * HS * 4);
-  const __amdgpu_buffer_rsrc_t r1 = make_rsrc_uniform(x1T + (long)m_lo * HS, mrem * HS * 4);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(xe + (long)m_lo * XE, mrem * XE * 4);
+  const long mrem = work ? (long)m_hi - m_lo : 0;
+  const long mbase = work ? m_lo : 0;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(gT + mbase * HS, mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t r1 = make_rsrc_uniform(x1T + mbase * HS, mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(xe + mbase * XE, mrem * XE * 4);
   const int c = c0 + r;
   const int cc = c < C ? c : C - 1;
   int hh, ff, sel;
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict
   }
   const int ho = (half * XE + hh) * 4, fo = (half * XE + ff) * 4, so = (half * XE + F + 1 + sel) * 4;
   const int go = (half * HS + 4 * r) * 4;
-  const int steps = (m_hi - m_lo + 1) >> 1;
+  const int steps = work ? (m_hi - m_lo + 1) >> 1 : 0;
   const int groups = (steps + DEPTH - 1) / DEPTH;
 
   f32x16 acc[8];
@@ -132,9 +150,7 @@ __global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict
       const f32x4s g4 = qg[d], x4 = q1[d];
       an = qh[(d + 1) % DEPTH] * qf[(d + 1) % DEPTH];   // (slot 0 of the next group was refilled a group ago)
       an2 = an * qs[(d + 1) % DEPTH];
-#ifndef FIL_ABL_DWQ_NOSB
       __builtin_amdgcn_sched_barrier(0);
-#endif
       acc[0] = mfma32(ac, g4[0], acc[0]);
       acc[1] = mfma32(ac, g4[1], acc[1]);
       acc[2] = mfma32(ac, g4[2], acc[2]);
@@ -145,16 +161,25 @@ __global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict
       acc[7] = mfma32(ac2, x4[3], acc[7]);
       ac = an;
       ac2 = an2;
-#ifndef FIL_ABL_DWQ_NOSB
       __builtin_amdgcn_sched_barrier(0);
-#endif
       fetch(g * DEPTH + d + DEPTH, d);   // after the step's MFMAs: the refill may land in the registers it replaces
-#ifndef FIL_ABL_DWQ_NOSB
       __builtin_amdgcn_sched_barrier(0);
-#endif
     }
   }
-  float* pout = part + (long)split * C * 256;
+  // hand-over: the upper wave's 128 accumulator registers through LDS ([register][lane]: conflict-free), then lower + upper
+  if (up == 1) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fold[wl][nb * 16 + i][lane] = acc[nb][i];
+  }
+  __syncthreads();
+  if (up == 1 || idle || pair >= npairs) return;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] += fold[wl][nb * 16 + i][lane];
+  float* pout = part + (long)pair * C * 256;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int cr = c0 + mfma32_row(reg, half);
@@ -166,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void cin_dwq_kernel(const float* __restrict
   }
 }
 
-// Fixed-order sum of the row-split partials [splits][C][256] of cin_dwq_kernel (64 outputs per workgroup, the 4 waves take every
+// Fixed-order sum of the partials [pairs of row splits][C][256] of cin_dwq_kernel (64 outputs per workgroup, the 4 waves take every
 // 4th partial, as cin_reduce_kernel), written straight to their destinations:
 //   pair row c = h*D + d, column n < H1:        dW1[(h,f), n] and, unless d == 0 or 2d == F, dW1[(f,h), n]      (f = (h + d) mod F)
 //   pair row c, column 128 + n, n < H2:         dT[(h,f), n] / dT[(f,h), n] likewise  ([F*F][H2])
