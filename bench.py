@@ -500,6 +500,8 @@ def main():
                          "there is a second rank to exchange with (on one rank the two stream hops cost ~0.02 ms and hide nothing)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group and run the collectives even at world size 1 (plumbing check on one GPU)")
+    ap.add_argument("--no-graph-replay", action="store_true", help="skip the HIP-graph replay timing of the headline step (profiling runs: "
+                    "keeps the number of step iterations the PMC summarisers expect)")
     ap.add_argument("--stub", default="", help=argparse.SUPPRESS)   # tests: module with install(namespace) -> CPU/gloo stand-ins
     args = ap.parse_args()
     if args.workload in ("deepfm", "xdeepfm"):
@@ -691,7 +693,7 @@ def main():
     # the same step replayed from a HIP graph (the C ABI neither allocates nor synchronises: capturable as it stands).  Reported beside
     # the headline, never as it: `value` stays the eagerly launched step.
     graph_ms = None
-    if device.type == "cuda" and not use_dist and not args.stub:
+    if device.type == "cuda" and not use_dist and not args.stub and not args.no_graph_replay:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
