@@ -60,14 +60,15 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_KSPLIT=0|4    reduction split of the row-parallel kernels over the 4 waves of a workgroup (default: by M)
 //   FIL_CIN_QMERGE=0      quadratic tail: two weight-gradient launches (first layer, quadratic form) instead of the merged one
 //   FIL_CIN_DZ2=0         ... its two data-gradient passes as two launches of the pair-symmetric dZ kernel instead of one two-pass launch
+//   FIL_CIN_FWDQ=0        ... its forward as two 128-column launches + the pool kernel instead of the 256-column launch with fused pools
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -299,6 +300,7 @@ static size_t fwd_ws_bytes(const CinShape& s) {
   t += align_up(wf_floats(s) * sizeof(float), 256);                                                      // packed W
   t += align_up((size_t)kCinMaxH * sizeof(float), 256);                                                  // quadratic tail: zero bias of the R GEMM
   t += align_up(cin_x2_floats(s.M(), cin_x2_len(s.F)) * sizeof(float), 256);                             // wrapped rows of x (pair-symmetric forward)
+  t += align_up((size_t)chunks_of(s.H[0]) * s.F * 2 * cin_jt_sym(s.F) * 128 * sizeof(float), 256);       // merged quadratic-tail forward: T's packed operand beside W1's
   return t;
 }
 // floats of the dW partial-sum buffer: the largest splits * C * H over the layers (both first-layer forms, so the
@@ -403,6 +405,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);                    // last two layers as one implicit GEMM (cin_tail.h)
   const bool qtail = qtail_used(s, mode, tune);            // ... as a quadratic form over field pairs (cin_qtail.h)
+  const bool qmerge = qmerge_used(s, mode, tune);          // ... with merged launches (cin_qmerge.h)
   const TailGeom tg = tail_geom(s);
   mode &= 1;
   if (B == 0) return FIL_OK;
@@ -425,6 +428,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   const int XL = cin_x2_len(F);
   float* x2T = ws.take<float>(cin_x2_floats(M, XL));
   const bool need_x2 = tune.sym && !split;   // the exact pair-symmetric forward kernel reads the wrapped rows
+  float* WfT = ws.take<float>((size_t)chunks_of(H[0]) * F * 2 * cin_jt_sym(F) * 128);
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
   const float* xT = xt_in ? x : xT_own;
@@ -486,6 +490,34 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   bool fused_last = false;   // the last layer's sum-pool was produced by the epilogue of the layer below
   for (int l = 0; l < L; ++l) {
     FIL_CHECK_ARG(W[l] && bias[l]);
+    if (qtail && qmerge && l == 0 && knobs().fwdq != 0 && s.HS(0) == 128) {
+      // ---- merged quadratic tail, forward (cin_qmerge.h): [x1 | R] = pairs(x) [W1s | Ts] in ONE launch of 256 columns, all three
+      // sum-pools in its epilogue.  T (and its packed operand copies) depend on the weights alone: they come first.
+      const int p = tg.p, lL = L - 1, Hpp = tg.Hpp, Hq = tg.Hq, HS0 = s.HS(0);
+      FIL_CHECK_ARG(W[p] && W[lL] && bias[p] && bias[lL]);
+      const int JTs = cin_jt_sym(F), chunks = chunks_of(Hpp);
+      float* x1T = sv.take<float>((size_t)M * HS0);   // (the first layer's map: same place in `saved` as on the other paths)
+      {
+        ProfScope ps("cin_tail_prep", st);
+        const size_t sh = std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq) * sizeof(float);
+        allow_lds(cin_qtail_t_kernel, sh);
+        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        const long npack = (long)chunks * F * 2 * JTs * 128;
+        const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
+        const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);
+        hipLaunchKernelGGL(cin_qtail_pack_kernel, dim3(nbf + nbz), dim3(256), 0, st, qtT, WfT, qtWzT, F, Hpp, JTs, chunks, nbf, HS0, tiles);
+      }
+      FIL_CHECK_LAUNCH();
+      {
+        const double algo = gemm_flops(M, F, F, H[0]) + gemm_flops(M, Hpp, F, Hq) + gemm_flops(M, Hq, F, tg.HL);   // all three layers of the reference graph
+        ProfScope ps("cin_fwd_q", st, algo, gemm_flops(M, 1, F * (F / 2 + 1), H[0]) + gemm_flops(M, 1, F * (F / 2 + 1), Hpp));
+        cin_launch_fwdq(st, JTs, x2T, XL, Wf, WfT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
+                        const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0]);
+        pa.chunks[0] = pa.chunks[p] = pa.chunks[lL] = 1;
+      }
+      FIL_CHECK_LAUNCH();
+      break;
+    }
     if (qtail && l == tg.p) {
       // ---- quadratic tail (cin_qtail.h): R = (pairs of x) T through the first layer's pair-symmetric forward kernel,
       // pool_L = <x1, R> + <x, c> + const, pool_p through the pooled-weights shortcut

@@ -1,4 +1,5 @@
-// Instantiations + dispatch of cin_dz2_kernel<JT> (both data-gradient passes of the quadratic tail in one launch).
+// Instantiations + dispatch of cin_dz2_kernel<JT> (both data-gradient passes of the quadratic tail in one launch) and
+// cin_fwdq_kernel<JT> (first layer + quadratic form forward, 256 columns, all three sum-pools).
 #include "cin_qmerge.h"
 
 namespace fil {
@@ -20,6 +21,17 @@ void cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, 
   case JTV: dz2<JTV>(st, g1T, g2T, HS, dsc, ldp, K, Wz1, Wz2, xT, dxT, accumulate, M, F, H1, H2, periods); break;
   switch (JT) { FIL_Z2(2) FIL_Z2(4) FIL_Z2(6) FIL_Z2(8) FIL_Z2(10) FIL_Z2(12) FIL_Z2(14) FIL_Z2(16) FIL_Z2(18) }
 #undef FIL_Z2
+}
+
+void cin_launch_fwdq(hipStream_t st, int JT, const float* x2T, int XL, const float* W1f, const float* WTf, const float* bias1, const float* wsn, int JTG,
+                     const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H) {
+#define FIL_FQ(JTV)                                                                                                                             \
+  case JTV:                                                                                                                                     \
+    hipLaunchKernelGGL((cin_fwdq_kernel<JTV>), dim3(cdiv(M, 128)), dim3(kCinThreads), 0, st, x2T, XL, W1f, WTf, bias1, wsn, JTG, cvec, x1T, RT, HS, \
+                       pool1, pool_p, pool_L, M, F, H);                                                                                         \
+    break;
+  switch (JT) { FIL_FQ(2) FIL_FQ(4) FIL_FQ(6) FIL_FQ(8) FIL_FQ(10) FIL_FQ(12) FIL_FQ(14) FIL_FQ(16) FIL_FQ(18) }
+#undef FIL_FQ
 }
 
 }  // namespace fil
