@@ -316,7 +316,7 @@ inline int cin_dz2_rows(int F, int JT) {   // LDS field rows: the wrapped slot f
   return std::max(cin_dz_sym_rows(F, JT), (F + hpp - 1) / hpp * hpp);
 }
 
-template <int JT>
+template <int JT, int G>
 __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
                                                          const float* __restrict__ dsc, int ldp, int K, const float* __restrict__ Wz1,
                                                          const float* __restrict__ Wz2, const float* __restrict__ xT, float* __restrict__ dxT,
@@ -402,8 +402,20 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     int hprev = 0;   // h base of the period the previous tile belongs to (the fake tile before the first one: dZ = 0, any valid rows)
     // A slot is contracted in two halves one step group apart (read, then FMA + write a group later): the LDS latency stays off the
     // MFMA chain.  Within a group the apply (write) precedes the next fetch (read), so slots that alias one word stay ordered.
-    float2 lv = make_float2(0.f, 0.f);
-    float* la = lrow;
+    // Slots per block: G slots are fetched together behind a block of 4 G MFMAs and applied behind the next block, the blocks pinned
+    // by scheduling barriers.  One slot per step group (G = 1, pinned: cin_dz3_kernel's form) 0.280 ms; G = 1 left to the compiler
+    // 0.248; G = 2 / 4 / 8 unpinned 0.242 / 0.235 / 0.235; G = 4 pinned 0.2285; G = 8 pinned 0.234: runs of 16 dependent MFMAs
+    // keep the pipe fed by the SIMD's other wave while this one does its four LDS round trips in one go.
+    // G > 1 needs the G slots of a block (and the rows completed while they are pending) to be distinct words: slots alias at a
+    // distance of 2 JT - 1 (offsets hl + 2j) or through the wrap of f -- the launcher picks G = 4 for JT >= 4 and
+    // F >= HPP + 2 JT (no two offsets of a period differ by F), G = 1 otherwise.
+    float2 lv[G];
+    float* la[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      lv[k] = make_float2(0.f, 0.f);
+      la[k] = lrow;
+    }
     float *abase = lrow, *awrap = lrow;
     int symh = 0;
     auto sym_period = [&](int hb) {
@@ -411,18 +423,18 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
       abase = lrow + symh * FS;
       awrap = abase - F * FS;
     };
-    auto slot_fetch = [&](int tp, int rr) {
+    auto slot_fetch = [&](int tp, int rr, int k) {
       const int sp = 16 * tp + rr;
       const int off = sp / JT + 2 * (sp % JT);   // compile-time after unrolling: f = (h + off + half) mod F, h + off + half < F + FR
-      la = (symh >= F - off ? awrap : abase) + off * FS;
-      lv = *reinterpret_cast<const float2*>(la);
+      la[k] = (symh >= F - off ? awrap : abase) + off * FS;
+      lv[k] = *reinterpret_cast<const float2*>(la[k]);
     };
-    auto slot_apply = [&](const f32x16& d, const float (&xpv)[HPP], int hb, int tp, int rr) {
+    auto slot_apply = [&](const f32x16& d, const float (&xpv)[HPP], int hb, int tp, int rr, int k) {
       const int sp = 16 * tp + rr;
       const int hl = sp / JT, j = sp % JT;
       const float dz = d[rr];
-      gx = fmaf(dz, lv.x, gx);
-      la[1] = fmaf(dz, xpv[hl], lv.y);
+      gx = fmaf(dz, lv[k].x, gx);
+      la[k][1] = fmaf(dz, xpv[hl], lv[k].y);
       if (j == JT - 1) {
         // h = hb + hl is complete: dX[m,h] += sum over both lane halves (one LDS add by the lower half; the row's own words only)
         const float t = lane_halves_sum(gx);
@@ -431,7 +443,8 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
       }
     };
     sym_period(hprev);
-    slot_fetch(P - 1, 0);
+#pragma unroll
+    for (int k = 0; k < G; ++k) slot_fetch(P - 1, k, k);
 #pragma unroll 1
     for (int per = 0; per < periods; ++per) {
       const int hbase = per * HPP;
@@ -452,17 +465,26 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
           d = mfma32(w[2], greg[4 * s4 + 2], d);
           d = mfma32(w[3], greg[4 * s4 + 3], d);
           q[s4 % QD] = s4 + QD < NQ ? ldw(t, s4 + QD) : ldw(t + 1, s4 + QD - NQ);   // (the stream is allocated one tile past the last period)
-          // the previous tile's slots, one per step group in program order -- and NO scheduling barrier between the groups: the compiler
-          // then runs the MFMAs in long back-to-back bursts with the slot work in blocks between them, 0.250 ms; with every group
-          // pinned in place (a barrier here, as cin_dz3_kernel has it) 0.280; with each tile's 64 MFMAs and its 16 slots as two
-          // explicit blocks 0.268
-          if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, s4);
-          else slot_apply(dprev, xcur, hbase, tp - 1, s4);
-          if (s4 < 15) {
-            slot_fetch(tp == 0 ? P - 1 : tp - 1, s4 + 1);
-          } else {
-            if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
-            slot_fetch(tp, 0);                // first slot of this tile, applied in the first group of the next one
+          if (s4 % G == G - 1) {
+            // the previous tile's slots s4-G+1 .. s4: applied (their words were fetched a block ago), then the next G fetched.  An
+            // aliasing word is written before it is fetched again: applies precede fetches, and the slots of one block are distinct.
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+              const int rr = s4 - G + 1 + k;
+              if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, rr, k);
+              else slot_apply(dprev, xcur, hbase, tp - 1, rr, k);
+            }
+            if (s4 < 15) {
+#pragma unroll
+              for (int k = 0; k < G; ++k) slot_fetch(tp == 0 ? P - 1 : tp - 1, s4 + 1 + k, k);
+            } else {
+              if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
+#pragma unroll
+              for (int k = 0; k < G; ++k) slot_fetch(tp, k, k);   // first slots of this tile, applied behind the first block of the next one
+            }
+#ifndef FIL_DZ2_NOSB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
           }
         }
         dprev = d;
@@ -473,9 +495,13 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     }
     // the last tile's slots
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      slot_apply(dprev, xprev, hprev, P - 1, rr);
-      if (rr < 15) slot_fetch(P - 1, rr + 1);
+    for (int r0 = 0; r0 < 16; r0 += G) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) slot_apply(dprev, xprev, hprev, P - 1, r0 + k, k);
+      if (r0 + G < 16) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) slot_fetch(P - 1, r0 + G + k, k);
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
