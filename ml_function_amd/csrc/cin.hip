@@ -464,8 +464,10 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
     const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
     const long npack = (long)chunks0 * F * 2 * JTs * 128;
-    const int nt = B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nwl = cdiv(tg.Hq * F, 8), nwp = cdiv(tg.Hpp * F, 8);
-    const size_t sh = xt_in ? 0 : (size_t)F * (K + 1) * sizeof(float);
+    // (merged forward: the x transposes ride in the NEXT launch, beside the T workgroups -- this one is the weight work alone)
+    const bool fq = qmerge && knobs().fwdq != 0 && s.HS(0) == 128;
+    const int nt = fq ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nwl = cdiv(tg.Hq * F, 8), nwp = cdiv(tg.Hpp * F, 8);
+    const size_t sh = (xt_in || fq) ? 0 : (size_t)F * (K + 1) * sizeof(float);
     allow_lds(cin_qtail_prep_kernel, sh);
     hipLaunchKernelGGL(cin_qtail_prep_kernel, dim3(nt + npk + nwl + nwp), dim3(256), sh, st, x, xT_own, F, K, nt, W[0], Wf, H[0], 2 * JTs, chunks0, npk,
                        W[L - 1], qtWsumL, tg.Hq, tg.HL, nwl, W[L - 2], qtWsumP, qtWsnP, tg.Hpp, 2 * JT, chunks_of(tg.Hpp), x2T, XL, xt_in ? 1 : 0);
@@ -499,9 +501,11 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       float* x1T = sv.take<float>((size_t)M * HS0);   // (the first layer's map: same place in `saved` as on the other paths)
       {
         ProfScope ps("cin_tail_prep", st);
-        const size_t sh = std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq) * sizeof(float);
-        allow_lds(cin_qtail_t_kernel, sh);
-        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        // T / cvec (weights only) and, beside them, the x -> xT / wrapped-row transposes (x only)
+        const size_t sh = std::max(std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq), (size_t)F * (K + 1)) * sizeof(float);
+        allow_lds(cin_qtail_t_x_kernel, sh);
+        hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(2 * Hpp + 1 + B), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
+                           2 * Hpp + 1, x, xT_own, K, x2T, XL, xt_in ? 1 : 0);
         const long npack = (long)chunks * F * 2 * JTs * 128;
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
         const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);

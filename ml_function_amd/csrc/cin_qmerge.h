@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
   const int wo = (r * 128 + half * 64) * 4;
 
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 2; ++pass) {   // (running the passes in the other order in half of the workgroups, so that the two waves of a
+    // SIMD do not reload their operands at the same moment, changed nothing)
     const float* gT = pass == 0 ? g1T : g2T;
     const int Hk = pass == 0 ? H1 : H2;
     const float sc = pass == 0 ? 1.f : dpl;

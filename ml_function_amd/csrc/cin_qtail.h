@@ -99,12 +99,11 @@ static __global__ __launch_bounds__(256) void cin_qtail_pack_kernel(const float*
 constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
 
 // T[(f'*F + f)*Hpp + h] for block h < Hpp; block Hpp writes cvec and a zero bias vector for the R GEMM.
-static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
-                                                                 const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
-                                                                 float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
-                                                                 int Hpp, int F, int Hq) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int h = blockIdx.x >> 1, part = blockIdx.x & 1;   // two workgroups per h (each half of the (f', f) outputs); the last one: cvec
+__device__ __forceinline__ void cin_qtail_t_body(const float* __restrict__ Wp, const float* __restrict__ wsumL,
+                                                 const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
+                                                 float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
+                                                 int Hpp, int F, int Hq, int bid, float* smem) {
+  const int h = bid >> 1, part = bid & 1;   // two workgroups per h (each half of the (f', f) outputs); the last one: cvec
   if (h == Hpp) {
     float* wl = smem;            // wsum_L [Hq][F]
     float* bp = wl + Hq * F;     // bias_p [Hq]
@@ -166,6 +165,33 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __
       t3 = fmaf(av.w, bv.w, t3);
     }
     T[(long)idx * Hpp + h] = (t0 + t1) + (t2 + t3);
+  }
+}
+
+static __global__ __launch_bounds__(256) void cin_qtail_t_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
+                                                                 const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
+                                                                 float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
+                                                                 int Hpp, int F, int Hq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cin_qtail_t_body(Wp, wsumL, bias_p, bias_L, HL, T, cvec, zbias, Hpp, F, Hq, blockIdx.x, smem);
+}
+
+// Merged quadratic-tail forward, second preparation launch: [0, nT) the T / cvec workgroups (weights only; they need wsum_L of the
+// first launch), the rest: the x -> xT / wrapped-row transposes, which depend on nothing but x -- the two run side by side instead of
+// one after the other (the T workgroups are the longer-running ones and come first).
+static __global__ __launch_bounds__(256) void cin_qtail_t_x_kernel(const float* __restrict__ Wp, const float* __restrict__ wsumL,
+                                                                   const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
+                                                                   float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
+                                                                   int Hpp, int F, int Hq, int nT, const float* __restrict__ x, float* __restrict__ xT,
+                                                                   int K, float* __restrict__ x2T, int XL, int xt_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < nT) {
+    cin_qtail_t_body(Wp, wsumL, bias_p, bias_L, HL, T, cvec, zbias, Hpp, F, Hq, b, smem);
+  } else if (xt_in) {
+    cin_wrap_rows_body(x, x2T, F, K, b - nT, XL);
+  } else {
+    cin_transpose_in_body(x, xT, F, K, b - nT, smem, x2T, XL);
   }
 }
 
