@@ -112,10 +112,10 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *           pair-symmetric GEMM kernels -- F(F+1)/2 x H_1 products per row, half of the fused tail's, no column padding
  *           (csrc/cin_qtail.h).  Used above 16,384 rows (B*K; smaller batches are launch-latency bound and keep the fused tail,
  *           FIL_CIN_TAIL_ALWAYS lifts that rule).  This bit keeps three-layer nets on the F+1-column fused tail (tests / comparison).
- *         + FIL_CIN_NOQMERGE (512): the quadratic tail's backward normally runs ONE weight-gradient GEMM with 256 output columns,
- *           pairs(x)^T [G^1 | dP_L x^1], for the first layer and the quadratic form together (csrc/cin_qmerge.h: the generated operand
- *           is paid once instead of twice and every wave of the grid carries the same number of steps); this bit keeps round 3's two
- *           launches (tests / comparison).
+ *         + FIL_CIN_NOQMERGE (512): the quadratic tail normally runs THREE GEMM launches (csrc/cin_qmerge.h): the forward
+ *           [x^1 | R] = pairs(x) [W_1 | T] with 256 output columns and all three sum-pools in its epilogue, the weight gradients
+ *           pairs(x)^T [G^1 | dP_L x^1] with 256 output columns, and the data gradients as two passes of one launch over one dX image.
+ *           This bit keeps round 3's two launches per direction (tests / comparison).  Same function up to summation order.
  *         + FIL_CIN_NOKSPLIT (128): small batches (B*K <= 16,384 rows) give each block of 32 rows to the FOUR waves of a workgroup,
  *           which split the reduction between them (strong-scaling shards: without it the row-parallel kernels stop getting faster
  *           below one row block per SIMD); this bit keeps one wave per row block.  Same function up to summation order.
