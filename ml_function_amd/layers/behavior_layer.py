@@ -65,26 +65,41 @@ class MultHeadAttentionLayer(Layer):
         return (self.query_w, self.key_w, self.res_w if self.use_res else None,
                 self.ln_gamma if self.use_ln else None, self.ln_beta if self.use_ln else None)
 
+    def fits_fused_kernel(self, inputs):
+        """The fused kernel's menu (include/fil.h): K <= 64, A <= 16, H <= 8, F <= 512.  A reference-legal layer outside it
+        (e.g. attention_dim = 32) takes the composed path below instead of raising."""
+        return (inputs.dim() == 3 and inputs.shape[2] <= 64 and self.attention_dim <= 16 and self.attention_head_dim <= 8
+                and inputs.shape[1] <= 512)
+
+    def _composed(self, inputs, mask):
+        """The reference's op order (:358-369) with the attention core on the stand-alone kernel (fil_pattn_*: A <= 64, any mask) --
+        projections as tensordot, ProductAttentionLayer([q, k, v], mask), LayerNormalization (epsilon 1e-3) by torch."""
+        Wq, Wk, Wr, g, b = self._args()
+        q = torch.tensordot(inputs, Wq, dims=1).permute(2, 0, 1, 3)
+        k = torch.tensordot(inputs, Wk, dims=1).permute(2, 0, 1, 3)
+        atten_v = self.attention_cal([q, k, k], mask=mask)                  # v is projected with key_w (:360)
+        res = torch.tensordot(inputs, Wr, dims=1).permute(2, 0, 1, 3) if Wr is not None else None
+        if g is not None:
+            atten_v = torch.nn.functional.layer_norm(atten_v, (self.attention_dim,), g, b, self.ln_epsilon)
+        return atten_v, res
+
     def fused_relu(self, inputs):
         """relu(res + LN(attention)) in one kernel: what DnnLayer(res_unit=1, other_dense=[self]) computes."""
         Wq, Wk, Wr, g, b = self._args()
+        if not self.fits_fused_kernel(inputs):
+            atten_v, res = self._composed(inputs, None)
+            return torch.relu(atten_v + res) if res is not None else torch.relu(atten_v)
         return Fn.autoint_interact(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale, eps=self.ln_epsilon,
                                    precision=self.precision)
 
     def call(self, inputs, mask=None, **kwargs):
         Wq, Wk, Wr, g, b = self._args()
-        if mask is None:
+        if mask is None and self.fits_fused_kernel(inputs):
             atten_v, res = Fn.mult_head_attention(inputs, Wq, Wk, Wr, g, b, use_scale=self.attention_cal.use_scale,
                                                   eps=self.ln_epsilon, precision=self.precision)
         else:
-            # masked: the reference's op order (:358-369) with the attention core on the stand-alone kernel -- projections
-            # as tensordot, ProductAttentionLayer([q, k, v], mask), LayerNormalization (epsilon 1e-3) by torch
-            q = torch.tensordot(inputs, Wq, dims=1).permute(2, 0, 1, 3)
-            k = torch.tensordot(inputs, Wk, dims=1).permute(2, 0, 1, 3)
-            atten_v = self.attention_cal([q, k, k], mask=mask)                  # v is projected with key_w (:360)
-            res = torch.tensordot(inputs, Wr, dims=1).permute(2, 0, 1, 3) if Wr is not None else None
-            if g is not None:
-                atten_v = torch.nn.functional.layer_norm(atten_v, (self.attention_dim,), g, b, self.ln_epsilon)
+            # masked, or a shape outside the fused kernel's menu: the composed path
+            atten_v, res = self._composed(inputs, mask)
         if res is None:
             res = []
         if self.head_concat:

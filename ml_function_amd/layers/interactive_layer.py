@@ -256,9 +256,40 @@ class CIN(Layer):
                                or getattr(x, "_fil_xt_version", None) != x._version):
             xt = None       # (version: the block was edited in place after the gather -- mask multiply, dropout_ -- xt is stale)
         Ws = [w[0] for w in self.conv_kernels]
+        if not self.fits_kernel_menu(x):
+            return self._composed(x, Ws)
         if self.output_dim == 1:
             return Fn.cin(x, Ws, self.conv_biases, self.logit_kernel, self.logit_bias, output_dim=1, mode=self.mode, xt=xt)
         return Fn.cin(x, Ws, self.conv_biases, None, None, output_dim=self.output_dim, mode=self.mode, xt=xt)
+
+    def fits_kernel_menu(self, x):
+        """fil_cin_*'s limits (include/fil.h): F <= 64, H_l <= 256, L <= 8.  The reference has none (:296-327): a layer outside them
+        takes the composed path below instead of raising."""
+        return x.shape[1] <= 64 and max(self.conv_size) <= 256 and len(self.conv_size) <= 8
+
+    def _composed(self, x, Ws, rows_per_chunk=1 << 16):
+        """The reference's op graph (:310-327) on the GPU for shapes outside the HIP kernels' menu: per layer the outer product
+        z[b,k,(h,f)] = x^{l-1}[b,h,k] x[b,f,k] and one library GEMM with the Conv1D kernel (plain rocBLAS through torch, autograd for
+        the backward), in chunks of samples so that the materialised z stays bounded.  Slow next to the kernels -- it exists so
+        that a reference-legal layer never raises."""
+        Fn._require_cuda(x)          # (torch ops would run on a CPU tensor: there is no CPU path in this package)
+        B, F, K = x.shape
+        cmax = max([F] + self.conv_size[:-1]) * F
+        step = max(1, rows_per_chunk // max(1, K * cmax // 64))
+        outs = []
+        for lo in range(0, B, step):
+            xc = x[lo:lo + step]
+            xk = xc.permute(0, 2, 1)                                # [b,K,F]
+            pre, pools = xk, []
+            for w, bias in zip(Ws, self.conv_biases):
+                z = (pre.unsqueeze(3) * xk.unsqueeze(2)).reshape(xc.shape[0], K, -1)     # channel c = h*F + f (:316-318)
+                pre = torch.matmul(z, w) + bias                     # Conv1D(size, 1) (:319)
+                pools.append(pre.sum(-1))                           # reduce_sum over the feature maps (:322)
+            outs.append(torch.cat(pools, 1))
+        pooled = torch.cat(outs, 0)
+        if self.output_dim == 1:
+            return torch.matmul(pooled, self.logit_kernel) + self.logit_bias
+        return pooled
 
 
 class SparseEmbed(Layer):

@@ -1058,6 +1058,68 @@ def test_attn_unfused_matches_reference_layer_outputs():
         check("mha d" + n, t[n].grad, o[n].grad.numpy(), tol=2e-5)
 
 
+@pytest.mark.parametrize("B,F,K,conv,output_dim", [(6, 80, 4, [5, 4], 1), (5, 9, 4, [300, 6], 2), (3, 4, 2, [2] * 9, 1)])
+def test_cin_layer_outside_the_kernel_menu_takes_the_composed_path(B, F, K, conv, output_dim):
+    """F > 64, H > 256, L > 8: the reference has no such limits (interactive_layer.py:296-327).  The HIP entry point refuses the shape
+    (FIL_ERR_UNSUPPORTED), the CIN layer does not: it runs the reference's op graph with library GEMMs on the GPU."""
+    from ml_function_amd import functional as Fn
+    from ml_function_amd._lib import FilError
+    from ml_function_amd.layers import CIN
+    c = synth.cin_case(B, F, K, conv, dist="uniform", output_dim=output_dim)
+    c["x"] = (c["x"] * 10).astype(np.float32)
+    with pytest.raises(FilError):
+        Fn.cin(dev(c["x"]), [dev(w) for w in c["Ws"]], [dev(b) for b in c["bs"]], dev(c["dense_w"]), dev(c["dense_b"]), output_dim=output_dim)
+    lay = CIN(conv_size=conv, output_dim=output_dim)
+    x = dev(c["x"]).requires_grad_()
+    lay(x)            # builds the weights
+    with torch.no_grad():
+        for l in range(len(conv)):
+            lay.conv_kernels[l].copy_(dev(c["Ws"][l])[None])
+            lay.conv_biases[l].copy_(dev(c["bs"][l]))
+        if output_dim == 1:
+            lay.logit_kernel.copy_(dev(c["dense_w"]))
+            lay.logit_bias.copy_(dev(c["dense_b"]))
+    out = lay(x)
+    check("composed cin out", out, closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"], output_dim))
+    out.backward(dev(c["g"]))
+    dx, dWs, dbs, ddw, ddb = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"], output_dim)
+    check("composed cin dx", x.grad, dx, tol=2e-5)
+    for l in range(len(conv)):
+        check("composed cin dW%d" % l, lay.conv_kernels[l].grad[0], dWs[l], tol=2e-5)
+    with pytest.raises(FilError):
+        lay(torch.tensor(c["x"]))     # a CPU tensor: no CPU path
+
+
+def test_autoint_layer_outside_the_kernel_menu_takes_the_composed_path():
+    """attention_dim = 32 (the fused kernel's menu ends at A = 16; behavior_layer.py:323-353 has no limit): MultHeadAttentionLayer.call
+    and the DnnLayer-fused relu(res + LN(attention)) go through the stand-alone attention kernel and match the oracle graph."""
+    from ml_function_amd.layers import MultHeadAttentionLayer
+    from oracle import graph
+    B, F, K, H, A = 3, 20, 16, 2, 32
+    c = synth.attn_case(B, F, K, H, A, dist="normal")
+    lay = MultHeadAttentionLayer(A, H)
+    x = dev(c["x"]).requires_grad_()
+    assert not lay.fits_fused_kernel(x)
+    lay(x)
+    with torch.no_grad():
+        lay.query_w.copy_(dev(c["Wq"])); lay.key_w.copy_(dev(c["Wk"])); lay.res_w.copy_(dev(c["Wr"]))
+        lay.ln_gamma.copy_(dev(c["gamma"])); lay.ln_beta.copy_(dev(c["beta"]))
+    T64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=True)
+    o = {n: T64(c[n]) for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
+    av, res = lay(x)
+    av_o, res_o = graph.mult_head_attention(o["x"], o["Wq"], o["Wk"], o["Wr"], o["gamma"], o["beta"])
+    check("composed mha atten_v", av, av_o.detach().numpy())
+    check("composed mha res", res, res_o.detach().numpy())
+    y = lay.fused_relu(x)
+    y_o = graph.autoint_interacting(o["x"], o["Wq"], o["Wk"], o["Wr"], o["gamma"], o["beta"])
+    check("composed autoint y", y, y_o.detach().numpy())
+    y.backward(dev(c["dy"]))
+    y_o.backward(torch.tensor(c["dy"], dtype=torch.float64))
+    check("composed autoint dx", x.grad, o["x"].grad.numpy(), tol=2e-5)
+    check("composed autoint dWq", lay.query_w.grad, o["Wq"].grad.numpy(), tol=2e-5)
+    check("composed autoint dWk", lay.key_w.grad, o["Wk"].grad.numpy(), tol=2e-5)
+
+
 def test_cin_step_is_hipgraph_capturable():
     """The C ABI enqueues on the caller's stream without allocating or synchronising, so a whole forward+backward can be
     captured into a HIP graph (torch.cuda.CUDAGraph) and replayed: results equal the eager run bit for bit."""
