@@ -854,7 +854,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     if (NHMAX == 64 && knobs().dz2 != 0) {
       // both data-gradient passes in one launch (cin_dz2_kernel): G1 with W1, then dP_L x1 with T, into one dX image
       ProfScope ps("cin_bwd_dz_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
-      cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods);
+      // (the kernel also finishes dx: + the shortcut's part in dxT, + dP_L c, transposed to [B,F,K] on the way out)
+      cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec);
       qm_joined = true;
     } else {
       const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
@@ -1165,12 +1166,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     cur ^= 1;
   }
-  {
+  if (!qm_joined) {   // (merged quadratic tail: cin_dz2_kernel wrote dx itself)
     ProfScope ps("cin_transpose_out", st, 2.0 * M * F * sizeof(float));
-    if (qm_joined)
-      hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, nullptr, dx, F, K, nullptr, nullptr, qtCvec,
-                         dPsrc + (size_t)(L - 1) * K, (int)LK);
-    else if (qmerge)
+    if (qmerge)
       hipLaunchKernelGGL(cin_transpose_out_kernel, dim3(B), dim3(256), (size_t)K * (F + 1) * sizeof(float), st, dxT, have_gx0 ? gx0T : nullptr, dx, F, K,
                          Gbuf[1] + (size_t)M * (F + 3), Gbuf[1] + (size_t)M * (F + 3) + (size_t)M * F, qtCvec, dPsrc + (size_t)(L - 1) * K, (int)LK);
     else if (qtail)

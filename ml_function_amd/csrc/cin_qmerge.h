@@ -320,7 +320,8 @@ template <int JT, int G>
 __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
                                                          const float* __restrict__ dsc, int ldp, int K, const float* __restrict__ Wz1,
                                                          const float* __restrict__ Wz2, const float* __restrict__ xT, float* __restrict__ dxT,
-                                                         int accumulate, int M, int F, int H1, int H2, int periods, int FR) {
+                                                         int accumulate, int M, int F, int H1, int H2, int periods, int FR,
+                                                         float* __restrict__ dx, const float* __restrict__ cvec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [FR][128 rows][2]
   constexpr int P = JT / gcd_c(16, JT);
   constexpr int HPP = 16 * P / JT;
@@ -506,9 +507,27 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     }
   }
   __builtin_amdgcn_wave_barrier();
-  // dX rows of the wave are contiguous in dxT ([32 rows][F]): written cooperatively from the LDS image, whole lines per store
   const float* img = smem + wave * 32 * 2 + 1;
   const int nrow = min(32, M - wrow0);
+  if (dx != nullptr) {
+    // final form: dx [B,F,K] = (what dxT holds: the shortcut's part) + the image + dP_L[m] c[f], transposed on the way out -- no
+    // separate transpose launch.  Lanes walk the wave's rows fastest: consecutive k of a sample are consecutive floats of dx.
+    const int rr = lane & 31;
+    const int mm = wrow0 + rr;
+    const bool ok = rr < nrow;
+    const long mc = ok ? mm : M - 1;
+    const long bb = mc / K;
+    const int kk = (int)(mc - bb * K);
+    const float sc = dsc[bb * ldp + kk];
+    float* dxb = dx + (bb * F) * K + kk;
+    const float* add = dxT + mc * F;
+    for (int f = lane >> 5; f < F; f += 2) {
+      const float v = (accumulate ? add[f] : 0.f) + img[f * FS + rr * 2] + sc * cvec[f];
+      if (ok) dxb[(long)f * K] = v;
+    }
+    return;
+  }
+  // dX rows of the wave are contiguous in dxT ([32 rows][F]): written cooperatively from the LDS image, whole lines per store
   float* dst = dxT + (long)wrow0 * F;
   for (int idx = lane; idx < nrow * F; idx += 64) {
     const int rr = idx / F, f = idx - rr * F;
@@ -517,8 +536,10 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
   }
 }
 
+// dx != nullptr: the kernel finishes the job -- dx [B,F,K] = transpose(dxT (read only) + its image) + dP_L c -- instead of updating dxT
 void cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const float* Wz1,
-                    const float* Wz2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods);
+                    const float* Wz2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods,
+                    float* dx = nullptr, const float* cvec = nullptr);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Forward of the first layer and of the quadratic form in ONE launch: [x1 | R] = pairs(x) [W1s | Ts] (+ b1), 256 output columns.
