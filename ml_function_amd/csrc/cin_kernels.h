@@ -1965,15 +1965,16 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
       xr[j] = (f < F && nrow > 0) ? xrow[min(f, F - 1)] : 0.f;
     }
   }
-  float dpr[16], dppr[16], dpa[16];
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int mm = min(wrow0 + mfma32_row(reg, half), M - 1);
-    const int b = mm / K, k = mm - b * K;
-    dpr[reg] = dP[(long)b * ldp + k];
-    dppr[reg] = dPprev != nullptr ? dPprev[(long)b * ldp + k] : 0.f;
-    dpa[reg] = Radd != nullptr ? dPadd[(long)b * ldp + k] : 0.f;
+  // the three pooled gradients of the wave's rows: lane r fetches row r's once, the store loops read them from LDS by row (48
+  // registers per lane in the accumulator layout: the kernel sat at the 256-register limit with spills)
+  __shared__ float dps[4][3][32];
+  if (half == 0) {
+    const int b = (int)(mq / K), k = (int)(mq - (long)b * K);
+    dps[wave][0][r] = dP[(long)b * ldp + k];
+    dps[wave][1][r] = dPprev != nullptr ? dPprev[(long)b * ldp + k] : 0.f;
+    dps[wave][2][r] = Radd != nullptr ? dPadd[(long)b * ldp + k] : 0.f;
   }
+  __builtin_amdgcn_wave_barrier();
   const int chunks = (Hp + 127) >> 7;
   for (int chunk = 0; chunk < chunks; ++chunk) {
     f32x16 t[4];
@@ -2002,19 +2003,31 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
     }
     const int n0 = chunk * 128 + 4 * r;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    // the rows of R this lane adds on the way out, eight loads in flight at a time (one by one inside the loop they were 16 exposed
+    // memory latencies in a row per wave)
+    float4 rq[8];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int m = wrow0 + mfma32_row(reg, half);
+      if (Radd != nullptr && (reg & 7) == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long mm = min(wrow0 + mfma32_row(reg + u, half), M - 1);
+          rq[u] = *reinterpret_cast<const float4*>(Radd + mm * HSr + n0);   // (rows of a feature map are 512-byte aligned and padded to whole chunks)
+        }
+      }
+      const int row = mfma32_row(reg, half);
+      const int m = wrow0 + row;
+      const float dpr = dps[wave][0][row], dppr = dps[wave][1][row], dpa = dps[wave][2][row];
       if (m < M) {
         float* dst = GprevT + (long)m * HSp + n0;
-        float v0 = fmaf(dpr[reg], t[0][reg], dppr[reg]), v1 = fmaf(dpr[reg], t[1][reg], dppr[reg]);
-        float v2 = fmaf(dpr[reg], t[2][reg], dppr[reg]), v3 = fmaf(dpr[reg], t[3][reg], dppr[reg]);
-        if (Radd != nullptr) {   // (rows of a feature map are 512-byte aligned and padded to whole chunks)
-          const float4 ra = *reinterpret_cast<const float4*>(Radd + (long)m * HSr + n0);
-          v0 = fmaf(dpa[reg], ra.x, v0);
-          v1 = fmaf(dpa[reg], ra.y, v1);
-          v2 = fmaf(dpa[reg], ra.z, v2);
-          v3 = fmaf(dpa[reg], ra.w, v3);
+        float v0 = fmaf(dpr, t[0][reg], dppr), v1 = fmaf(dpr, t[1][reg], dppr);
+        float v2 = fmaf(dpr, t[2][reg], dppr), v3 = fmaf(dpr, t[3][reg], dppr);
+        if (Radd != nullptr) {
+          const float4 ra = rq[reg & 7];
+          v0 = fmaf(dpa, ra.x, v0);
+          v1 = fmaf(dpa, ra.y, v1);
+          v2 = fmaf(dpa, ra.z, v2);
+          v3 = fmaf(dpa, ra.w, v3);
         }
         c0 += v0;
         c1 += v1;
@@ -2110,8 +2123,9 @@ __global__ __launch_bounds__(256, 2) void cin_last_bwd2_kernel(const float* __re
   for (int reg = 0; reg < 16; ++reg) {
     const int m = wrow0 + mfma32_row(reg, half);
     if (m < M) {
-      if (r < F) dxT[(long)m * F + r] = dpr[reg] * u0[reg];
-      if (two && r + 32 < F) dxT[(long)m * F + 32 + r] = dpr[reg] * u1[reg];
+      const float dpr = dps[wave][0][mfma32_row(reg, half)];
+      if (r < F) dxT[(long)m * F + r] = dpr * u0[reg];
+      if (two && r + 32 < F) dxT[(long)m * F + 32 + r] = dpr * u1[reg];
     }
   }
 }
