@@ -521,9 +521,19 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     const float sc = dsc[bb * ldp + kk];
     float* dxb = dx + (bb * F) * K + kk;
     const float* add = dxT + mc * F;
-    for (int f = lane >> 5; f < F; f += 2) {
-      const float v = (accumulate ? add[f] : 0.f) + img[f * FS + rr * 2] + sc * cvec[f];
-      if (ok) dxb[(long)f * K] = v;
+    // (eight loads in flight per batch: one at a time they were F/2 exposed memory latencies in a row at the very end of the wave)
+    for (int f0 = lane >> 5; f0 < F; f0 += 16) {
+      float a8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] = accumulate ? add[min(f0 + 2 * u, F - 1)] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + 2 * u;
+        if (f < F) {
+          const float v = a8[u] + img[f * FS + rr * 2] + sc * cvec[f];
+          if (ok) dxb[(long)f * K] = v;
+        }
+      }
     }
     return;
   }
