@@ -394,8 +394,8 @@ def _gemm_launch_of(per, kind, layer):
     GEMMs in a fixed order: forward l1, l2, .., tail; backward tail, .., l2, l1 -- and a kernel launched several times per step appears
     as '<name> #slot' entries.  The quadratic tail runs the FIRST layer's kernels a second time (forward: second launch; backward:
     first), the fused tail has kernels of its own (cin_tail_*)."""
-    if layer == "q":   # merged quadratic tail (cin_qmerge.h): one weight-gradient / one data-gradient launch for layer 1 + the quadratic form
-        name = {"bwd_dw": "cin_dwq_kernel", "bwd_dz": "cin_dz2_kernel"}.get(kind)
+    if layer == "q":   # merged quadratic tail (cin_qmerge.h): one forward / weight-gradient / data-gradient launch for layer 1 + the quadratic form
+        name = {"fwd": "cin_fwdq_kernel", "bwd_dw": "cin_dwq_kernel", "bwd_dz": "cin_dz2_kernel"}.get(kind)
         hits = sorted(k for k in per if name is not None and k.startswith(name))
         return hits[0] if hits else None
     prefixes = {"fwd": ("cin_fwd3_kernel", "cin_tail_fwd_kernel"), "bwd_dz": ("cin_dz3_kernel", "cin_tail_dz_kernel"),

@@ -57,7 +57,7 @@ def scopes_of(res):
             n += 1
         if has_tail:
             by_scope["cin_%s_tail" % kind] = pick(last)
-        q = bench._gemm_launch_of(res, kind, "q")   # merged quadratic tail: cin_dwq_kernel / cin_dz2_kernel
+        q = bench._gemm_launch_of(res, kind, "q")   # merged quadratic tail: cin_fwdq_kernel / cin_dwq_kernel / cin_dz2_kernel
         if q is not None:
             by_scope["cin_%s_q" % kind] = pick(q)
     return by_scope
