@@ -61,14 +61,15 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_QMERGE=0      quadratic tail: two weight-gradient launches (first layer, quadratic form) instead of the merged one
 //   FIL_CIN_DZ2=0         ... its two data-gradient passes as two launches of the pair-symmetric dZ kernel instead of one two-pass launch
 //   FIL_CIN_FWDQ=0        ... its forward as two 128-column launches + the pool kernel instead of the 256-column launch with fused pools
+//   FIL_CIN_HEADFOLD=0    ... the pooled relayout + Dense(1) head as their own launch instead of the 256-column launch's epilogue
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq, headfold;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1), env_int("FIL_CIN_HEADFOLD", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -339,6 +340,7 @@ static size_t bwd_ws_bytes(const CinShape& s) {
   t += align_up(gb_bytes(s), 256);                                       // split-bf16 planes of G (mode bit 1)
   t += align_up((size_t)s.F * s.F * kCinMaxH * sizeof(float), 256);      // quadratic tail: dT
   t += align_up(((M + 255) / 256 + 1) * kQtConst * sizeof(float), 256);  //                 column-sum partials of dP_L x, their sum
+  t += align_up(((M + 255) / 256) * (LK + 1) * sizeof(float), 256);      //                 the dense head's block partials (merged launches)
   return t;
 }
 
@@ -379,8 +381,9 @@ extern "C" int fil_cin_grad_ready_points(int B, int F, int K, int L, const int* 
   }
   int pt = 0, l = L - 1;
   point[L] = pt++;                                      // the dense head
-  if (qmerge_used(s, mode, CinTune(mode))) {            // merged weight gradients: the first layer's come out first, then the top two layers'
-    point[0] = pt++;
+  if (qmerge_used(s, mode, CinTune(mode))) {            // merged weight gradients: the first layer's come out first (the dense head's with them), then the top two layers'
+    point[0] = point[L] = 0;
+    pt = 1;
     point[1] = point[2] = pt++;
     return pt;
   }
@@ -490,6 +493,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   FIL_CHECK_LAUNCH();
   const float* xpT = xT;
   bool fused_last = false;   // the last layer's sum-pool was produced by the epilogue of the layer below
+  bool head_done = false;    // merged forward: pooled and out came out of cin_fwdq_kernel's epilogue
   for (int l = 0; l < L; ++l) {
     FIL_CHECK_ARG(W[l] && bias[l]);
     if (qtail && qmerge && l == 0 && knobs().fwdq != 0 && s.HS(0) == 128) {
@@ -515,8 +519,16 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       {
         const double algo = gemm_flops(M, F, F, H[0]) + gemm_flops(M, Hpp, F, Hq) + gemm_flops(M, Hq, F, tg.HL);   // all three layers of the reference graph
         ProfScope ps("cin_fwd_q", st, algo, gemm_flops(M, 1, F * (F / 2 + 1), H[0]) + gemm_flops(M, 1, F * (F / 2 + 1), Hpp));
+        // (K a power of two <= 32: a wave's rows are whole samples, and the pooled relayout + Dense(1) head ride in the epilogue)
+        CinHeadFold hf{};
+        if (K <= 32 && (K & (K - 1)) == 0 && knobs().headfold != 0) {
+          int ks = 0;
+          while ((1 << ks) < K) ++ks;
+          hf = CinHeadFold{pooled, output_dim == 1 ? out : nullptr, dense_w, dense_b, ks, (int)(L * K), p * K, lL * K};
+          head_done = true;
+        }
         cin_launch_fwdq(st, JTs, x2T, XL, Wf, WfT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
-                        const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0]);
+                        const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf);
         pa.chunks[0] = pa.chunks[p] = pa.chunks[lL] = 1;
       }
       FIL_CHECK_LAUNCH();
@@ -662,7 +674,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     xpT = xoutT;
   }
-  {
+  if (!head_done) {
     ProfScope ps("cin_head_fwd", st);
     hipLaunchKernelGGL(cin_head_fwd_kernel, dim3(cdiv(B, kHeadSamples)), dim3(256), (size_t)kHeadSamples * L * K * sizeof(float), st, pa, dense_w, dense_b, pooled,
                        output_dim == 1 ? out : nullptr, B, K, L);
@@ -736,6 +748,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   float* qt_dT = ws.take<float>((size_t)F * F * kCinMaxH);
   const int qt_ndc = (int)((M + 255) / 256);
   float* qt_dcpart = ws.take<float>((size_t)(qt_ndc + 1) * kQtConst);   // block partials | their sum
+  float* qt_hpart = ws.take<float>((size_t)qt_ndc * (LK + 1));           // merged launches: the dense head's block partials
 
   // saved tensors
   Carver sv(const_cast<float*>(saved));
@@ -765,7 +778,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
 
   // ---- head backward: dP, ddense_w, ddense_b
   const float* dPsrc = g;  // output_dim != 1: g is already dL/dpooled
-  if (output_dim == 1) {
+  if (output_dim == 1 && qmerge) {
+    dPsrc = dP;   // (merged launches: the head's backward rides in cin_qtail_xe_kernel / cin_reduce_expand_q_kernel, below)
+  } else if (output_dim == 1) {
     ProfScope ps("cin_head_bwd", st);
     hipLaunchKernelGGL(cin_head_bwd_kernel, dim3(nblk), dim3(256), 0, st, g, dense_w, pooled, dP, small, B, (int)LK, kHeadChunk);
     // (fused tail: the fixed-order sum of the head's partials rides in the tail's first launch, below)
@@ -806,15 +821,14 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     float* dxR = gxR + (size_t)M * F;
     {
       ProfScope ps("cin_tail_a", st, (double)M * (2 * F + 3) * sizeof(float));
-      const size_t sh = (size_t)256 * (F + 3) * sizeof(float);
+      const size_t sh = (size_t)256 * (F + 3 + (output_dim == 1 ? L : 0)) * sizeof(float);
       allow_lds(cin_qtail_xe_kernel, sh);
-      const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + the head's partial sums
       const int np = (int)std::min<long>(((long)tiles0 * 32 * HS0 + 255) / 256, 1024);   // + W1 in the dZ kernel's slot order
-      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + nh + np), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc, small,
-                         ddense_w, ddense_b, (int)LK, nblk, nh, W[0], Wz, H[0], JTs, HS0, tiles0);
+      // (output_dim == 1: + the dense head's backward -- dP and the block partials of ddense_w | ddense_b)
+      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + np), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc,
+                         output_dim == 1 ? g : nullptr, dense_w, pooled, dP, qt_hpart, (int)LK, lL, p, W[0], Wz, H[0], JTs, HS0, tiles0);
     }
     FIL_CHECK_LAUNCH();
-    ready(L);
     {
       ProfScope ps("cin_last_bwd", st, 6.0 * (double)M * Hpp * F);
       cin_launch_last_bwd2(st, JT, xT, xpT, xps, qtWsumP, qtWsnP, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL, small);
@@ -831,10 +845,13 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       // fixed-order sums of the partials -> dW1 (both rows of a pair), dT, v^T; + dbias1 from the column sums cin_last_bwd2_kernel left
       ProfScope ps("cin_reduce_dw", st);
       const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
-      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F) * 4 + cdiv(H[0], 64)), dim3(256), 0, st, part, dp.pairs, F, symD, H[0], Hpp, dW[0], qt_dT,
-                         vlast, small, ncol, dbias[0]);
+      const int nb1 = cdiv(H[0], 64);
+      const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + ddense_w | ddense_b from the head's block partials
+      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F) * 4 + nb1 + nh), dim3(256), 0, st, part, dp.pairs, F, symD, H[0], Hpp, dW[0], qt_dT,
+                         vlast, small, ncol, dbias[0], nb1, qt_hpart, qt_ndc, (int)LK, ddense_w, ddense_b);
     }
     FIL_CHECK_LAUNCH();
+    ready(L);
     ready(0);
     {
       ProfScope ps("cin_tail_params", st);

@@ -566,9 +566,6 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     for (int d = 0; d < DEPTH; ++d) q[d] = ldw(s_lo + d);
     float xa[MB][JT], xb[MB][JT], pa[MB], pb[MB];
     ldfrag(hs, xa, pa);
-#ifdef FIL_ABL_NOXLOAD
-    ldfrag(hs, xb, pb);
-#endif
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) settle(q[d]);
 #pragma unroll
@@ -578,18 +575,14 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
     for (int mb = 0; mb < MB; ++mb) ac[mb] = pa[mb] * xa[mb][0];
     // one value of h: fragment (xc, pc) in use, (xn_, pn) being fetched for h + 1
     auto run_h = [&](int h, float (&xc)[MB][JT], float (&pc)[MB], float (&xn_)[MB][JT], float (&pn)[MB]) {
-#ifndef FIL_ABL_NOXLOAD
       ldfrag(min(h + 1, Hp - 1), xn_, pn);
-#endif
       const int sb = h * JT;
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
         const f32x4s w = q[j % DEPTH];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) an[mb] = j + 1 < JT ? pc[mb] * xc[mb][j + 1 < JT ? j + 1 : 0] : pn[mb] * xn_[mb][0];
-#ifndef FIL_ABL_FWD_NOSB
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        __builtin_amdgcn_sched_barrier(0);   // (these three pin the step: without them the kernel runs 0.135 ms instead of 0.103)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const float a = ac[mb];
@@ -600,15 +593,9 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) ac[mb] = an[mb];
-#ifndef FIL_ABL_FWD_NOSB
         __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef FIL_ABL_NOWLOAD
         q[j % DEPTH] = ldw(sb + j + DEPTH);   // (after the step's MFMAs: it may land in the registers it replaces)
-#endif
-#ifndef FIL_ABL_FWD_NOSB
         __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     };
     int h = h_lo;
@@ -1198,13 +1185,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
 #pragma unroll
       for (int s4 = 0; s4 < NQ; ++s4) {
         const float4 w = q[s4];
-#if defined(FIL_ABL_DZ_NOW)
-        asm volatile("" : "+v"(q[s4].x), "+v"(q[s4].y), "+v"(q[s4].z), "+v"(q[s4].w));
-#elif defined(FIL_ABL_DZ_SAMEW)
-        q[s4] = wz[s4];
-#else
         q[s4] = wnext[s4];
-#endif
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           d[mb] = mfma32(w.x, greg[mb][4 * s4 + 0], d[mb]);
@@ -1213,11 +1194,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
           d[mb] = mfma32(w.w, greg[mb][4 * s4 + 3], d[mb]);
         }
         // previous tile's slots, spread over this tile's step groups (NQ is 16 or 32; 16 slots per tile)
-#ifdef FIL_ABL_DZ_NOSLOT
-        if (s4 < 1) {
-#else
         if (s4 < 16) {
-#endif
           if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, s4);
           else slot_apply(dprev, xcur, hbase, tp - 1, s4);
           if (s4 < 15) {

@@ -199,9 +199,15 @@ __global__ __launch_bounds__(kDwqThreads, 2) void cin_dwq_kernel(const float* __
 // Workgroups past those rows: the fixed-order sum of the nbp column-sum partials bpart [nbp][H1] -> dbias1 (cin_reduce_body).
 static __global__ __launch_bounds__(256) void cin_reduce_expand_q_kernel(const float* __restrict__ part, int parts, int F, int D, int H1, int H2,
                                                                           float* __restrict__ dW1, float* __restrict__ dT, float* __restrict__ vT,
-                                                                          const float* __restrict__ bpart, int nbp, float* __restrict__ dbias1) {
+                                                                          const float* __restrict__ bpart, int nbp, float* __restrict__ dbias1,
+                                                                          int nb1, const float* __restrict__ hpart, int nhp, int LK,
+                                                                          float* __restrict__ ddw, float* __restrict__ ddb) {
   const int Cp = F * D, C = Cp + F;
   const int nbw = C * 4;   // 64-column groups
+  if ((int)blockIdx.x >= nbw + nb1) {   // the dense head's block partials (cin_qtail_xe_kernel) -> ddense_w | ddense_b
+    cin_reduce_body(hpart, ddw, (long)LK + 1, nhp, ddb, (long)LK, (int)blockIdx.x - nbw - nb1);
+    return;
+  }
   if ((int)blockIdx.x >= nbw) {
     cin_reduce_body(bpart, dbias1, (long)H1, nbp, nullptr, 0, (int)blockIdx.x - nbw);
     return;
@@ -249,24 +255,39 @@ static __global__ __launch_bounds__(256) void cin_reduce_expand_q_kernel(const f
 static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
                                                                   const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xe,
                                                                   float* __restrict__ dcpart, int M, int F, int nscale,
-                                                                  const float* __restrict__ hpart, float* __restrict__ ddw, float* __restrict__ ddb,
-                                                                  int LK, int nhp, int nhead, const float* __restrict__ W0, float* __restrict__ Wz,
+                                                                  const float* __restrict__ g, const float* __restrict__ dense_w,
+                                                                  const float* __restrict__ pooled, float* __restrict__ dP, float* __restrict__ hpart,
+                                                                  int LK, int lL, int lp, const float* __restrict__ W0, float* __restrict__ Wz,
                                                                   int H0, int JTs, int HS0, int tiles0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x >= nscale + nhead) {   // the first layer's weights in the dZ kernel's slot order (nothing else uses that buffer here)
-    cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, blockIdx.x - nscale - nhead, gridDim.x - nscale - nhead);
+  if ((int)blockIdx.x >= nscale) {   // the first layer's weights in the dZ kernel's slot order (nothing else uses that buffer here)
+    cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, blockIdx.x - nscale, gridDim.x - nscale);
     return;
   }
-  if ((int)blockIdx.x >= nscale) {   // the dense head's partial sums -> ddense_w | ddense_b (fixed order)
-    cin_reduce_body(hpart, ddw, (long)LK + 1, nhp, ddb, (long)LK, blockIdx.x - nscale);
-    return;
-  }
-  const int ld = F + 3, XE = F + 3;
-  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  // row image: F products | dP_L | dP_p | (head) g * pooled of the row's column in each of the L = LK/K layers | g on the sample's first row
+  const int nl = g != nullptr ? LK / K : 0;
+  const int ld = F + 3 + nl, XE = F + 3;
+  const long m0 = (long)blockIdx.x * 256;
+  const long m = m0 + threadIdx.x;
   float* row = smem + threadIdx.x * ld;
   if (m < M) {
     const long b = m / K;
-    const float dl = dPL[b * ldp + (m - b * K)], dp = dPp[b * ldp + (m - b * K)];
+    const int k = (int)(m - b * K);
+    float dl, dp;
+    if (g != nullptr) {   // the dense head's backward rides here: dP[b, j] = g[b] dense_w[j], and this row's terms of ddense_w | ddense_b
+      const float gb = g[b];
+      for (int l = 0; l < nl; ++l) {
+        const float d = gb * dense_w[l * K + k];
+        dP[b * LK + l * K + k] = d;
+        row[F + 2 + l] = gb * pooled[b * LK + l * K + k];
+      }
+      row[F + 2 + nl] = k == 0 ? gb : 0.f;
+      dl = gb * dense_w[lL * K + k];
+      dp = gb * dense_w[lp * K + k];
+    } else {
+      dl = dPL[b * ldp + k];
+      dp = dPp[b * ldp + k];
+    }
     for (int f = 0; f < F; ++f) {
       const float v = xT[m * F + f];
       xe[m * XE + f] = v;
@@ -278,7 +299,7 @@ static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* _
     row[F] = dl;
     row[F + 1] = dp;
   } else {
-    for (int f = 0; f < F + 2; ++f) row[f] = 0.f;
+    for (int f = 0; f < ld; ++f) row[f] = 0.f;
   }
   __syncthreads();
   // column sums: wave q takes rows 64q .. 64q+63 of column f = lane, the four partial sums meet in wave order
@@ -293,6 +314,20 @@ static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* _
       }
     }
     cs[q][f] = t0 + t1;
+  }
+  // the head's partials of this block: column j = l K + k collects the rows whose k matches, in row order (fixed order); column LK = sum of g
+  if (g != nullptr) {
+    const int k0 = (int)(m0 % K);
+    for (int j = threadIdx.x; j <= LK; j += 256) {
+      float t = 0.f;
+      if (j < LK) {
+        const int l = j / K, k = j - l * K;
+        for (int rr = (k - k0 + K) % K; rr < 256; rr += K) t += smem[rr * ld + F + 2 + l];
+      } else {
+        for (int rr = (K - k0) % K; rr < 256; rr += K) t += smem[rr * ld + F + 2 + nl];
+      }
+      hpart[(long)blockIdx.x * (LK + 1) + j] = t;
+    }
   }
   __syncthreads();
   if (threadIdx.x < F + 2) dcpart[(long)blockIdx.x * kQtConst + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
@@ -370,11 +405,7 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     };
     // queue depth in step groups (half a tile ahead: 8 x 256 cycles covers the L2 latency; the full tile, 16, measured 7 us slower --
     // 32 more registers at the 256-register limit of two waves per SIMD)
-#ifdef FIL_ABL_DZ2_QD
-    constexpr int QD = FIL_ABL_DZ2_QD;
-#else
     constexpr int QD = 8;
-#endif
     f32x4s q[QD];
 #pragma unroll
     for (int s4 = 0; s4 < QD; ++s4) q[s4] = ldw(0, s4);
@@ -484,9 +515,7 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
 #pragma unroll
               for (int k = 0; k < G; ++k) slot_fetch(tp, k, k);   // first slots of this tile, applied behind the first block of the next one
             }
-#ifndef FIL_DZ2_NOSB
             __builtin_amdgcn_sched_barrier(0);
-#endif
           }
         }
         dprev = d;
@@ -553,6 +582,16 @@ void cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, 
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Forward of the first layer and of the quadratic form in ONE launch: [x1 | R] = pairs(x) [W1s | Ts] (+ b1), 256 output columns.
+// The sum-pool relayout and Dense(1) head folded into cin_fwdq_kernel's epilogue (three layers in the order first | p | L, K a power of
+// two <= 32: a wave's 32 rows are whole samples).  pooled == nullptr: the kernel leaves per-layer pool arrays for cin_head_fwd_kernel.
+struct CinHeadFold {
+  float* pooled;          // [B][LK]
+  float* out;             // [B] or nullptr (output_dim != 1)
+  const float* dense_w;   // [LK]
+  const float* dense_b;
+  int kshift, LK, op, oL; // K = 1 << kshift; column offsets p K and (L-1) K of the two upper layers
+};
+
 // Wave = 32 rows x 256 columns, two waves per SIMD (after the wrapped, position-major x rows took the fragment loads off the vector
 // memory pipeline, 32-row waves run the 128-column kernel 4 % faster than 64-row ones: the second wave covers prologue and
 // epilogue).  The generated operand and the x fragment of a step are paid once for both column halves, and all three sum-pools come
@@ -567,10 +606,11 @@ __global__ __launch_bounds__(256, 2) void cin_fwdq_kernel(const float* __restric
                                                           const float* __restrict__ bias1, const float* __restrict__ wsn, int JTG,
                                                           const float* __restrict__ cvec, float* __restrict__ x1T, float* __restrict__ RT, int HS,
                                                           float* __restrict__ pool1, float* __restrict__ pool_p, float* __restrict__ pool_L, int M, int F,
-                                                          int H) {
+                                                          int H, CinHeadFold hf) {
   constexpr int DEPTH = JT % 5 == 0 ? 5 : (JT % 4 == 0 ? 4 : (JT % 7 == 0 ? 7 : (JT % 3 == 0 ? 3 : 2)));
   static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
   __shared__ float lin_s[4][32];
+  __shared__ float pv_s[4][3][32];   // (head folded in) the wave's pooled values, then their products with dense_w
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int wrow0 = (blockIdx.x * 4 + wave) * 32;
@@ -722,14 +762,43 @@ __global__ __launch_bounds__(256, 2) void cin_fwdq_kernel(const float* __restric
     eL = half_wave_sum_hi(eL);
     ep = half_wave_sum_hi(ep);
     if (r == 31 && m < M) {
-      pool1[m] = p1;
-      pool_p[m] = ep + cp;
-      pool_L[m] = (eL + lin_s[wave][row]) + cL;
+      const float vp = ep + cp, vL = (eL + lin_s[wave][row]) + cL;
+      if (hf.pooled != nullptr) {   // pooled [B][L K] directly (row m = sample m >> kshift, position m & (K - 1))
+        float* pr = hf.pooled + (long)(m >> hf.kshift) * hf.LK + (m & ((1 << hf.kshift) - 1));
+        pr[0] = p1;
+        pr[hf.op] = vp;
+        pr[hf.oL] = vL;
+        pv_s[wave][0][row] = p1;
+        pv_s[wave][1][row] = vp;
+        pv_s[wave][2][row] = vL;
+      } else {
+        pool1[m] = p1;
+        pool_p[m] = vp;
+        pool_L[m] = vL;
+      }
     }
+  }
+  if (hf.out == nullptr) return;
+  // ---- the dense head of this wave's 32 >> kshift samples: out[b] = sum_j pooled[b, j] dense_w[j] + dense_b, the products first and
+  // then their sum in index order -- the arithmetic of cin_head_fwd_kernel, bit for bit
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int k = (wrow0 + r) & ((1 << hf.kshift) - 1);
+    const int o0 = half == 0 ? 0 : hf.op;
+    pv_s[wave][half][r] *= hf.dense_w[o0 + k];
+    if (half == 0) pv_s[wave][2][r] *= hf.dense_w[hf.oL + k];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int K = 1 << hf.kshift;
+  if (lane < (32 >> hf.kshift) && wrow0 + lane * K < M) {
+    float o = 0.f;
+    for (int l = 0; l < 3; ++l)
+      for (int k = 0; k < K; ++k) o += pv_s[wave][l][lane * K + k];
+    hf.out[(wrow0 >> hf.kshift) + lane] = o + hf.dense_b[0];
   }
 }
 
 void cin_launch_fwdq(hipStream_t st, int JT, const float* x2T, int XL, const float* W1f, const float* WTf, const float* bias1, const float* wsn, int JTG,
-                     const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H);
+                     const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H, CinHeadFold hf);
 
 }  // namespace fil

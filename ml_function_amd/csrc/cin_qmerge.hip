@@ -31,11 +31,11 @@ void cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, 
 }
 
 void cin_launch_fwdq(hipStream_t st, int JT, const float* x2T, int XL, const float* W1f, const float* WTf, const float* bias1, const float* wsn, int JTG,
-                     const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H) {
+                     const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H, CinHeadFold hf) {
 #define FIL_FQ(JTV)                                                                                                                             \
   case JTV:                                                                                                                                     \
     hipLaunchKernelGGL((cin_fwdq_kernel<JTV>), dim3(cdiv(M, 128)), dim3(kCinThreads), 0, st, x2T, XL, W1f, WTf, bias1, wsn, JTG, cvec, x1T, RT, HS, \
-                       pool1, pool_p, pool_L, M, F, H);                                                                                         \
+                       pool1, pool_p, pool_L, M, F, H, hf);                                                                                       \
     break;
   switch (JT) { FIL_FQ(2) FIL_FQ(4) FIL_FQ(6) FIL_FQ(8) FIL_FQ(10) FIL_FQ(12) FIL_FQ(14) FIL_FQ(16) FIL_FQ(18) }
 #undef FIL_FQ

@@ -165,7 +165,7 @@ def merge_segments_by_point(segments, points):
             merged.append((lo, hi))
             layer_of_event.append(l)
     # issue order = readiness order: the merged quadratic tail finishes the FIRST layer's gradients before the top two layers'
-    # (points [1, 2, 2, 0]); a collective queued behind a later event would wait for it although its own data is final
+    # (points [0, 1, 1, 0]: the head's come out with layer 0's); a collective queued behind a later event would wait for it although its own data is final
     order = sorted(range(len(merged)), key=lambda i: points[layer_of_event[i]])
     return [merged[i] for i in order], [layer_of_event[i] for i in order]
 

@@ -59,7 +59,7 @@ def run(lib):
     qt = (65536 * 128 + 39 * 39 * 128 + 128 * 39 + 128 + 128 * 39 + 40 * 128 + 26 * 32 * 128) * 4
     assert lib.fil_cin_saved_bytes(4096, 39, 16, 3, H3) == 65536 * 39 * 4 + 65536 * 128 * 4 + (qt + 255) // 256 * 256
     pts = (ctypes.c_int * 4)()
-    assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 0, pts) == 3 and list(pts) == [1, 2, 2, 0]     # merged quadratic tail: layer 0, then 1 + 2
+    assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 0, pts) == 2 and list(pts) == [0, 1, 1, 0]     # merged quadratic tail: layer 0 (+ the head), then 1 + 2
     assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 512, pts) == 3 and list(pts) == [2, 1, 1, 0]   # FIL_CIN_NOQMERGE: layers 1, 2 together first
     assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 32, pts) == 4 and list(pts) == [3, 2, 1, 0]    # FIL_CIN_NOTAIL
     assert lib.fil_cin_grad_ready_points(0, 39, 16, 3, H3, 0, pts) == 1 and list(pts) == [0, 0, 0, 0]

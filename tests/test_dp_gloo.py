@@ -124,7 +124,7 @@ def test_segments_merge_where_gradients_finish_together():
     # everything at once (empty batch)
     assert dp.merge_segments_by_point(segments, [0, 0, 0, 0]) == ([(0, 434)], [0])
     # merged quadratic tail: layer 0 is final BEFORE layers 1 + 2 -> its segment is issued first
-    assert dp.merge_segments_by_point(segments, [1, 2, 2, 0]) == ([(338, 434), (0, 338)], [0, 1])
+    assert dp.merge_segments_by_point(segments, [0, 1, 1, 0]) == ([(338, 434), (0, 338)], [0, 1])
     # four layers with the tail on top
     segs4 = [(0, 10), (10, 30), (30, 60), (60, 100)]
     assert dp.merge_segments_by_point(segs4, [3, 2, 1, 1, 0]) == ([(0, 30), (30, 60), (60, 100)], [2, 1, 0])
