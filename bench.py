@@ -360,17 +360,6 @@ def side_traffic(workload_name, kernel_scope):
     return None, None
 
 
-def _split_instance(key):
-    """Template instantiations with SPLIT = true belong to the split-bf16 experiment, not to the headline: SPLIT is argument 4 of
-    cin_fwd3_kernel<MB,JT,SYM,SPLIT,KS>, 5 of cin_dz3_kernel<MB,JT,WG,SYM,SPLIT,KS>, 2 of cin_dw3_kernel<MB,SPLIT,DEPTH>."""
-    name = key.split(" grid=")[0]
-    if "<" not in name:
-        return False
-    targs = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",")
-    pos = 3 if name.startswith("cin_fwd3") else 4 if name.startswith("cin_dz3") else 1 if name.startswith("cin_dw3") else None
-    return pos is not None and len(targs) > pos and targs[pos] == "true"
-
-
 def pmc_traffic(scope):
     """(HBM bytes per launch of the kernel behind profiler scope `scope`, name of the file they come from).  Hardware
     counters cannot be read from inside the timed run: the number is a LOOKUP in the newest committed PMC summary
@@ -400,7 +389,7 @@ def _gemm_launch_of(per, kind, layer):
         return hits[0] if hits else None
     prefixes = {"fwd": ("cin_fwd3_kernel", "cin_tail_fwd_kernel"), "bwd_dz": ("cin_dz3_kernel", "cin_tail_dz_kernel"),
                 "bwd_dw": ("cin_dw3_kernel", "cin_tail_dw_kernel")}[kind]
-    hits = sorted((v["first_dispatch"], k) for k, v in per.items() if k.startswith(prefixes) and not _split_instance(k))
+    hits = sorted((v["first_dispatch"], k) for k, v in per.items() if k.startswith(prefixes))
     if not hits:
         return None
     order = [k for _, k in hits] if kind == "fwd" else [k for _, k in hits][::-1]     # -> l1, l2, .., (tail)
@@ -658,29 +647,6 @@ def main():
                 "step_without_allreduce_ms": dt_nocomm / args.steps * 1e3,
                 "exposed_allreduce_ms": (dt - dt_nocomm) / args.steps * 1e3}
 
-    # candidate, reported beside the headline, never as it: the same step with every layer GEMM (incl. the pair-symmetric
-    # first layer) on split-bf16 operands (fil_cin mode bit 1; fp32-equivalent results)
-    split = None
-    if args.cin_mode == 0 and prof_on:
-        for _ in range(2):
-            step(mode=2)
-        _lib.profile_begin(GEMMS)
-        dt2 = max_over_ranks(timed_steps(lambda: step(mode=2), fence, args.steps))
-        prof2 = _lib.profile_end()
-        split = {"note": "NOT the headline (`value` is the exact-fp32 path): fil_cin mode 2 = split-bf16 GEMMs (3 bf16 pieces per "
-                         "fp32 operand, 6 bf16 MFMAs per product, fp32 accumulate) for every layer's fwd/dW/dZ incl. the "
-                         "pair-symmetric first layer; same 1e-5 / 2e-5 parity bars as the exact mode, green at this shape and "
-                         "over 1e-36..1e30 magnitudes, subnormal and non-finite inputs "
-                         "(tests/test_gpu_parity.py::test_cin_split_promotion_*, test_cin_at_the_benchmark_shape; DESIGN.md 4.1)",
-                 "value": world * shape["batch"] * args.steps / dt2 if args.scaling == "weak" else ns["shape"]["batch"] * args.steps / dt2,
-                 "unit": "samples/s", "ms_per_step": dt2 / args.steps * 1e3,
-                 "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(prof2.items())}}
-        dom2 = max(prof2, key=lambda k: prof2[k]["total_ms"])
-        # priced as what the pipe executes: 6 bf16 MFMA products per algorithmic multiply-add, against the dense bf16 peak
-        exe = 6.0 * prof2[dom2]["executed"] / (prof2[dom2]["avg_ms"] * 1e-3) / 1e12
-        split["roofline"] = {"bound": "mfma", "kernel": dom2, "achieved": exe, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": exe / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": prof2[dom2]["avg_ms"],
-                             "flops_per_launch": prof2[dom2]["executed"], "executed_flops_per_launch": 6.0 * prof2[dom2]["executed"]}
     # separate, untimed pass with every scope recorded: the per-kernel table of the small kernels
     prof_all, n_all = {}, max(2, args.steps // 4)
     if prof_on:
@@ -723,7 +689,7 @@ def main():
             "metric": "samples/sec fwd+bwd xDeepFM-CIN B=4096,F=39,K=16",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.cin_mode < 2 else "f32 (GEMMs: split-bf16 x3, fp32-equivalent; experiment)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "xDeepFM CIN 3x128 feature maps fwd+bwd, F=39 K=16, B=%d per GPU, fp32 "
                                    "(BASELINE.json configs[3])" % shape["batch"], "global_batch": global_batch,
                        "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if use_dist else 0},
@@ -774,8 +740,6 @@ def main():
             res["hipgraph_replay_ms_per_step"] = graph_ms
         if rccl is not None:
             res["rccl"] = rccl
-        if split is not None:
-            res["candidate_split_bf16"] = split
         if world == 1 and not args.stub and not args.no_side:
             res["side_workloads"] = side_workloads(args)
         if not args.no_cpu_baseline and world == 1 and not args.stub:  # reported at N=1 only (rank 0)

@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 209
+#define FIL_ABI_VERSION 210
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -96,10 +96,8 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *             the flops) and, for L >= 3, the layer below it contracted against [1 | wsum_L] (its map is only ever sum-pooled
  *             or fed to the last layer: F+1 observable columns instead of H_{L-1}; the "fused tail", csrc/cin_tail.h);
  *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
- *         + FIL_CIN_SPLIT_BF16 (2), opt-in and experimental: the three GEMMs (forward, dW, dZ) of the general layers
- *             l >= 1 run on split-bf16 operands (every fp32 value as three bf16 pieces, six bf16 MFMAs with fp32
- *             accumulation per product: the same measured error as modes 0/1, but not their exact-fp32 FMA chain);
- *             the pair-symmetric first layer and the last-layer shortcut stay exact fp32.
+ *         (bit 2 was the split-bf16 experiment of rounds 1-3 -- every GEMM on three bf16 pieces per operand; retired in ABI 210
+ *             once the exact path overtook it: FIL_ERR_UNSUPPORTED.)
  *         + FIL_CIN_X_TRANSPOSED (16), forward and backward alike: `x` is given transposed, [B*K][F] row-major (x_t[(b*K+k)*F+f]
  *           = x[b,f,k], as written by fil_embed_gather_xt): no input transpose, saved's own copy of it stays unused.  dx is
  *           still returned as [B,F,K].
@@ -171,7 +169,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
-enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_SPLIT_BF16 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
+enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_RETIRED_2 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
                          FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128, FIL_CIN_NOQTAIL = 256, FIL_CIN_NOQMERGE = 512 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);

@@ -203,9 +203,10 @@ static TailGeom tail_geom(const CinShape& s) {   // what the tail WOULD look lik
   g.uz_floats = (size_t)g.tiles * 64 * g.JHp;
   return g;
 }
-// is the tail used by a call with these mode bits?  (the split-bf16 experiment keeps the round-2 layer structure)
+constexpr int kCinRetiredBits = FIL_CIN_RETIRED_2;   // mode bits that no longer select anything: FIL_ERR_UNSUPPORTED
+// is the tail used by a call with these mode bits?
 static bool tail_used(const CinShape& s, int mode) {
-  if ((mode & (FIL_CIN_GENERAL | FIL_CIN_NOTAIL | FIL_CIN_SPLIT_BF16)) != 0) return false;
+  if ((mode & (FIL_CIN_GENERAL | FIL_CIN_NOTAIL)) != 0) return false;
   const TailGeom g = tail_geom(s);
   if (!g.on) return false;
   return (mode & FIL_CIN_TAIL_ALWAYS) != 0 || 4 * g.JP <= 3 * g.Hq;
@@ -274,9 +275,8 @@ static size_t wf_floats(const CinShape& s) {
   size_t w = 0;
   for (int l = 0; l < s.L; ++l) {
     w = std::max(w, (size_t)chunks_of(s.H[l]) * s.Hp(l) * 2 * s.JT() * 128);
-    w = std::max(w, cin_wb_floats(s.Hp(l), s.JT(), chunks_of(s.H[l])));   // split-bf16 planes (mode bit 1)
   }
-  w = std::max(w, cin_wb_sym_floats(s.F, cin_jt_sym(s.F), chunks_of(s.H[0])));   // ... of the pair-symmetric first layer
+  w = std::max(w, (size_t)chunks_of(s.H[0]) * s.F * 2 * cin_jt_sym(s.F) * 128);   // the pair-symmetric first layer
   w += (size_t)2 * 2 * s.JT() * 128;   // + the packed pooled weights of a fused last layer (<= 2 chunks)
   return w;
 }
@@ -286,9 +286,6 @@ static size_t wz_floats(const CinShape& s) {
   size_t w = ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
   w = std::max(w, (size_t)s.F * (s.F / 2 + 1) * s.H[0]);
   for (int l = 0; l < s.L; ++l) w = std::max(w, ((size_t)dz_periods(s, l) * cin_dz_tiles_per_period(s.JT()) + 1) * 32 * s.HS(l));
-  w = w + w / 2;   // the split-bf16 planes (mode bit 1) take 6 bytes per weight instead of 4
-  const TailGeom g = tail_geom(s);
-  (void)g;
   return w;
 }
 // column chunks a layer's pooled partials may come in: its own, or (last layer pooled by the epilogue of the layer
@@ -321,8 +318,6 @@ static size_t dw_part_floats(const CinShape& s) {
   }
   return pmax;
 }
-// bytes of G as three bf16 planes in row blocks of 16 (cin_split_g_kernel)
-static size_t gb_bytes(const CinShape& s) { return (size_t)((s.M() + 15) / 16) * (s.HSmax() / 128) * 12 * 1024; }
 static size_t bwd_ws_bytes(const CinShape& s) {
   const size_t LK = (size_t)s.L * s.K;
   const size_t M = (size_t)s.M();
@@ -337,7 +332,6 @@ static size_t bwd_ws_bytes(const CinShape& s) {
   t += 2 * align_up(cl * sizeof(float), 256);                            // wsum, v of the last layer
   t += align_up(wz_floats(s) * sizeof(float), 256);                      // packed W (slot order)
   t += 2 * align_up(M * s.F * sizeof(float), 256);                       // dxT, Gx^0
-  t += align_up(gb_bytes(s), 256);                                       // split-bf16 planes of G (mode bit 1)
   t += align_up((size_t)s.F * s.F * kCinMaxH * sizeof(float), 256);      // quadratic tail: dT
   t += align_up(((M + 255) / 256 + 1) * kQtConst * sizeof(float), 256);  //                 column-sum partials of dP_L x, their sum
   t += align_up(((M + 255) / 256) * (LK + 1) * sizeof(float), 256);      //                 the dense head's block partials (merged launches)
@@ -375,6 +369,7 @@ extern "C" int fil_cin_grad_ready_points(int B, int F, int K, int L, const int* 
   CinShape s;
   if (int rc = check_shape("fil_cin_grad_ready_points", B, F, K, L, H, s)) return rc;
   if (point == nullptr || mode < 0 || mode > 1023) return fail(FIL_ERR_ARG, "fil_cin_grad_ready_points: point == NULL or mode %d out of range", mode);
+  if ((mode & kCinRetiredBits) != 0) return fail(FIL_ERR_UNSUPPORTED, "fil_cin_grad_ready_points: mode %d holds a retired bit (2: the split-bf16 experiment)", mode);
   if (B == 0) {                                         // empty batch: zero gradients, every slot at once
     for (int i = 0; i <= L; ++i) point[i] = 0;
     return 1;
@@ -401,9 +396,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 1023)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE)", mode);
-  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;
+  if (mode < 0 || mode > 1023 || (mode & kCinRetiredBits) != 0)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE; 2 = the retired split-bf16 experiment)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);                    // last two layers as one implicit GEMM (cin_tail.h)
@@ -430,7 +424,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   float* qt_zbias = ws.take<float>((size_t)kCinMaxH);
   const int XL = cin_x2_len(F);
   float* x2T = ws.take<float>(cin_x2_floats(M, XL));
-  const bool need_x2 = tune.sym && !split;   // the exact pair-symmetric forward kernel reads the wrapped rows
+  const bool need_x2 = tune.sym;   // the pair-symmetric forward kernel reads the wrapped rows
   float* WfT = ws.take<float>((size_t)chunks_of(H[0]) * F * 2 * cin_jt_sym(F) * 128);
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
@@ -461,7 +455,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   // the exact pair-symmetric first layer + fused tail (the north-star path): every preparation job that depends on the inputs
   // alone -- x transpose, first-layer weight pack, pooled weights of the last layer, clearing the tail's operand buffers -- in ONE
   // launch instead of four
-  const bool prep_fused = tail && tune.sym && !split;
+  const bool prep_fused = tail && tune.sym;
   if (qtail) {
     FIL_CHECK_ARG(W[0] && W[L - 1] && W[L - 2]);
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
@@ -559,7 +553,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         const int ks = tune.ksplit(M);
         // (the kernel's own sum-pool output is not used: it goes to the last layer's slot, which the pool kernel below overwrites)
         cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, x2T, XL, Wf, qt_zbias, qtR, HS0,
-                            const_cast<float*>(pa.part[lL]), (int)M, F, Hpp, false, ks);
+                            const_cast<float*>(pa.part[lL]), (int)M, F, Hpp, ks);
       }
       FIL_CHECK_LAUNCH();
       {
@@ -631,30 +625,16 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       if (l == 0 && tune.sym) {
         // first layer: x^{l-1} = x, reduce over unordered field pairs (half the steps)
         const int JTs = cin_jt_sym(F);
-        if (split) {
-          const int hps = cin_sym_hps(JTs);
-          const long nvec = (long)cin_wb_sym_floats(F, JTs, chunks) / 4;
-          hipLaunchKernelGGL(cin_pack_wb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
-                             reinterpret_cast<bf16x8*>(Wf), F, F, Hl, JTs, (F + hps - 1) / hps, chunks, 1, hps);
-        } else {
-          const long npack = (long)chunks * F * 2 * JTs * 128;
-          if (!prep_fused)
-            hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
-        }
+        const long npack = (long)chunks * F * 2 * JTs * 128;
+        if (!prep_fused)
+          hipLaunchKernelGGL(cin_pack_wf_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, F, Hl, 2 * JTs, chunks);
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));   // (executed: unordered pairs)
-        const int ks = split ? 1 : tune.ksplit(M);
+        const int ks = tune.ksplit(M);
         cin_launch_fwd3_sym(st, MB, JTs, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MB), chunks), xT, x2T, XL, Wf, bias[l], xoutT, s.HS(l), part,
-                            (int)M, F, Hl, split, ks);
+                            (int)M, F, Hl, ks);
       } else {
-        long npack = (long)chunks * Hp * 2 * JT * 128;
-        if (split) {
-          npack = (long)cin_wb_floats(Hp, JT, chunks);
-          const long nvec = npack / 4;
-          hipLaunchKernelGGL(cin_pack_wb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
-                             reinterpret_cast<bf16x8*>(Wf), Hp, F, Hl, JT, (Hp + 3) / 4, chunks);
-        } else {
-          hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
-        }
+        const long npack = (long)chunks * Hp * 2 * JT * 128;
+        hipLaunchKernelGGL(cin_pack_wf_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wf, Hp, F, Hl, 2 * JT, chunks);
         const float* wsn = nullptr;
         if (fuse_next) {
           FIL_CHECK_ARG(W[l + 1] && bias[l + 1]);
@@ -667,8 +647,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         }
         ProfScope ps(kFwdNames[l], st, gemm_flops(M, Hp, F, Hl) + (fuse_next ? 2.0 * (double)M * Hl * F : 0.0));
         cin_launch_fwd3(st, MB, JT, dim3(cdiv((int)M, 128 * MB), chunks), xT, xpT, xps, Wf, bias[l], xoutT, s.HS(l), part, (int)M, F, Hp, Hl,
-                        wsn, fuse_next ? bias[l + 1] : nullptr, fuse_next ? H[l + 1] : 0, fuse_next ? const_cast<float*>(pa.part[l + 1]) : nullptr,
-                        split);
+                        wsn, fuse_next ? bias[l + 1] : nullptr, fuse_next ? H[l + 1] : 0, fuse_next ? const_cast<float*>(pa.part[l + 1]) : nullptr);
       }
     }
     FIL_CHECK_LAUNCH();
@@ -691,10 +670,9 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   CinShape s;
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
-  if (mode < 0 || mode > 1023)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 split-bf16 GEMMs, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE)", mode);
+  if (mode < 0 || mode > 1023 || (mode & kCinRetiredBits) != 0)
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE; 2 = the retired split-bf16 experiment)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
-  const bool split = (mode & FIL_CIN_SPLIT_BF16) != 0;   // (every layer GEMM incl. the pair-symmetric first layer; the last-layer shortcut stays exact fp32)
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);
   const bool qtail = qtail_used(s, mode, tune);
@@ -744,7 +722,6 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   float* Wz = ws.take<float>(wz_floats(s));
   float* dxT = ws.take<float>((size_t)M * F);
   float* gx0T = ws.take<float>((size_t)M * F);
-  bf16x8* Gb = reinterpret_cast<bf16x8*>(ws.take<char>(gb_bytes(s)));
   float* qt_dT = ws.take<float>((size_t)F * F * kCinMaxH);
   const int qt_ndc = (int)((M + 255) / 256);
   float* qt_dcpart = ws.take<float>((size_t)(qt_ndc + 1) * kQtConst);   // block partials | their sum
@@ -881,13 +858,13 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const dim3 zgrid(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs));
       {
         ProfScope ps("cin_bwd_dz_tail", st, algo_tail, gemm_flops(M, 1, Cl, Hpp));   // (T in slot order: packed and saved by the forward)
-        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp, periods, false, ks);
+        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp, periods, ks);
         // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
       }
       FIL_CHECK_LAUNCH();
       {
         ProfScope ps("cin_bwd_dz_l1", st, algo1, gemm_flops(M, 1, Cl, H[0]));
-        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, Gbuf[cur], HS0, Wz, xT, gx0T, dxT, 1, (int)M, F, H[0], periods, false, ks);
+        cin_launch_dz3_sym(st, MBs, JTs, NHMAX, zgrid, Gbuf[cur], HS0, Wz, xT, gx0T, dxT, 1, (int)M, F, H[0], periods, ks);
       }
       have_gx0 = true;
     }
@@ -968,7 +945,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const int MBs = two_waves ? 1 : tune.mb_rows(M);
       const int ks = MBs != 1 ? 1 : tune.ksplit(M);
       cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), xpT, HS0, qtWzT, xT, gxR, dxR, 0, (int)M, F, Hpp,
-                         periods, false, ks);
+                         periods, ks);
       // (gxR + dxR, scaled by dP_L, and the linear term join dX in the final transpose)
     }
     FIL_CHECK_LAUNCH();
@@ -984,7 +961,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     float* Apk = Gbuf[1];
     // the first general layer below the tail is the pair-symmetric layer 0 (L == 3): its slot-ordered weights can be packed now
     // (nothing else uses the packed-W buffer any more), together with A and the head's partial sums -- one launch for the three
-    wz_prepacked = p == 1 && tune.sym && F >= 2 && !split;
+    wz_prepacked = p == 1 && tune.sym && F >= 2;
     {
       ProfScope ps("cin_tail_a", st, (double)M * (F + 64) * sizeof(float));
       const int na = (int)std::min<long>((M * 16 * tg.NCB + 255) / 256, 4096);
@@ -1108,18 +1085,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     const int Cl = symD > 0 ? F * symD : Hp * F;
     {
       ProfScope ps(kDwNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, Cl, Hl));
-      if (split) {
-        // opt-in split-bf16 GEMM: G re-laid as three bf16 planes (inside the scope: it is part of this GEMM's cost)
-        const long nthr = ((M + 15) / 16) * (HSl / 128) * 64;
-        hipLaunchKernelGGL(cin_split_g_kernel, dim3((int)std::min<long>((nthr + 255) / 256, 8192)), dim3(256), 0, st, G, HSl, Gb, (int)M, Hl);
-        const DwPlan p = dw_plan(M, Cl, Hl);
-        const int items = p.blocks_x * p.splits * p.chunks;
-        hipLaunchKernelGGL(cin_dw3b_kernel, dim3((items + 7) / 8 * 8), dim3(kCinThreads), 0, st, Gb, xT, xpT, xps, part, (int)M, F, Hp, Hl,
-                           p.rows_per_split, p.blocks_x, p.chunks, items, symD);
-        parts = p.splits;
-      } else {
-        parts = launch_dw3(st, dw_plan(M, Cl, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl, symD);
-      }
+      parts = launch_dw3(st, dw_plan(M, Cl, Hl), G, HSl, xT, xpT, xps, part, M, F, Hp, Hl, symD);
     }
     FIL_CHECK_LAUNCH();
     const long nW = (long)Cl * Hl;
@@ -1136,7 +1102,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const int NHMAX = HSl / 2;                  // 64 (H <= 128) or 128
       const int MB = NHMAX == 128 ? 1 : tune.mb_rows(M);      // pair-symmetric first layer: 64 rows per wave measured best
       // general dZ kernel: 32 rows per wave, two waves per SIMD -- the second wave covers the issue time of the first
-      // one's register contraction (c4: 0.715 -> 0.687 ms exact fp32, 0.436 -> 0.420 split-bf16); FIL_CIN_DZ_MB overrides
+      // one's register contraction (c4: 0.715 -> 0.687 ms); FIL_CIN_DZ_MB overrides
       const int MBg = NHMAX == 128 ? 1 : ((knobs().dz_mb == 2 && JT <= 28) ? 2 : 1);   // (JT = 32 at 64 rows: scratch + line buffers > 160 KB of LDS)
       const float* dPprev = l > 0 ? dPsrc + (size_t)(l - 1) * K : nullptr;
       if (l == 0 && tune.sym && F >= 2) {
@@ -1149,33 +1115,23 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
         // covers the first one's prologue, epilogue and contraction issue: c4 0.154 -> 0.136 ms); FIL_CIN_MB2 / FIL_CIN_MB=2 /
         // FIL_CIN_DZS_MB=2 keep 64 rows per wave
         const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;
-        const int MBs = split ? MBg : (two_waves ? 1 : MB);
-        if (split) {
-          const long nvec = (long)tiles * (HSl / 16) * 3 * 64;
-          hipLaunchKernelGGL(cin_pack_wzb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
-                             reinterpret_cast<bf16x8*>(Wz), F, F, Hl, JTs, HSl, tiles, 1);
-        } else if (!wz_prepacked) {
+        const int MBs = two_waves ? 1 : MB;
+        if (!wz_prepacked) {
           hipLaunchKernelGGL(cin_pack_wz_sym_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, F, Hl, JTs, HSl, tiles);
         }
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl), gemm_flops(M, 1, F * (F / 2 + 1), Hl));
-        const int ks = (split || NHMAX != 64 || MBs != 1) ? 1 : tune.ksplit(M);
+        const int ks = (NHMAX != 64 || MBs != 1) ? 1 : tune.ksplit(M);
         cin_launch_dz3_sym(st, MBs, JTs, NHMAX, dim3(ks == 4 ? cdiv((int)M, 32) : cdiv((int)M, 128 * MBs)), G, HSl, Wz, xT, gx0T, dxT,
-                           dx_started ? 1 : 0, (int)M, F, Hl, periods, split, ks);
+                           dx_started ? 1 : 0, (int)M, F, Hl, periods, ks);
       } else {
         const int periods = dz_periods(s, l);
         const int tiles = periods * cin_dz_tiles_per_period(JT) + 1;
         const long npack = (long)tiles * 32 * HSl;
-        if (split) {
-          const long nvec = (long)tiles * (HSl / 16) * 3 * 64;
-          hipLaunchKernelGGL(cin_pack_wzb_kernel, dim3((int)std::min<long>((nvec + 255) / 256, 2048)), dim3(256), 0, st, W[l],
-                             reinterpret_cast<bf16x8*>(Wz), Hp, F, Hl, JT, HSl, tiles);
-        } else {
-          hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
-        }
+        hipLaunchKernelGGL(cin_pack_wz_kernel, dim3((int)std::min<long>((npack + 255) / 256, 2048)), dim3(256), 0, st, W[l], Wz, Hp, F, Hl, JT, HSl, tiles);
         ProfScope ps(kDzNames[l], st, gemm_flops(M, Hp, F, Hl));
         cin_launch_dz3(st, MBg, JT, NHMAX, dim3(cdiv((int)M, 128 * MBg)), G, HSl, Wz, xT, xpT, xps, dPprev, (int)LK, K,
                        l > 0 ? Gbuf[cur ^ 1] : nullptr, l > 0 ? s.HS(l - 1) : 0, l == 0 ? gx0T : nullptr, dxT, dx_started ? 1 : 0,
-                       (int)M, F, Hp, Hl, periods, split);
+                       (int)M, F, Hp, Hl, periods);
       }
       dx_started = true;
       if (l == 0) have_gx0 = true;

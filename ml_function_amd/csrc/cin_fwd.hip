@@ -7,22 +7,18 @@ namespace fil {
 template <int MB, int JT>
 static void fwd3(hipStream_t st, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf, const float* bias,
                  float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H, const float* wsn, const float* bias_next,
-                 int H_next, float* pool_next, bool split) {
-  if (split)
-    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, false, true>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M,
-                       F, Hp, H, wsn, bias_next, H_next, pool_next);
-  else
-    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H,
-                       wsn, bias_next, H_next, pool_next);
+                 int H_next, float* pool_next) {
+  hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT>), grid, dim3(kCinThreads), 0, st, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn,
+                     bias_next, H_next, pool_next);
 }
 
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
                      const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H, const float* wsn,
-                     const float* bias_next, int H_next, float* pool_next, bool split) {
+                     const float* bias_next, int H_next, float* pool_next) {
 #define FIL_F3(JTV)                                                                                                                      \
   case JTV:                                                                                                                              \
-    if (MB == 2) fwd3<2, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next, split);   \
-    else fwd3<1, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next, split);           \
+    if (MB == 2) fwd3<2, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next);   \
+    else fwd3<1, JTV>(st, grid, xT, xpT, xps, Wf, bias, xoutT, HS, pool_part, M, F, Hp, H, wsn, bias_next, H_next, pool_next);           \
     break;
   switch (JT) { FIL_F3(4) FIL_F3(8) FIL_F3(12) FIL_F3(16) FIL_F3(20) FIL_F3(24) FIL_F3(28) FIL_F3(32) }
 #undef FIL_F3
@@ -30,29 +26,25 @@ void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT,
 
 template <int MB, int JT>
 static void fwd3s(hipStream_t st, dim3 grid, const float* xT, const float* x2T, int XL, const float* Wf, const float* bias, float* xoutT, int HS,
-                  float* pool_part, int M, int F, int H, bool split, int ks) {
-  // exact kernels: the wrapped rows x2T [M][XL] travel in the xpT / xps slots (x^{l-1} = x needs no operand of its own)
+                  float* pool_part, int M, int F, int H, int ks) {
+  // the wrapped rows x2T [M][XL] travel in the xpT / xps slots (x^{l-1} = x needs no operand of its own)
   if constexpr (MB == 1) {
-    if (ks == 4 && !split) {
-      hipLaunchKernelGGL((cin_fwd3_kernel<1, JT, true, false, 4>), grid, dim3(kCinThreads), 0, st, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F,
+    if (ks == 4) {
+      hipLaunchKernelGGL((cin_fwd3_kernel<1, JT, true, 4>), grid, dim3(kCinThreads), 0, st, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F,
                          F, H, nullptr, nullptr, 0, nullptr);
       return;
     }
   }
-  if (split)
-    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, true, true>), grid, dim3(kCinThreads), 0, st, xT, xT, F, Wf, bias, xoutT, HS, pool_part, M, F, F,
-                       H, nullptr, nullptr, 0, nullptr);
-  else
-    hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, true>), grid, dim3(kCinThreads), 0, st, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, F, H,
-                       nullptr, nullptr, 0, nullptr);
+  hipLaunchKernelGGL((cin_fwd3_kernel<MB, JT, true>), grid, dim3(kCinThreads), 0, st, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, F, H,
+                     nullptr, nullptr, 0, nullptr);
 }
 
 void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* x2T, int XL, const float* Wf, const float* bias,
-                         float* xoutT, int HS, float* pool_part, int M, int F, int H, bool split, int ks) {
+                         float* xoutT, int HS, float* pool_part, int M, int F, int H, int ks) {
 #define FIL_F3S(JTV)                                                                             \
   case JTV:                                                                                      \
-    if (MB == 2) fwd3s<2, JTV>(st, grid, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, H, split, 1);  \
-    else fwd3s<1, JTV>(st, grid, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, H, split, ks);         \
+    if (MB == 2) fwd3s<2, JTV>(st, grid, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, H, 1);  \
+    else fwd3s<1, JTV>(st, grid, xT, x2T, XL, Wf, bias, xoutT, HS, pool_part, M, F, H, ks);         \
     break;
   switch (JT) { FIL_F3S(2) FIL_F3S(4) FIL_F3S(6) FIL_F3S(8) FIL_F3S(10) FIL_F3S(12) FIL_F3S(14) FIL_F3S(16) FIL_F3S(18) }
 #undef FIL_F3S

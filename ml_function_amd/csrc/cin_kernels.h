@@ -182,96 +182,6 @@ static __global__ __launch_bounds__(256) void cin_pack_wf_sym_kernel(const float
   cin_pack_wf_sym_body(W, Wf, F, H, JT2, chunks, blockIdx.x, gridDim.x);
 }
 
-// ---- split-bf16 ("bf16x3") operands -------------------------------------------------------------------------------
-// fp32 value v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) (3 x 8 significand bits).
-// A product a*b is then a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 (+ terms below 2^-24 relative, dropped): six bf16 MFMAs
-// with fp32 accumulation on the separate bf16 matrix pipe (16x the f32-MFMA rate) instead of one f32 MFMA step, and the
-// split's VALU work hides behind them (tools/probe_bf16x3.hip).  Opt-in (mode bit 1): the exact-fp32 kernels stay the default.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x16 mfma32b(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ void split3(const float (&p)[8], bf16x8& a1, bf16x8& a2, bf16x8& a3) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h1 = (__bf16)p[i];
-    const float r1 = p[i] - (float)h1;
-    const __bf16 h2 = (__bf16)r1;
-    const float r2 = r1 - (float)h2;
-    a1[i] = h1;
-    a2[i] = h2;
-    a3[i] = (__bf16)r2;
-  }
-}
-
-// acc += a * b to fp32 accuracy from the split operands (small terms first)
-__device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-  c = mfma32b(a[2], b[0], c);
-  c = mfma32b(a[0], b[2], c);
-  c = mfma32b(a[1], b[1], c);
-  c = mfma32b(a[1], b[0], c);
-  c = mfma32b(a[0], b[1], c);
-  c = mfma32b(a[0], b[0], c);
-  return c;
-}
-
-// Split-bf16 forward weights.  The reduction runs in groups of 8 steps; a super-period = 4 values of h = 4*JT steps =
-// JT/2 groups (even, JT being a multiple of 4: the kernel double-buffers groups).  Group gg of super-period sp, element e: step s = 8*gg + e,
-// h = 4*sp + s / JT, j = s % JT, f = 2j + half.  Layout [chunk][sp][gg][plane][nb][lane 64][8 bf16]: one aligned
-// 16-byte load per (group, plane, nb) and lane; lane r owns columns 4r..4r+3 (nb) of the chunk.
-//
-// sym (pair-symmetric first layer, Hp = F): the super-period holds hps = 4 or 8 values of h (8 when JT is not a multiple of 4,
-// so that the group count stays even), step (h, j) of lane half `half` is the pair (h, f = (h + d) mod F), d = 2j + half, and
-// carries the pair weight of cin_pack_wf_sym_kernel (W[(h,h)]; W[(h,f)] + W[(f,h)], halved at 2d == F; zero for d > F/2).
-static __global__ __launch_bounds__(256) void cin_pack_wb_kernel(const float* __restrict__ W, bf16x8* __restrict__ Wb, int Hp, int F, int H,
-                                                          int JT, int nsp, int chunks, int sym = 0, int hps = 4) {
-  const int ngs = hps * JT / 8;  // groups per super-period
-  const long total = (long)chunks * nsp * ngs * 12 * 64;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    long t = idx >> 6;
-    const int nb = (int)(t & 3);
-    t >>= 2;
-    const int plane = (int)(t % 3);
-    t /= 3;
-    const int gg = (int)(t % ngs);
-    t /= ngs;
-    const int sp = (int)(t % nsp), chunk = (int)(t / nsp);
-    const int r = lane & 31, half = lane >> 5;
-    const int n = chunk * 128 + 4 * r + nb;
-    bf16x8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int s = 8 * gg + e;
-      const int h = hps * sp + s / JT, j = s % JT;
-      const int f = 2 * j + half;
-      float w = 0.f;
-      if (sym) {
-        const int d = f;
-        if (h < F && n < H && d <= F / 2) {
-          const int fp = (h + d) % F;
-          if (d == 0) w = W[((long)h * F + h) * H + n];
-          else {
-            w = W[((long)h * F + fp) * H + n] + W[((long)fp * F + h) * H + n];
-            if (2 * d == F) w *= 0.5f;
-          }
-        }
-      } else {
-        w = (h < Hp && f < F && n < H) ? W[((long)h * F + f) * H + n] : 0.f;
-      }
-      const __bf16 h1 = (__bf16)w;
-      const float r1 = w - (float)h1;
-      const __bf16 h2 = (__bf16)r1;
-      const __bf16 h3 = (__bf16)(r1 - (float)h2);
-      out[e] = plane == 0 ? h1 : (plane == 1 ? h2 : h3);
-    }
-    Wb[idx] = out;
-  }
-}
-
 // Forward layer, streaming form.  Wave = 32*MB rows x 128 columns (one chunk); step (h, j): half 0 / 1 take
 // f = 2j / 2j+1; the W row pair of step s = h*JT + j is Wf row 2s+half, so the B-operand stream is linear.
 // x^{l-1}[m,h] is one dword per h (prefetched); the queue holds DEPTH steps of B operands (16 B per lane each).
@@ -281,13 +191,10 @@ static __global__ __launch_bounds__(256) void cin_pack_wb_kernel(const float* __
 // (cin_pack_wf_sym_kernel): half the MFMA work.  Step (h, j) then multiplies by x[m,(h + 2j + half) mod F], which
 // moves with h, so the x fragment is re-fetched per h (one h ahead) instead of living in registers for the whole run.
 //
-// SPLIT (opt-in, general layers): the main loop runs on split-bf16 operands (see above); Wf then points to the
-// cin_pack_wb_kernel layout.  Prologue, epilogue and the fused next-layer pooling are shared with the fp32 form.
-//
-// KS > 1 (exact kernels only; small M: fewer row blocks than SIMDs): KS waves of the workgroup share one row block and split the
+// KS > 1 (small M: fewer row blocks than SIMDs): KS waves of the workgroup share one row block and split the
 // reduction over h between them; the partial accumulators are folded through LDS in wave order and the group's first wave runs
 // the epilogue (see cin_tail_fwd_kernel).
-template <int MB, int JT, bool SYM = false, bool SPLIT = false, int KS = 1>
+template <int MB, int JT, bool SYM = false, int KS = 1>
 __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                           const float* __restrict__ Wf, const float* __restrict__ bias,
                                                           float* __restrict__ xoutT, int HS, float* __restrict__ pool_part, int M,
@@ -297,7 +204,6 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   // queue depth: the largest divisor of JT not above kQDepthMax (slot j % DEPTH must mean the same step in every h)
   constexpr int DEPTH = JT <= kQDepthMax ? JT : (JT % 10 == 0 ? 10 : (JT % 8 == 0 ? 8 : (JT % 7 == 0 ? 7 : (JT % 6 == 0 ? 6 : 4))));
   static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
-  static_assert(KS == 1 || !SPLIT, "the h split exists for the exact kernels");
   const int tid = threadIdx.x, lane = tid & 63, wave = KS == 1 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
   const int chunk = blockIdx.y;
@@ -310,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
   const int hs = min(h_lo, Hp - 1);
   long mq[MB];
   bool vq[MB];
-  float xr[MB][JT];   // (unused by the SYM + SPLIT form: it keeps a sliding window instead)
+  float xr[MB][JT];
   float xn[SYM ? MB : 1][SYM ? JT : 1];
   int d0[SYM ? JT : 1];  // (2j + half) mod F
   if constexpr (SYM) {
@@ -353,182 +259,7 @@ __global__ __launch_bounds__(256, 1) void cin_fwd3_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
-  if constexpr (SPLIT && SYM) {
-    // Pair-symmetric first layer on split-bf16 operands.  Step (h, j) of a lane multiplies x[m,h] by x[m,(h + 2j + half) mod F]:
-    // the second factor moves with h, so the lane keeps a sliding window wl[t] = x[m,(h0 + half + t) mod F] over the
-    // super-period's HPS values of h (h0 = HPS*sp); the next super-period's window is this one shifted by HPS, i.e. HPS
-    // new values per super-period, fetched one super-period ahead together with the next x[m,h] values.
-    constexpr int HPS = JT % 4 == 0 ? 4 : 8;   // h per super-period (an even number of 8-step groups)
-    constexpr int NGS = HPS * JT / 8;
-    constexpr int WS = HPS + 2 * JT - 2;       // window length: t = u + 2j, u < HPS, j < JT
-    static_assert(NGS % 2 == 0 && JT % 2 == 0, "groups per super-period must be even");
-    const int nsp = (F + HPS - 1) / HPS;
-    const long chunk_bytes = (long)nsp * NGS * 12 * 1024;
-    const __amdgpu_buffer_rsrc_t rw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wf) + (long)chunk * (chunk_bytes >> 2), 0, (int)chunk_bytes, 0x00020000);
-    const int vo = lane * 16;
-    u32x4 bb[2][12];
-    auto fetch_group = [&](int grp, u32x4 (&dst)[12]) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (grp * 12 + i) * 1024, 0));
-    };
-    fetch_group(0, bb[0]);
-    const float* xrow[MB];
-    float wl[MB][WS], wnew[MB][HPS], xph[MB][HPS], xpn[MB][HPS];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      xrow[mb] = xT + mq[mb] * F;
-#pragma unroll
-      for (int t = 0; t < WS; ++t) wl[mb][t] = xrow[mb][(half + t) % F];
-#pragma unroll
-      for (int u = 0; u < HPS; ++u) xph[mb][u] = xrow[mb][u % F];
-    }
-    auto make_a = [&](const float (&xp)[MB][HPS], const float (&win)[MB][WS], int gg, int mb, bf16x8 (&a)[3]) {
-      float p[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int st = 8 * gg + e;  // compile-time
-        p[e] = xp[mb][st / JT] * win[mb][st / JT + 2 * (st % JT)];
-      }
-      split3(p, a[0], a[1], a[2]);
-    };
-    bf16x8 acur[3], anext[3];
-    make_a(xph, wl, 0, 0, acur);
-#pragma unroll 1
-    for (int sp = 0; sp < nsp; ++sp) {
-      // next super-period: x[m, h0' + u] and the HPS window entries that slide in (h >= F steps meet zero weights)
-      const int h1 = HPS * (sp + 1);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int u = 0; u < HPS; ++u) {
-          xpn[mb][u] = xrow[mb][(h1 + u) % F];
-          wnew[mb][u] = xrow[mb][(h1 + half + WS - HPS + u) % F];
-        }
-#pragma unroll
-      for (int gg = 0; gg < NGS; ++gg) {
-        fetch_group(sp * NGS + gg + 1, bb[(gg + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 b[4][3];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bb[gg & 1][pl * 4 + nb]);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          if (mb + 1 < MB) make_a(xph, wl, gg, mb + 1, anext);
-          else if (gg + 1 < NGS) make_a(xph, wl, gg + 1, 0, anext);
-          else {
-            // first unit of the next super-period: its window is this one shifted by HPS (entries beyond it: wnew)
-            float p[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int t = e / JT + 2 * (e % JT) + HPS;   // compile-time; e < 8 <= steps of the first group
-              p[e] = xpn[0][e / JT] * (t < WS ? wl[0][t < WS ? t : 0] : wnew[0][t >= WS ? t - WS : 0]);
-            }
-            split3(p, anext[0], anext[1], anext[2]);
-          }
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma_split(acur, b[nb], acc[mb][nb]);
-#pragma unroll
-          for (int i = 0; i < 24; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU behind it
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) acur[pl] = anext[pl];
-        }
-      }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int t = 0; t + HPS < WS; ++t) wl[mb][t] = wl[mb][t + HPS];
-#pragma unroll
-        for (int u = 0; u < HPS; ++u) {
-          wl[mb][WS - HPS + u] = wnew[mb][u];
-          xph[mb][u] = xpn[mb][u];
-        }
-      }
-    }
-  } else if constexpr (SPLIT) {
-    static_assert(JT % 4 == 0, "groups per super-period must be even");
-    constexpr int NGS = JT / 2;  // groups of 8 steps per super-period of 4 h
-    const int nsp = (Hp + 3) >> 2;
-    const long chunk_bytes = (long)nsp * NGS * 12 * 1024;
-    const __amdgpu_buffer_rsrc_t rw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wf) + (long)chunk * (chunk_bytes >> 2), 0, (int)chunk_bytes, 0x00020000);
-    // B planes: a register double buffer per wave, fetched one group ahead with scalar-offset buffer loads.  (Sharing
-    // them between the 4 waves through LDS-DMA + one barrier per group was tried: same speed, so the L2 stream is not
-    // what holds this loop at ~60 % of the bf16 pipe.)
-    const int vo = lane * 16;
-    u32x4 bb[2][12];
-    auto fetch_group = [&](int grp, u32x4 (&dst)[12]) {  // grp = sp*NGS + gg (uniform); past the end reads zeros
-#pragma unroll
-      for (int i = 0; i < 12; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, (grp * 12 + i) * 1024, 0));
-    };
-    fetch_group(0, bb[0]);
-    const float* xprow[MB];
-    float xph[MB][4], xpn[MB][4];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      xprow[mb] = xpT + mq[mb] * xps;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xph[mb][u] = xprow[mb][min(u, Hp - 1)];   // (h >= Hp meets zero weights: any finite value)
-    }
-    // A operand of unit (gg, mb): the 8 products x^{l-1}[m,h] * x[m,f] of the group's steps, split into three bf16 planes
-    auto make_a = [&](const float (&xp4)[MB][4], int gg, int mb, bf16x8 (&a)[3]) {
-      float p[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int st = 8 * gg + e;  // compile-time
-        p[e] = xp4[mb][st / JT] * xr[mb][st % JT];
-      }
-      split3(p, a[0], a[1], a[2]);
-    };
-    // Software pipeline over the units (gg, mb): the split of the NEXT unit's A operand is issued alongside the 24 MFMAs
-    // of the current one (bf16 MFMAs run on their own pipe; VALU issued between them is hidden, VALU issued in a
-    // block is not), the B planes of the next group are fetched one group ahead.
-    bf16x8 acur[3], anext[3];
-    make_a(xph, 0, 0, acur);
-#pragma unroll 1
-    for (int sp = 0; sp < nsp; ++sp) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xpn[mb][u] = xprow[mb][min(4 * (sp + 1) + u, Hp - 1)];   // branch-free (see the fp32 loop)
-#pragma unroll
-      for (int gg = 0; gg < NGS; ++gg) {
-        fetch_group(sp * NGS + gg + 1, bb[(gg + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);  // keep the fetch here (the scheduler would sink it to its use)
-        bf16x8 b[4][3];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bb[gg & 1][pl * 4 + nb]);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          if (mb + 1 < MB) make_a(xph, gg, mb + 1, anext);
-          else if (gg + 1 < NGS) make_a(xph, gg + 1, 0, anext);
-          else make_a(xpn, 0, 0, anext);
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma_split(acur, b[nb], acc[mb][nb]);
-#pragma unroll
-          for (int i = 0; i < 24; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU behind it
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) acur[pl] = anext[pl];
-        }
-      }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xph[mb][u] = xpn[mb][u];
-    }
-  } else if constexpr (SYM) {
+  if constexpr (SYM) {
     // Exact pair-symmetric first layer.  Step (h, j) of lane half `half` multiplies x[m,h] by x[m,(h + 2j + half) mod F], read from the
     // WRAPPED, position-major rows x2 (cin_transpose_in_body; xpT / xps carry x2T / XL here) as x2[m][h + 2j + half]: the lane part of
     // the address is a constant, h a scalar offset and 2j an immediate -- raw buffer loads, no per-load index arithmetic, two lines per
@@ -822,53 +553,6 @@ static __global__ __launch_bounds__(256) void cin_pack_wz_sym_kernel(const float
   cin_pack_wz_sym_body(W, Wz, F, H, JT, NCOL, tiles, blockIdx.x, gridDim.x);
 }
 
-// Split-bf16 form of Wz: [(tile*NT + t)*3 + plane][lane 64][8 bf16], NT = NCOL/16.  Element e of lane (r, half) is the
-// plane of Wz[tile][row r][col = half*NCOL/2 + 8t + e] (rows and columns as in cin_pack_wz_kernel).
-// sym: the pair weights of cin_pack_wz_sym_kernel (slot (h, j), parity hf <-> pair (h, (h + 2j + hf) mod F)).
-static __global__ __launch_bounds__(256) void cin_pack_wzb_kernel(const float* __restrict__ W, bf16x8* __restrict__ Wzb, int Hp, int F, int H,
-                                                           int JT, int NCOL, int tiles, int sym = 0) {
-  const int NT = NCOL / 16;
-  const long total = (long)tiles * NT * 3 * 64;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    long u = idx >> 6;
-    const int plane = (int)(u % 3);
-    u /= 3;
-    const int t = (int)(u % NT);
-    const long tile = u / NT;
-    const int i = lane & 31, half = lane >> 5;
-    const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
-    const long slot = 16 * tile + rr;
-    const int h = (int)(slot / JT), j = (int)(slot - (long)h * JT);
-    const int f = 2 * j + hf;
-    bf16x8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int col = half * (NCOL / 2) + 8 * t + e;
-      float w = 0.f;
-      if (sym) {
-        const int d = f;
-        if (h < F && d <= F / 2 && col < H) {
-          const int fp = (h + d) % F;
-          if (d == 0) w = W[((long)h * F + h) * H + col];
-          else {
-            w = W[((long)h * F + fp) * H + col] + W[((long)fp * F + h) * H + col];
-            if (2 * d == F) w *= 0.5f;
-          }
-        }
-      } else {
-        w = (h < Hp && f < F && col < H) ? W[((long)h * F + f) * H + col] : 0.f;
-      }
-      const __bf16 h1 = (__bf16)w;
-      const float r1 = w - (float)h1;
-      const __bf16 h2 = (__bf16)r1;
-      const __bf16 h3 = (__bf16)(r1 - (float)h2);
-      out[e] = plane == 0 ? h1 : (plane == 1 ? h2 : h3);
-    }
-    Wzb[idx] = out;
-  }
-}
-
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
 // Backward data path, streaming form.  Wave = 32*MB rows m (on the lanes).  dZ^T tile = Wz tile (32 slot rows,
@@ -892,19 +576,15 @@ constexpr int kSymStride = 160;  // 4 waves x 32 rows + 32: consecutive f land i
 // per row and the wave flushes whole 128-byte lines (8 lanes x 16 bytes per row).
 constexpr int kGlStride = 36;    // floats per buffered row: 16-byte aligned, rows 36 banks apart
 
-//
-// SPLIT (opt-in, general layers): dZ^T = W G^T on split-bf16 operands -- Wz then points to the three bf16 planes of the
-// slot-ordered weights (cin_pack_wzb_kernel), the lane's G row is split once into planes, and a tile is NHMAX/8 steps
-// of 6 bf16 MFMAs per row block (accumulator layout, slot order and the register contraction are unchanged).
 // (exact general kernel at 32 rows per wave, H <= 128: two waves per SIMD are part of the design -- the register budget is held
-// to 256; the split forms sit just below it on their own and schedule better without the cap)
+// to 256)
 // KS > 1 (pair-symmetric exact kernel only; small M): KS waves of the workgroup share one block of rows and split the periods
 // (values of h) between them; each writes the Gx columns of its own h range, the dX partial sums meet in the LDS scratch
 // (see cin_tail_dz_kernel).
 // pair-symmetric exact kernel at 32 rows per wave: the slot counts whose instantiation fits 256 registers without spilling
 constexpr bool cin_dzs_two_waves(int JT) { return JT <= 12 || JT == 16; }
-template <int MB, int JT, int NHMAX, bool SYM = false, bool SPLIT = false, int KS = 1>
-__global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 && (!SYM || cin_dzs_two_waves(JT))) ? 2 : 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
+template <int MB, int JT, int NHMAX, bool SYM = false, int KS = 1>
+__global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && KS == 1 && (!SYM || cin_dzs_two_waves(JT))) ? 2 : 1) void cin_dz3_kernel(const float* __restrict__ gT, int HS, const float* __restrict__ Wz,
                                                          const float* __restrict__ xT, const float* __restrict__ xpT, int xps,
                                                          const float* __restrict__ dPprev, int ldp, int K, float* __restrict__ GprevT,
                                                          int HSp, float* __restrict__ gx0T, float* __restrict__ dxT, int accumulate,
@@ -916,7 +596,7 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
   constexpr int NQ = NHMAX / 4;
   constexpr int P = JT / gcd_c(16, JT);
   constexpr int HPP = 16 * P / JT;
-  static_assert(KS == 1 || (SYM && !SPLIT), "the period split exists for the exact pair-symmetric kernel");
+  static_assert(KS == 1 || SYM, "the period split exists for the pair-symmetric kernel");
   const int tid = threadIdx.x, lane = tid & 63, wave = KS == 1 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
   const int kpart = wave % KS;
@@ -992,34 +672,9 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
   if constexpr (SYM) __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
   const float4* wz = reinterpret_cast<const float4*>(Wz) + ((long)r * NCOL + half * NHMAX) / 4;
   constexpr long kTileStride = 32L * NCOL / 4;  // float4 per tile
-  constexpr int NT = NHMAX / 8;            // SPLIT: steps (of 16 reduction columns: 8 per wave half) per tile
-  constexpr int QD = 4;                    // SPLIT: A-operand queue depth in steps (divides NT)
-  constexpr int SPS = 16 / NT;             // SPLIT: contraction slots per step
-  float4 q[SPLIT ? 1 : NQ];
-  bf16x8 gpl[SPLIT ? MB : 1][SPLIT ? NT : 1][3];
-  u32x4 aq[SPLIT ? QD : 1][3];
-  const __amdgpu_buffer_rsrc_t rwz = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(Wz), 0, SPLIT ? (int)std::min<long>(((long)periods * P + 1) * NT * 3 * 1024, 0x7fffffffL) : 0, 0x00020000);
-  auto fetch_a = [&](int gs, u32x4 (&dst)[3]) {  // gs = global step = tile * NT + t (uniform)
+  float4 q[NQ];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwz, lane * 16, (gs * 3 + pl) * 1024, 0));
-  };
-  if constexpr (SPLIT) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        float p8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) p8[e] = greg[mb][8 * t + e];
-        split3(p8, gpl[mb][t][0], gpl[mb][t][1], gpl[mb][t][2]);
-      }
-#pragma unroll
-    for (int t = 0; t < QD; ++t) fetch_a(t, aq[t]);
-  } else {
-#pragma unroll
-    for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[(long)per_lo * P * kTileStride + s4];
-  }
+  for (int s4 = 0; s4 < NQ; ++s4) q[s4] = wz[(long)per_lo * P * kTileStride + s4];
   float gx[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) gx[mb] = 0.f;
@@ -1156,32 +811,6 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) d[mb][i] = 0.f;
-      if constexpr (SPLIT) {
-        const int gs0 = (per * P + tp) * NT;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          bf16x8 a[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a[pl] = __builtin_bit_cast(bf16x8, aq[t % QD][pl]);
-          fetch_a(gs0 + t + QD, aq[t % QD]);   // (the stream is allocated one tile past the last one)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) d[mb] = mfma_split(a, gpl[mb][t], d[mb]);
-#pragma unroll
-          for (int qs = 0; qs < SPS; ++qs) {
-            const int sl = t * SPS + qs;   // previous tile's slot contracted behind this step
-            if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, sl);
-            else slot_apply(dprev, xcur, hbase, tp - 1, sl);
-            if (sl < 15) {
-              if (tp == 0) slot_fetch(hprev, P - 1, sl + 1);
-              else slot_fetch(hbase, tp - 1, sl + 1);
-            } else {
-              if (tp == 0) sym_period(hbase);   // (from here on the slots belong to this period)
-              slot_fetch(hbase, tp, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
 #pragma unroll
       for (int s4 = 0; s4 < NQ; ++s4) {
         const float4 w = q[s4];
@@ -1206,7 +835,6 @@ __global__ __launch_bounds__(256, (MB == 1 && NHMAX == 64 && !SPLIT && KS == 1 &
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) dprev[mb] = d[mb];
@@ -1393,159 +1021,6 @@ __global__ __launch_bounds__(256, 1) void cin_dw3_kernel(const float* __restrict
           for (int nb = 0; nb < 4; ++nb)
             if (n + nb < H) dst[nb] = acc[mb][nb][reg];
         }
-      }
-    }
-  }
-}
-
-// ---- split-bf16 dW (opt-in, general layers; see the split-bf16 notes above the forward kernel) ---------------------
-// Gb = G as three bf16 planes in the B-operand layout of v_mfma_f32_32x32x16_bf16 with the reduction over rows:
-// [chunk][row block of 16][plane][nb][lane 64][8 bf16]; element e of lane (r, half) = G[16*blk + 8*half + e][chunk*128 + 4r + nb].
-// One thread per (row block, wave half, r): eight 16-byte row reads (a half wave covers whole 512-byte rows), twelve
-// 16-byte plane stores (64 lanes = 1 KiB contiguous each).
-static __global__ __launch_bounds__(256) void cin_split_g_kernel(const float* __restrict__ gT, int HS, bf16x8* __restrict__ Gb, int M, int H) {
-  const int chunks = HS >> 7;
-  const long nblk = ((long)M + 15) >> 4;
-  const long total = (long)chunks * nblk * 64;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    const long t = idx >> 6;
-    const long blk = t % nblk;
-    const int chunk = (int)(t / nblk);
-    const int r = lane & 31, half = lane >> 5;
-    const int n = chunk * 128 + 4 * r;
-    float g[8][4];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const long m = blk * 16 + 8 * half + e;
-      const float4 v = m < M ? *reinterpret_cast<const float4*>(gT + m * HS + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      g[e][0] = n + 0 < H ? v.x : 0.f;
-      g[e][1] = n + 1 < H ? v.y : 0.f;
-      g[e][2] = n + 2 < H ? v.z : 0.f;
-      g[e][3] = n + 3 < H ? v.w : 0.f;
-    }
-    bf16x8* dst = Gb + ((long)chunk * nblk + blk) * 12 * 64 + lane;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      float p[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) p[e] = g[e][nb];
-      bf16x8 a1, a2, a3;
-      split3(p, a1, a2, a3);
-      dst[(0 * 4 + nb) * 64] = a1;
-      dst[(1 * 4 + nb) * 64] = a2;
-      dst[(2 * 4 + nb) * 64] = a3;
-    }
-  }
-}
-
-// dW[c,n] = sum_m Z[m,c] G[m,n] on split-bf16 operands.  Wave = 32 channel rows x one 128-column chunk over one row split
-// (same work mapping as cin_dw3_kernel).  Per block of 16 rows: lane (c = r, half) gathers x^{l-1}[m,h_c] and x[m,f_c] of
-// its 8 rows m = 16 blk + 8 half + e, multiplies, splits the 8 products into three bf16 planes (one block ahead of
-// their MFMAs), and reads the 12 plane vectors of Gb (fetched one block ahead): 24 bf16 MFMAs per block.
-static __global__ __launch_bounds__(256, 2) void cin_dw3b_kernel(const bf16x8* __restrict__ Gb, const float* __restrict__ xT,
-                                                           const float* __restrict__ xpT, int xps, float* __restrict__ part, int M, int F,
-                                                           int Hp, int H, int rows_per_split, int blocks_x, int chunks, int items,
-                                                           int symD) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-  const int C = symD > 0 ? F * symD : Hp * F;   // symD > 0: unordered pairs c = h*symD + d <-> (h, (h+d) mod F), as in cin_dw3_kernel
-  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware, as in cin_dw3_kernel
-  if (item >= items) return;
-  const int bx = item % blocks_x;
-  const int chunk = (item / blocks_x) % chunks;
-  const int split = item / (blocks_x * chunks);
-  const int c0 = (bx * 4 + wave) * 32;
-  if (c0 >= C) return;
-  const int m_lo = split * rows_per_split;          // a multiple of 16
-  const int m_hi = min(M, m_lo + rows_per_split);
-  const int nkb = (m_hi - m_lo + 15) >> 4;          // row blocks of this split
-  const long mrem = (long)M - m_lo;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(xT + (long)m_lo * F, mrem * F * 4);
-  const __amdgpu_buffer_rsrc_t rp = make_rsrc(xpT + (long)m_lo * xps, mrem * xps * 4);
-  const long nblk = ((long)M + 15) >> 4;
-  const bf16x8* gbase = Gb + ((long)chunk * nblk + (m_lo >> 4)) * 12 * 64;
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(gbase), 0, (int)std::min<long>((long)nkb * 12 * 1024, 0x7fffffffL), 0x00020000);
-  const int c = c0 + r;
-  const bool cv = c < C;
-  const int cc = cv ? c : C - 1;
-  const int hh = symD > 0 ? cc / symD : cc / F;
-  const int ff = symD > 0 ? (hh + (cc - hh * symD)) % F : cc - hh * F;
-  const int ho = (8 * half * xps + hh) * 4, fo = (8 * half * F + ff) * 4;  // byte offsets of the lane's first row inside a block
-  const int vo = lane * 16;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-
-  float xq[2][8], pq[2][8];
-  u32x4 bq[2][12];
-  auto fetch = [&](int kb, int buf) {  // kb uniform; rows past the tensor / blocks past the split's planes read zeros
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xq[buf][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, fo, (kb * 16 + e) * F * 4, 0));
-      pq[buf][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ho, (kb * 16 + e) * xps * 4, 0));
-    }
-    // (order pinned: the next block's A operand needs the 16 gathered dwords only; issued after the plane vectors -- as the
-    // scheduler likes to place them -- its wait would also cover those twelve 16-byte loads, i.e. drain the whole prefetch)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) bq[buf][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, (kb * 12 + i) * 1024, 0));
-  };
-  auto make_a = [&](int kb, int buf, bf16x8 (&a)[3]) {
-    float p[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool live = cv && m_lo + kb * 16 + 8 * half + e < m_hi;
-      p[e] = live ? xq[buf][e] * pq[buf][e] : 0.f;
-    }
-    split3(p, a[0], a[1], a[2]);
-  };
-  bf16x8 acur[3], anext[3];
-  fetch(0, 0);
-  fetch(1, 1);
-  make_a(0, 0, acur);
-  // two blocks per iteration so that the double buffers are indexed at compile time
-#pragma unroll 1
-  for (int kb = 0; kb < nkb; kb += 2) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      bf16x8 b[4][3];
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[nb][pl] = __builtin_bit_cast(bf16x8, bq[u][pl * 4 + nb]);
-      make_a(kb + u + 1, u ^ 1, anext);   // the next block's operand, issued alongside this block's MFMAs
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma_split(acur, b[nb], acc[nb]);
-#pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(kb + u + 2, u);               // refill the buffer this block just released
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) acur[pl] = anext[pl];
-    }
-  }
-  float* pout = part + (long)split * C * H;
-  const bool vec = (H & 3) == 0;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int cr = c0 + mfma32_row(reg, half);
-    if (cr < C) {
-      const int n = chunk * 128 + 4 * r;
-      float* dst = pout + (long)cr * H + n;
-      if (vec && n + 3 < H) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
-      } else {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-          if (n + nb < H) dst[nb] = acc[nb][reg];
       }
     }
   }

@@ -10,32 +10,21 @@ inline int cin_jt_of(int F) { return ((F + 1) / 2 + 3) / 4 * 4; }
 // steps per h of the symmetric first-layer kernels: d = 0..F/2 in pairs, rounded up to an even count (menu 2..18)
 inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
 
-// ks = 4: four waves share a block of 32 rows and split the reduction over h (small M; exact kernels, MB = 1 only; the grid must
+// ks = 4: four waves share a block of 32 rows and split the reduction over h (small M; MB = 1 only; the grid must
 // then be cdiv(M, 32) workgroups in x)
-// x2T [M][XL]: the wrapped rows of x (cin_transpose_in_body), XL = cin_x2_len(F); read by the exact kernels only (split: may be NULL)
+// x2T [M][XL]: the wrapped rows of x (cin_transpose_in_body), XL = cin_x2_len(F)
 inline int cin_x2_len(int F) { return F + 2 * cin_jt_sym(F); }
 void cin_launch_fwd3_sym(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* x2T, int XL, const float* Wf, const float* bias,
-                         float* xoutT, int HS, float* pool_part, int M, int F, int H, bool split = false, int ks = 1);
-
-// split-bf16 form of the symmetric first layer: h per super-period, and floats of its packed weight planes
-inline int cin_sym_hps(int JTs) { return JTs % 4 == 0 ? 4 : 8; }
-inline size_t cin_wb_sym_floats(int F, int JTs, int chunks) {
-  const int hps = cin_sym_hps(JTs);
-  return (size_t)chunks * ((F + hps - 1) / hps) * (hps * JTs / 8) * 12 * 256;
-}
+                         float* xoutT, int HS, float* pool_part, int M, int F, int H, int ks = 1);
 
 // wsn != nullptr: also sum-pool the next (last, mode 0) layer in the epilogue -> pool_next (see cin_fwd3_kernel)
 void cin_launch_fwd3(hipStream_t st, int MB, int JT, dim3 grid, const float* xT, const float* xpT, int xps, const float* Wf,
                      const float* bias, float* xoutT, int HS, float* pool_part, int M, int F, int Hp, int H,
-                     const float* wsn = nullptr, const float* bias_next = nullptr, int H_next = 0, float* pool_next = nullptr,
-                     bool split = false);
-
-// floats of the split-bf16 forward weight buffer (cin_pack_wb_kernel layout) of one layer
-inline size_t cin_wb_floats(int Hp, int JT, int chunks) { return (size_t)chunks * ((Hp + 3) / 4) * (JT / 2) * 12 * 256; }
+                     const float* wsn = nullptr, const float* bias_next = nullptr, int H_next = 0, float* pool_next = nullptr);
 
 void cin_launch_dz3(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
                     const float* xpT, int xps, const float* dPprev, int ldp, int K, float* GprevT, int HSp, float* gx0T, float* dxT,
-                    int accumulate, int M, int F, int Hp, int H, int periods, bool split = false);
+                    int accumulate, int M, int F, int Hp, int H, int periods);
 
 // MFMA data gradients of the last layer in mode 0 (L >= 2): see cin_last_bwd2_kernel
 void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* xpT, int xps, const float* wsum, const float* wsn,
@@ -44,7 +33,7 @@ void cin_launch_last_bwd2(hipStream_t st, int JT, const float* xT, const float* 
 
 // symmetric first layer (x^{l-1} = x); FR = field rows of the LDS scratch (see cin_dz_sym_rows)
 void cin_launch_dz3_sym(hipStream_t st, int MB, int JT, int NHMAX, dim3 grid, const float* gT, int HS, const float* Wz, const float* xT,
-                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods, bool split = false, int ks = 1);
+                        float* gx0T, float* dxT, int accumulate, int M, int F, int H, int periods, int ks = 1);
 
 // tiles per period / h per period of the dZ kernel for a given JT (mirrors the constexprs in cin_dz3_kernel)
 inline int cin_gcd(int a, int b) { return b == 0 ? a : cin_gcd(b, a % b); }

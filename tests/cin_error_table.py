@@ -1,5 +1,5 @@
 """Test utility (lives under tests/ because it checks against oracle/): norm-relative / max-relative error of the CIN
-outputs and gradients against the fp64 oracle, for the exact-fp32 modes (0, 1) and the split-bf16 modes (2, 3).
+outputs and gradients against the fp64 oracle, for modes 0 (the default path) and 1 (general kernels).
     python tests/cin_error_table.py   (needs a GPU)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ for dist in ["uniform","normal"]:
     if dist=="uniform": c["x"]=(c["x"]*10).astype(np.float32)
     want=closed.cin_fwd(c["x"],c["Ws"],c["bs"],c["dense_w"],c["dense_b"],1)
     dx,dWs,dbs,ddw,ddb=closed.cin_bwd(c["x"],c["Ws"],c["bs"],c["dense_w"],c["g"],1)
-    for mode in [0,2,1,3]:
+    for mode in [0,1]:
         dev=lambda a: torch.tensor(a,dtype=torch.float32,device="cuda")
         x=dev(c["x"]).requires_grad_(); Ws=[dev(w).requires_grad_() for w in c["Ws"]]; bs=[dev(b).requires_grad_() for b in c["bs"]]
         dw,db=dev(c["dense_w"]).requires_grad_(),dev(c["dense_b"]).requires_grad_()

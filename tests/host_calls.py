@@ -48,6 +48,7 @@ def run(lib):
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 9, H3, 1, 0, None, 0, None), -4)
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 1, _lib.int_array([300]), 1, 0, None, 0, None), -4)
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 1999, None, 0, None), -4, b"mode")
+    expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 2, None, 0, None), -4, b"retired")   # the split-bf16 experiment's bit
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 70, 16, 3, H3, 1, 0, None, 0, None), -4, b"64 fields")
     expect(lib.fil_cin_bwd(None, None, None, None, None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 0, None, None, 0, None), -1)
     for B in (0, 1, 4096, 150000):

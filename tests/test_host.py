@@ -237,7 +237,7 @@ def test_auc_matches_sklearn():
 
 def test_pmc_traffic_summary_and_bench_lookup(tmp_path, monkeypatch):
     """tools/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024 per kernel and launch slot; bench.pmc_traffic maps the
-    profiler scope of the dominant kernel onto it and ignores the split-bf16 instantiations."""
+    profiler scope of the dominant kernel onto it."""
     import json
     import os
     import subprocess
@@ -248,21 +248,20 @@ def test_pmc_traffic_summary_and_bench_lookup(tmp_path, monkeypatch):
 
     def rows(counter, vals):
         out, d = hdr, 0
-        for it in range(2):  # two step iterations: fwd l1, fwd l2, split fwd l2, dz l2, dz l1
+        for it in range(2):  # two step iterations: fwd l1, fwd l2, dz l2, dz l1
             for name, grid, v in vals:
                 d += 1
                 out += '%d,%d,"Agent 2",1,1,1,%d,6,"%s",256,0,0,8,0,32,"%s",%f,0,1\n' % (d, d, grid, name, counter, v)
         return out
 
-    k_f1 = "void fil::cin_fwd3_kernel<2, 10, true, false>(float const*)"
-    k_f2 = "void fil::cin_fwd3_kernel<2, 20, false, false>(float const*)"
-    k_f2s = "void fil::cin_fwd3_kernel<2, 20, false, true>(float const*)"
-    k_z2 = "void fil::cin_dz3_kernel<1, 20, 64, false, false>(float const*)"
-    k_z1 = "void fil::cin_dz3_kernel<2, 10, 64, true, false>(float const*)"
+    k_f1 = "void fil::cin_fwd3_kernel<2, 10, true, 1>(float const*)"
+    k_f2 = "void fil::cin_fwd3_kernel<2, 20, false, 1>(float const*)"
+    k_z2 = "void fil::cin_dz3_kernel<1, 20, 64, false, 1>(float const*)"
+    k_z1 = "void fil::cin_dz3_kernel<2, 10, 64, true, 1>(float const*)"
     (tmp_path / "f").mkdir()
     (tmp_path / "w").mkdir()
-    (tmp_path / "f" / "1_counter_collection.csv").write_text(rows("FETCH_SIZE", [(k_f1, 64, 10.0), (k_f2, 64, 20.0), (k_f2s, 64, 99.0), (k_z2, 128, 30.0), (k_z1, 64, 40.0)]))
-    (tmp_path / "w" / "1_counter_collection.csv").write_text(rows("WRITE_SIZE", [(k_f1, 64, 1.0), (k_f2, 64, 2.0), (k_f2s, 64, 9.0), (k_z2, 128, 3.0), (k_z1, 64, 4.0)]))
+    (tmp_path / "f" / "1_counter_collection.csv").write_text(rows("FETCH_SIZE", [(k_f1, 64, 10.0), (k_f2, 64, 20.0), (k_z2, 128, 30.0), (k_z1, 64, 40.0)]))
+    (tmp_path / "w" / "1_counter_collection.csv").write_text(rows("WRITE_SIZE", [(k_f1, 64, 1.0), (k_f2, 64, 2.0), (k_z2, 128, 3.0), (k_z1, 64, 4.0)]))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = tmp_path / "profiles"
     prof.mkdir()
@@ -270,10 +269,10 @@ def test_pmc_traffic_summary_and_bench_lookup(tmp_path, monkeypatch):
     subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), str(tmp_path / "f"), str(tmp_path / "w"), str(out), "2"],
                    check=True, capture_output=True)
     per = json.loads(out.read_text())["per_launch"]
-    assert per["cin_fwd3_kernel<2,20,false,false> grid=64"]["hbm_bytes"] == (2 * 20.0 + 2.0) * 1024
+    assert per["cin_fwd3_kernel<2,20,false,1> grid=64"]["hbm_bytes"] == (2 * 20.0 + 2.0) * 1024
     import bench
     monkeypatch.setattr(bench.os.path, "dirname", lambda p: str(tmp_path))  # bench looks under <its dir>/profiles
-    # (a lookup of a committed file, labelled as such in the JSON line) -- not the split instantiation (99 / 9)
+    # (a lookup of a committed file, labelled as such in the JSON line)
     assert bench.pmc_traffic("cin_fwd_l2") == ((2 * 20.0 + 2.0) * 1024, "committed profile r99_pmc_traffic.json")
     assert bench.pmc_traffic("cin_fwd_l1")[0] == (2 * 10.0 + 1.0) * 1024
     assert bench.pmc_traffic("cin_bwd_dz_l2")[0] == (2 * 30.0 + 3.0) * 1024   # backward visits layer 2 first

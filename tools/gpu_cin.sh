@@ -7,8 +7,6 @@ python - <<PY
 import json
 d=json.load(open("gpurun_out/r2c/bench.json"))
 print("mode 0 ms/step %.3f"%d["ms_per_step"], {k:v["avg_ms"] for k,v in d["kernels"].items()})
-c=d.get("candidate_split_bf16")
-if c: print("split ms/step %.3f"%c["ms_per_step"], c["kernels_ms"], c["roofline"])
 PY
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r2c

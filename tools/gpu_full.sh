@@ -16,5 +16,4 @@ print("roofline", {k: j["roofline"][k] for k in ("kernel","achieved","frac","avg
 for k,v in j["kernels"].items(): print("  ", k, v.get("avg_ms"), v.get("executed_tflops"))
 print("cpu", j.get("cpu_baseline"))
 print("side", json.dumps(j.get("side_workloads"), indent=1)[:3000])
-print("split", j["candidate_split_bf16"]["ms_per_step"])
 PY

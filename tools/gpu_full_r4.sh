@@ -12,5 +12,4 @@ d=json.load(open("$out/bench.json"))
 print("ms/step %.4f value %.0f graph %s roofline %s frac %.3f" % (d["ms_per_step"], d["value"], d.get("hipgraph_replay_ms_per_step"), d["roofline"]["kernel"], d["roofline"]["frac"]))
 print("cpu_baseline", d.get("cpu_baseline", {}).get("value"))
 for k,v in d.get("side_workloads", {}).items(): print(" ", k, v.get("ms_per_step"), v.get("hipgraph_replay_ms_per_step"))
-c=d.get("candidate_split_bf16"); print("split", c and c["ms_per_step"])
 PY

@@ -18,17 +18,6 @@ COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "S
             "GRBM_GUI_ACTIVE"]
 
 
-def is_split_instance(key):
-    """True for the template instantiations of the split-bf16 experiment: SPLIT is the 4th argument of cin_fwd3_kernel<MB,JT,SYM,SPLIT,KS>,
-    the 5th of cin_dz3_kernel<MB,JT,WG,SYM,SPLIT,KS> and the 2nd of cin_dw3_kernel<MB,SPLIT,DEPTH>."""
-    name = key.split(" grid=")[0]
-    if "<" not in name:
-        return False
-    args = name[name.index("<") + 1:name.rindex(">")].replace(" ", "").split(",")
-    pos = 3 if name.startswith("cin_fwd3") else 4 if name.startswith("cin_dz3") else 1 if name.startswith("cin_dw3") else None
-    return pos is not None and len(args) > pos and args[pos] == "true"
-
-
 def scopes_of(res):
     """bench.py's profiler scope -> the counters of the GEMM launch behind it (bench._gemm_launch_of: forward l1, .., tail; backward
     tail, .., l1; '#slot' entries for a kernel launched several times per step, as the quadratic tail does)."""
