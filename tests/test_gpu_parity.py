@@ -1153,7 +1153,7 @@ def test_embed_gather_xt_and_cin_transposed_input():
     b2 = Fn.embed_gather(t2, off2, i2, emit_xt=True)
     assert torch.equal(b2, Fn.embed_gather(t2, off2, i2)) and torch.equal(b2._fil_xt, b2.permute(0, 2, 1).reshape(55, 1))
     c = synth.cin_case(B, F, K, conv, dist="uniform")
-    for mode in (0, 1, 2, 64, 64 | 256):      # (64: the quadratic tail, 64 | 256: the fused tail -- both read the transpose in place too)
+    for mode in (0, 1, 64, 64 | 256):      # (64: the quadratic tail, 64 | 256: the fused tail -- both read the transpose in place too)
         res = []
         for use_xt in (False, True):
             x = ref.detach().clone().requires_grad_()
