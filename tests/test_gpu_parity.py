@@ -324,6 +324,11 @@ TAIL_SHAPES = [
     (6, 2, 4, [3, 2, 4]),
     (300, 21, 8, [16, 16, 16]),      # several workgroups, several row splits of the weight-gradient kernel
     (100, 5, 8, [6, 7, 5]),          # M = 800 rows: four 256-row blocks of dc partials on a net whose parameter kernel needs < 1 KB of LDS
+    (73, 6, 6, [8, 8, 8]),           # K = 6: samples straddle the 256-row blocks of the operand-row kernel (the head's block partials) and the
+                                     # 32-row waves of the forward (no head in its epilogue: the separate head kernel runs)
+    (21, 7, 5, [9, 8, 6]),           # K = 5, odd everything
+    (10, 5, 64, [6, 7, 5]),          # K = 64 > 32: a sample is two waves of the forward (B = 9 draws sum_m dP_L = -0.002 against 46 of
+                                     # absolute terms: db of the last layer is then a cancellation test, not a kernel test)
 ]
 TAIL_VARIANT_SHAPES = [TAIL_SHAPES[i] for i in (0, 1, 3, 6, 14)]
 
