@@ -370,6 +370,13 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
   const int m = wrow0 + r;
   const bool vq = m < M;
   const long mq = vq ? m : M - 1;
+  // the lane's half row of the first pass: 16-byte loads, issued before everything else (in flight behind the staging of x)
+  f32x4s gq[16];
+  {
+    const f32x4s* grow4 = reinterpret_cast<const f32x4s*>(g1T + mq * HS + half * 64);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) gq[s4] = grow4[s4];
+  }
   // x entries (zero past F and for rows past M) and zeroed dX accumulators: eight loads per batch, then the LDS writes
   for (int f0 = half; f0 < FR; f0 += 16) {
     float xt[8];
@@ -392,6 +399,19 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
   __builtin_amdgcn_wave_barrier();  // the halves of a row read each other's x entries from here on
   const long wbytes = ((long)periods * P + 1) * 32 * 128 * 4;
   const int wo = (r * 128 + half * 64) * 4;
+  // B operand of the current pass: the lane's half row, columns past the layer's width and rows past M zeroed, scaled (pass 1: by dP_L)
+  float greg[64];
+  auto to_greg = [&](const f32x4s (&gv4)[16], int Hk, float sc) {
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int keep = (vq && half * 64 + 4 * s4 + e < Hk) ? -1 : 0;
+        const float gv = gv4[s4][e];   // (a copy: __builtin_bit_cast applied to the vector ELEMENT expression reads element 0 for every e)
+        greg[4 * s4 + e] = __builtin_bit_cast(float, __builtin_bit_cast(int, gv) & keep) * sc;
+      }
+  };
+  to_greg(gq, H1, 1.f);
 
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {   // (running the passes in the other order in half of the workgroups, so that the two waves of a
@@ -409,21 +429,13 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     f32x4s q[QD];
 #pragma unroll
     for (int s4 = 0; s4 < QD; ++s4) q[s4] = ldw(0, s4);
-    // the lane's half row: 16-byte loads, all in flight together
-    float greg[64];
-    {
+    // the lane's half row of the second pass (the first pass's was fetched at the top, behind the staging of x)
+    if (pass == 1) {
       const f32x4s* grow4 = reinterpret_cast<const f32x4s*>(gT + mq * HS + half * 64);
-      f32x4s gq[16];
+      f32x4s g2[16];
 #pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) gq[s4] = grow4[s4];
-#pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int keep = (vq && half * 64 + 4 * s4 + e < Hk) ? -1 : 0;
-          const float gv = gq[s4][e];   // (a copy: __builtin_bit_cast applied to the vector ELEMENT expression reads element 0 for every e)
-          greg[4 * s4 + e] = __builtin_bit_cast(float, __builtin_bit_cast(int, gv) & keep) * sc;
-        }
+      for (int s4 = 0; s4 < 16; ++s4) g2[s4] = grow4[s4];
+      to_greg(g2, Hk, sc);
     }
     float gx = 0.f;
     f32x16 dprev;
