@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     auto ldw = [&](int t, int s4) {   // tile t is [32 slot rows][128]; lane (r, half) reads row r, columns half*64 + 4*s4 .. +3
       return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo + 16 * s4, t * (32 * 128 * 4), 0));
     };
-    // queue depth in step groups (half a tile ahead: 8 x 256 cycles covers the L2 latency; the full tile, 16, measured 7 us slower --
-    // 32 more registers at the 256-register limit of two waves per SIMD)
+    // queue depth in step groups (half a tile ahead: 8 x 256 cycles covers the L2 latency; the full tile, 16, buys nothing: 0.240 / 0.244 ms
+    // against 0.240 / 0.237 on one box, at 255 registers instead of 218)
     constexpr int QD = 8;
     f32x4s q[QD];
 #pragma unroll
