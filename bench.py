@@ -547,6 +547,8 @@ def main():
     if device.type == "cuda" and not args.no_overlap:
         sh0 = inp["x"].shape
         points = Fn.cin_grad_ready_points(sh0[0], sh0[1], sh0[2], [int(w.shape[1]) for w in inp["Ws"]], args.cin_mode)
+        if use_dist:      # the points depend on the LOCAL batch: an uneven shard can sit on the other side of the library's threshold
+            points = dp.agree_on_points(points, device)
         segments, layer_of_event = dp.merge_segments_by_point(segments, points)
     reducer = dp.LayerwiseAllReduce(flat, segments if not args.no_overlap else [(0, flat.numel())], force=args.force_collective)
     ready = None

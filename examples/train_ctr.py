@@ -67,17 +67,17 @@ def main():
     vocab = [int(v) for v in np.exp(rng0.uniform(np.log(10), np.log(2e5), args.fields))]
     teacher = {f: rng0.normal(0, 0.5, v).astype(np.float32) for f, v in enumerate(vocab)}
     teacher["dense"] = rng0.normal(0, 0.5, args.dense).astype(np.float32)
-    # raw log -> field-index front end -> ids + descriptors (every rank encodes the same vocabulary: the log's categories are drawn
-    # from one seeded stream per rank, so the front end sees this rank's shard; word sizes are taken from the full value range)
-    rng = np.random.default_rng(1000 + rank)
-    raw_sparse, raw_dense, labels = make_raw_log(rng, vocab, args.dense, args.steps * args.batch // 2, teacher)      # repeat(2) makes `steps` batches
+    # raw log -> field-index front end -> ids + descriptors.  LabelEncoder ids are ranks in the sorted set of the values PRESENT, so
+    # the encoder must see the same log on every rank or one raw category would land in different embedding rows on different
+    # replicas (and the averaged gradients would mix unrelated categories): the WHOLE log is drawn from one common seed and encoded
+    # identically everywhere; a rank then keeps its own row shard of the encoded frame.
+    per_rank = args.steps * args.batch // 2                                                  # repeat(2) makes `steps` batches
+    raw_sparse, raw_dense, labels = make_raw_log(np.random.default_rng(1000), vocab, args.dense, per_rank * world, teacher)
     prep = data_prepare(batch_size=args.batch)
     ids_df, info = prep.sparse_fea_deal(raw_sparse, embed_dim=args.embed_dim)
     dense_df, _ = prep.dense_fea_deal(raw_dense)
-    if world > 1:   # replicas must agree on the table shapes: the largest vocabulary any rank saw
-        sizes = torch.tensor([f.word_size for f in info], device=device)
-        dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
-        info = [f._replace(word_size=int(v)) for f, v in zip(info, sizes.tolist())]
+    lo, hi = rank * per_rank, (rank + 1) * per_rank
+    ids_df, dense_df, labels = ids_df.iloc[lo:hi], dense_df.iloc[lo:hi], labels[lo:hi]
     single = args.model == "XDeepFM"
     fi = models.FeatureInput(sparseInfo=info, useLinear=args.model != "DCN" and args.model != "AutoInt", useAddLinear=single,
                              useFlattenLinear=True)

@@ -35,7 +35,7 @@ struct CinShape {
 static int check_shape(const char* fn, int B, int F, int K, int L, const int* H, CinShape& s) {
   if (B < 0 || F < 1 || K < 1 || L < 1 || H == nullptr) return fail(FIL_ERR_ARG, "%s: bad shape B=%d F=%d K=%d L=%d", fn, B, F, K, L);
   if (L > kCinMaxL) return fail(FIL_ERR_UNSUPPORTED, "%s: L=%d > %d", fn, L, kCinMaxL);
-  if (F > 64) return fail(FIL_ERR_UNSUPPORTED, "%s: F=%d > 64 fields", fn, F);
+  if (F > kCinMaxFields) return fail(FIL_ERR_UNSUPPORTED, "%s: F=%d > %d fields", fn, F, kCinMaxFields);
   if ((long)B * K > (1L << 28)) return fail(FIL_ERR_UNSUPPORTED, "%s: B*K = %ld rows > 2^28 (row-split byte offsets of the dW kernel are 32-bit)", fn, (long)B * K);
   s.B = B; s.F = F; s.K = K; s.L = L;
   for (int l = 0; l < L; ++l) {
@@ -521,8 +521,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
           hf = CinHeadFold{pooled, output_dim == 1 ? out : nullptr, dense_w, dense_b, ks, (int)(L * K), p * K, lL * K};
           head_done = true;
         }
-        cin_launch_fwdq(st, JTs, x2T, XL, Wf, WfT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
-                        const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf);
+        if (!cin_launch_fwdq(st, JTs, x2T, XL, Wf, WfT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
+                             const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf))
+          return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: no merged forward kernel for JT=%d (F=%d)", JTs, F);
         pa.chunks[0] = pa.chunks[p] = pa.chunks[lL] = 1;
       }
       FIL_CHECK_LAUNCH();
@@ -849,7 +850,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       // both data-gradient passes in one launch (cin_dz2_kernel): G1 with W1, then dP_L x1 with T, into one dX image
       ProfScope ps("cin_bwd_dz_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
       // (the kernel also finishes dx: + the shortcut's part in dxT, + dP_L c, transposed to [B,F,K] on the way out)
-      cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec);
+      if (!cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec))
+        return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: no two-pass data-gradient kernel for JT=%d (F=%d)", JTs, F);
       qm_joined = true;
     } else {
       const bool two_waves = NHMAX == 64 && cin_dzs_two_waves(JTs) && tune.mb_forced != 2 && knobs().dzs_mb != 2;

@@ -8,7 +8,9 @@ namespace fil {
 inline int cin_jt_of(int F) { return ((F + 1) / 2 + 3) / 4 * 4; }
 
 // steps per h of the symmetric first-layer kernels: d = 0..F/2 in pairs, rounded up to an even count (menu 2..18)
-inline int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
+constexpr int kCinMaxFields = 64;   // check_shape's limit; the JT menus of the launchers are sized for it
+constexpr int cin_jt_sym(int F) { return ((F / 2 + 1 + 1) / 2 + 1) / 2 * 2; }
+static_assert(cin_jt_sym(kCinMaxFields) <= 18, "the symmetric kernels' JT menu (2..18) must cover every legal field count");
 
 // ks = 4: four waves share a block of 32 rows and split the reduction over h (small M; MB = 1 only; the grid must
 // then be cdiv(M, 32) workgroups in x)

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
 }
 
 // dx != nullptr: the kernel finishes the job -- dx [B,F,K] = transpose(dxT (read only) + its image) + dP_L c -- instead of updating dxT
-void cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const float* Wz1,
+bool cin_launch_dz2(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const float* Wz1,
                     const float* Wz2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods,
                     float* dx = nullptr, const float* cvec = nullptr);
 
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void cin_fwdq_kernel(const float* __restric
   }
 }
 
-void cin_launch_fwdq(hipStream_t st, int JT, const float* x2T, int XL, const float* W1f, const float* WTf, const float* bias1, const float* wsn, int JTG,
+bool cin_launch_fwdq(hipStream_t st, int JT, const float* x2T, int XL, const float* W1f, const float* WTf, const float* bias1, const float* wsn, int JTG,
                      const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H, CinHeadFold hf);
 
 }  // namespace fil

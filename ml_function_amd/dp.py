@@ -155,6 +155,8 @@ def merge_segments_by_point(segments, points):
     collective costs tens of microseconds of stream plumbing whatever its size: with the fused tail the two top layers finish
     together and share one."""
     L = len(segments)
+    if points is None:      # the ranks do not agree on the points (agree_on_points): bucket order, one collective per layer
+        return list(segments), list(range(L - 1, -1, -1))
     merged, layer_of_event = [], []
     for i, (lo, hi) in enumerate(segments):
         l = L - 1 - i
@@ -168,6 +170,23 @@ def merge_segments_by_point(segments, points):
     # (points [0, 1, 1, 0]: the head's come out with layer 0's); a collective queued behind a later event would wait for it although its own data is final
     order = sorted(range(len(merged)), key=lambda i: points[layer_of_event[i]])
     return [merged[i] for i in order], [layer_of_event[i] for i in order]
+
+
+def agree_on_points(points, device=None, group=None):
+    """The readiness points decide which segments merge and in which order the collectives are issued, and they depend on each
+    rank's LOCAL batch (the library switches tails at 16,384 rows: fil_cin_grad_ready_points gives [0,1,1,0] above and [2,1,1,0] at
+    or below it), so with uneven strong-scaling shards that straddle the threshold (global 4097 rows over 4 ranks: 1025 / 1024 /
+    1024 / 1024) the ranks would issue collectives of different sizes in different orders -- an RCCL hang or silently wrong sums.
+    Every rank contributes its vector; the result is `points` when ALL ranks hold the same one and None otherwise, which
+    merge_segments_by_point answers with the rank-invariant fallback (per-layer segments in bucket order, each behind its own
+    layer's event: correct on every rank whatever its tail, a little less overlap).  Collective: call it on every rank."""
+    points = [int(p) for p in points]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return points
+    mine = torch.tensor(points, dtype=torch.int64, device=device if device is not None else "cpu")
+    every = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(every, mine, group=group)
+    return points if all(bool(torch.equal(e, mine)) for e in every) else None
 
 
 def allreduce_module_grads(module, group=None):

@@ -43,9 +43,16 @@ def _scratch(nbytes, device, tag):
     nbytes = max(int(nbytes), 256)
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
-    key = (device, stream_ptr(), tag)
+    cur = stream_ptr()
+    key = (device, cur, tag)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
+        # a (re)allocation is also the moment to let go of what OTHER streams of this device left behind: warm-up side streams
+        # (capture_step, bench.py) would otherwise keep hundreds of MB at headline shapes alive for good, invisible to
+        # torch.cuda.empty_cache().  Work still queued on such a stream keeps its bytes: the caching allocator does not hand a
+        # block out again before the stream it was allocated on has passed the free.
+        for k in [k for k in _WS_CACHE if k[0] == device and k[1] != cur]:
+            del _WS_CACHE[k]
         ws = _WS_CACHE[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws
 
@@ -169,7 +176,7 @@ def dcn_cross(x, w, b):
 CIN_X_TRANSPOSED = 16   # fil.h FIL_CIN_X_TRANSPOSED: x handed over as [B*K, F] (embed_gather(emit_xt=True))
 CIN_TAIL_ALWAYS = 64    # fil.h FIL_CIN_TAIL_ALWAYS: the tails wherever they are defined, whatever the batch size (tests, smoke)
 CIN_NOQTAIL = 256       # fil.h FIL_CIN_NOQTAIL: three-layer nets on the F+1-column fused tail instead of the quadratic tail
-CIN_NOQMERGE = 512      # fil.h FIL_CIN_NOQMERGE: the quadratic tail's weight gradients as two launches instead of the merged one
+CIN_NOQMERGE = 512      # fil.h FIL_CIN_NOQMERGE: round 3's two launches per direction for the quadratic tail (no 256-column forward with the pools and the head in its epilogue, no 256-column dW, no two-pass dZ)
 
 
 def cin_grad_ready_points(B, F, K, H, mode=0):

@@ -38,7 +38,7 @@ _INDEPENDENT = {}   # (device index, priority, current stream, tag) -> the strea
 
 def independent_stream(device=None, tries=8, priority=0, tag=None):
     """A stream on `device` that does not share a hardware queue with the current stream (the first of `tries` candidates that
-    passes shares_queue_with_current; the last candidate if none does -- correctness never depends on it).  The probe drains the
+    passes shares_queue_with_current; the last candidate, NOT remembered, if none does -- correctness never depends on it).  The probe drains the
     device (a >= 2 ms sleep kernel per candidate), so its result is kept per (device, current stream, tag): a caller that asks again
     -- every epoch's data iterator, every reducer -- gets its stream back; different tags get different streams.  Under stream
     capture no probe can run: a plain new stream is returned."""
@@ -55,6 +55,8 @@ def independent_stream(device=None, tries=8, priority=0, tag=None):
         for _ in range(max(1, tries)):
             cand = torch.cuda.Stream(device=dev, priority=priority)
             if cand not in _INDEPENDENT.values() and not shares_queue_with_current(cand, dev):
-                break
-    _INDEPENDENT[key] = cand
+                _INDEPENDENT[key] = cand      # only a candidate that PASSED is remembered
+                return cand
+    # no candidate passed (a loaded device, a flaky probe): the last one is handed out uncached, so the next caller probes again
+    # instead of being pinned to a stream that may serialise with the compute stream for the rest of the process
     return cand

@@ -130,6 +130,41 @@ def test_segments_merge_where_gradients_finish_together():
     assert dp.merge_segments_by_point(segs4, [3, 2, 1, 1, 0]) == ([(0, 30), (30, 60), (60, 100)], [2, 1, 0])
 
 
+def _points_worker(rank, world, port, out_dir):
+    """Ranks whose LOCAL batch sits on different sides of the library's tail threshold report different readiness points
+    (global 4097 rows, K=16, 4 ranks: one shard of 1025 rows -> [0,1,1,0], three of 1024 -> [2,1,1,0]).  Every rank must still
+    issue the same collectives in the same order: agree_on_points -> None -> per-layer segments in bucket order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes, segments, index = dp.cin_bucket_layout([(15, 6), (30, 7), (35, 3)], [(6,), (7,), (3,)], [(12, 1), (1,)])
+        mine = [0, 1, 1, 0] if rank == 0 else [2, 1, 1, 0]
+        agreed = dp.agree_on_points(mine)
+        assert agreed is None
+        segs, layer_of_event = dp.merge_segments_by_point(segments, agreed)
+        assert segs == segments and layer_of_event == [2, 1, 0]          # the same on both ranks whatever `mine` was
+        # and the reduction through them is the plain sum
+        flat = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1)
+        red = dp.LayerwiseAllReduce(flat, segs)
+        red.launch()
+        red.wait()
+        assert torch.equal(flat, torch.arange(sum(sizes), dtype=torch.float32) * 3)
+        # identical vectors pass through unchanged
+        assert dp.agree_on_points([0, 1, 1, 0]) == [0, 1, 1, 0]
+        if rank == 0:
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_readiness_points_issue_the_same_collectives(tmp_path):
+    mp.spawn(_points_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+    # one rank: nothing to agree on
+    assert dp.agree_on_points([2, 1, 1, 0]) == [2, 1, 1, 0]
+
+
 def test_layerwise_allreduce_equals_full_batch(tmp_path):
     """The bucket reduced segment by segment (the order bench.py overlaps them in) == gradient of the full batch."""
     world = 2
