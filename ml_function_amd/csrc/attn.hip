@@ -146,8 +146,14 @@ __device__ __forceinline__ float lane_rows_sum(float v) {
   return a + b;
 }
 
-// sum over the four lanes {c, c+16, c+32, c+48} (the four 4-element pieces of one fragment row), result in all of them
-__device__ __forceinline__ float groups_sum(float v) { return lane_halves_sum(lane_rows_sum(v)); }
+// sum over the four lanes {c, c+16, c+32, c+48} (the four 4-element pieces of one fragment row), result in all of them.
+// One v_mfma_f32_16x16x4_f32 with A = 1: D[i][j] = sum_k B[k][j], and a lane's B element is B[k = lane >> 4][j = lane & 15] -- an
+// exact fp32 chain ((v0 + v1) + v2) + v3 in lane-group order.  The cross-lane form (v_permlane16_swap + v_permlane32_swap, each
+// fenced by s_nops) was ten vector-issue slots per sum; the LayerNorm backward makes four per query block, and the attention
+// kernels are bound by vector issue while their matrix pipe idles.
+__device__ __forceinline__ float groups_sum(float v) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)[0];
+}
 
 // sum over the 16 lanes of a row (lanes 16g .. 16g+15), result in all of them: DPP only, no LDS crossbar
 __device__ __forceinline__ float row16_allsum(float v) {
@@ -252,36 +258,86 @@ struct XSrc<F16, false> {
   }
 };
 
-// all threads: xs[ch][f][k] = (f16) x[b,f,16ch+k], zero padded.  Four 16-byte pieces per thread are fetched before the
-// first is converted (branch-free raw buffer loads: one HBM latency per pass, not one per piece).
+// idx / per_ch for idx < NC * per_ch without an integer division (a division by a run-time value is ~25 vector instructions)
+template <int NC>
+__device__ __forceinline__ int chunk_of(int idx, int per_ch) {
+  int ch = 0;
+#pragma unroll
+  for (int k = 1; k < NC; ++k) ch += idx >= k * per_ch ? 1 : 0;
+  return ch;
+}
+
+// all threads: xs[ch][f][k] = (f16) x[b,f,16ch+k], zero padded.  U 16-byte pieces per thread are fetched before the first is
+// converted (branch-free raw buffer loads: one HBM latency per pass, not one per piece; U = 2 NC covers K = 64 at 512 threads and
+// K = 16 at 256 in ONE pass -- while the image is staged nothing else runs in the workgroup).  VEC: four consecutive kin are one
+// aligned 16-byte piece (x_chunk and K multiples of 4); else element by element.
+template <int NC>
+struct XStage {
+  static constexpr int U = NC >= 2 ? 2 * NC : 4;
+};
+// the pieces base + u nthreads, u < U, of sample b as fp32 (on = false: every offset out of range, nothing moves)
+template <int NC, bool VEC>
+__device__ __forceinline__ void stage_x_load(__amdgpu_buffer_rsrc_t rx, const AttnDims& d, int b, int base, int nthreads, bool on,
+                                             f32x4 (&v)[XStage<NC>::U]) {
+  const int per_ch = d.FP * 4, total = NC * per_ch;
+#pragma unroll
+  for (int u = 0; u < XStage<NC>::U; ++u) {
+    const int idx = base + u * nthreads;
+    const int ch = chunk_of<NC>(idx, per_ch), rem = idx - ch * per_ch;
+    const int f = rem >> 2, k0 = 16 * ch + 4 * (rem & 3);
+    const bool rowok = on && idx < total && f < d.F;
+    if constexpr (VEC) {
+      v[u] = buf_load4(rx, (rowok && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[u][s] = buf_load1(rx, (rowok && k0 + s < d.K) ? 4 * x_off(d, b, f, k0 + s) : kOOB);
+    }
+  }
+}
+template <int NC>
+__device__ __forceinline__ void stage_x_write(_Float16* xs, const AttnDims& d, int base, int nthreads, const f32x4 (&v)[XStage<NC>::U]) {
+  const int per_ch = d.FP * 4, total = NC * per_ch;
+#pragma unroll
+  for (int u = 0; u < XStage<NC>::U; ++u) {
+    const int idx = base + u * nthreads;
+    if (idx < total) {
+      const int ch = chunk_of<NC>(idx, per_ch), rem = idx - ch * per_ch;
+      const int f = rem >> 2, p = rem & 3;
+      *reinterpret_cast<f16x4*>(xs + ch * d.FP * 16 + f * 16 + 4 * (p ^ swz16(f))) = __builtin_convertvector(v[u], f16x4);
+    }
+  }
+}
+template <int NC, bool VEC>
+__device__ __forceinline__ void stage_x_f16_pass(__amdgpu_buffer_rsrc_t rx, _Float16* xs, const AttnDims& d, int b, int nthreads) {
+  const int total = NC * d.FP * 4;
+  for (int base = threadIdx.x; base < total; base += XStage<NC>::U * nthreads) {
+    f32x4 v[XStage<NC>::U];
+    stage_x_load<NC, VEC>(rx, d, b, base, nthreads, true, v);
+    stage_x_write<NC>(xs, d, base, nthreads, v);
+  }
+}
+template <int NC>
 __device__ __forceinline__ void stage_x_f16(const float* __restrict__ x, _Float16* xs, const AttnDims& d, int b, int nthreads) {
-  const bool vec = (d.xcw & 3) == 0 && (d.K & 3) == 0;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)d.B * d.F * d.K * 4);
-  const int per_ch = d.FP * 4, total = d.NC * per_ch;
-  for (int base = threadIdx.x; base < total; base += 4 * nthreads) {
-    f32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * nthreads;
-      const int ch = idx / per_ch, rem = idx - ch * per_ch;
-      const int f = rem >> 2, k0 = 16 * ch + 4 * (rem & 3);
-      const bool rowok = idx < total && f < d.F;
-      if (vec) {
-        v[u] = buf_load4(rx, (rowok && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[u][s] = buf_load1(rx, (rowok && k0 + s < d.K) ? 4 * x_off(d, b, f, k0 + s) : kOOB);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * nthreads;
-      if (idx < total) {
-        const int ch = idx / per_ch, rem = idx - ch * per_ch;
-        const int f = rem >> 2, p = rem & 3;
-        *reinterpret_cast<f16x4*>(xs + ch * d.FP * 16 + f * 16 + 4 * (p ^ swz16(f))) = __builtin_convertvector(v[u], f16x4);
-      }
-    }
+  if ((d.xcw & 3) == 0 && (d.K & 3) == 0) {     // (wave-uniform: the two forms as two loops, not a test per piece)
+    stage_x_f16_pass<NC, true>(rx, xs, d, b, nthreads);
+  } else {
+    stage_x_f16_pass<NC, false>(rx, xs, d, b, nthreads);
+  }
+}
+
+// One dword per 64 bytes of sample b's x rows, into a scrap LDS word by LDS-DMA (no registers, nothing to wait for): the lines
+// are in L2 / the Infinity Cache when stage_x_f16 asks for them.  The persistent backward calls it for its NEXT sample while the
+// current one is in its last phases; b >= B touches nothing (offsets beyond the descriptor).
+template <int NC>
+__device__ __forceinline__ void prefetch_x_lines(const float* __restrict__ x, float* scrap, const AttnDims& d, int b, int nthreads) {
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, b < d.B ? (long)d.B * d.F * d.K * 4 : 0);
+  const int per_ch = d.FP * 4, total = NC * per_ch;        // 16-byte pieces
+  for (int idx = 4 * (int)threadIdx.x; idx < total; idx += 4 * nthreads) {     // (one touch per 64 bytes: rows of 16 floats)
+    const int ch = chunk_of<NC>(idx, per_ch), rem = idx - ch * per_ch;
+    const int f = rem >> 2, k0 = 16 * ch + 4 * (rem & 3);
+    const int off = (f < d.F && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)scrap, 4, off, 0, 0, 0);
   }
 }
 
@@ -290,14 +346,17 @@ __device__ __forceinline__ void stage_x_f16(const float* __restrict__ x, _Float1
 template <int NC, bool F16>
 __device__ __forceinline__ void load_w_kin(const float* __restrict__ W, int h, const AttnDims& d, int lane,
                                            typename Prec<F16>::Op (&w)[NC]) {
+  // (raw buffer loads: an element outside [K] x [A] -- or a missing matrix -- is an out-of-range offset that reads 0; as a branch per
+  // element these 12 NC loads were ~1000 instructions per wave, paid per SAMPLE by the forward's one-sample workgroups)
   const int a = lane & 15, g = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(W, W != nullptr ? (long)d.K * d.H * d.A * 4 : 0);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = 16 * c + 4 * g + s;
-      if (W != nullptr && k < d.K && a < d.A) v[s] = W[((long)k * d.H + h) * d.A + a];
+      v[s] = buf_load1(rw, (k < d.K && a < d.A) ? 4 * ((k * d.H + h) * d.A + a) : kOOB);
     }
     w[c] = to_op<F16>(v);
   }
@@ -337,6 +396,23 @@ struct SlabLane {
 #pragma unroll
     for (int s = 0; s < 4; ++s) u1[s] = __builtin_amdgcn_raw_buffer_load_b32(r, vec ? kOOB : off(f, s), 0, 0);
     return __builtin_bit_cast(f32x4, u4 | u1);
+  }
+  // A16 = true: the row width is known to be 16 (one aligned 16-byte piece per lane, no second form)
+  template <bool A16>
+  __device__ __forceinline__ f32x4 load_t(__amdgpu_buffer_rsrc_t r, int f) const {
+    if constexpr (A16) {
+      return buf_load4(r, 4 * (f * 16 + a0));
+    } else {
+      return load(r, f);
+    }
+  }
+  template <bool A16>
+  __device__ __forceinline__ void store_t(__amdgpu_buffer_rsrc_t r, int f, const f32x4& v) const {
+    if constexpr (A16) {
+      buf_store4(r, 4 * (f * 16 + a0), v);
+    } else {
+      store(r, f, v);
+    }
   }
   __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int f, const f32x4& v) const {
     if ((A & 3) == 0) {
@@ -397,7 +473,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // ================================================================================================= forward
 // grid = B, block = 64 H.  y[h,b,f,a] = fuse_relu ? relu(res + ln) : ln ; res_out (optional, !fuse_relu) = x Wr
-template <int NC, bool F16>
+template <int NC, bool F16, bool A16>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                         const float* __restrict__ Wk, const float* __restrict__ Wr,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -415,7 +491,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
   XSrc<F16, F16> xsrc;
   if constexpr (F16) {
     _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);
-    stage_x_f16(x, xs, d, b, blockDim.x);
+    stage_x_f16<NC>(x, xs, d, b, blockDim.x);
     xsrc.xs = xs;
     xsrc.FP = d.FP;
     kimg = xs + d.NC * d.FP * 16 + h * d.FP * RS;
@@ -434,10 +510,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
   sl.init(d.A, 4 * g);
   const float inv_a = 1.0f / (float)d.A;
   f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = {0.f, 0.f, 0.f, 0.f};
-  bool aval[4];
+  bool aval[4];     // (A16: all true at compile time, the masks fold away)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    aval[s] = 4 * g + s < d.A;
+    aval[s] = A16 || 4 * g + s < d.A;
     if (use_ln && aval[s]) {
       gam[s] = gamma[4 * g + s];
       bet[s] = beta[4 * g + s];
@@ -495,15 +571,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int s = 0; s < 4; ++s) ln[s] = dv[s] * rstd * gam[s] + bet[s];
     }
-    sl.store(r_av, f, avT);          // a zero-size descriptor drops the stores when av is not kept
+    sl.template store_t<A16>(r_av, f, avT);          // a zero-size descriptor drops the stores when av is not kept
     if (fuse_relu) {
       f32x4 o;
 #pragma unroll
       for (int s = 0; s < 4; ++s) o[s] = fmaxf(resT[s] + ln[s], 0.f);
-      sl.store(r_y, f, o);
+      sl.template store_t<A16>(r_y, f, o);
     } else {
-      sl.store(r_y, f, ln);
-      sl.store(r_res, f, resT);
+      sl.template store_t<A16>(r_y, f, ln);
+      sl.template store_t<A16>(r_res, f, resT);
     }
   }
 }
@@ -519,6 +595,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 #ifndef FIL_ATTN_TILE_GROUP
 #define FIL_ATTN_TILE_GROUP 1
 #endif
+#ifndef FIL_ATTN_EXIT_TEST
+#define FIL_ATTN_EXIT_TEST(J) (J >= nb_s)     // (experiments: -D'FIL_ATTN_EXIT_TEST(J)=false' = no exit test, nblk == NB only)
+#endif
 #ifndef FIL_ATTN_XL_MAXNC
 #define FIL_ATTN_XL_MAXNC 4
 #endif
@@ -529,7 +608,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 // nothing is computed twice (each wave runs the whole prologue + all key tiles of its own blocks and keeps its own partial dk /
 // dW / dgamma sums, merged after the loop), and a workgroup has twice the waves -- for the shapes whose LDS footprint lets only
 // one workgroup onto a CU (K = 64 layers of a stack, the f32 mode at large F) that is the second wave per SIMD.
-template <int NC, bool F16, int NB, int WPH, bool DXL>
+template <int NC, bool F16, int NB, int WPH, bool DXL, bool A16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BWD_WPE(NC, F16)))) void attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
@@ -543,9 +622,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
 #ifdef FIL_ATTN_STAMPS
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_last = __builtin_amdgcn_s_memtime();
-#define FIL_STAMP(P) { const long long t_now = __builtin_amdgcn_s_memtime(); ph[P] += t_now - t_last; t_last = t_now; }
+#define FIL_STAMP_AT(P) { const long long t_now = __builtin_amdgcn_s_memtime(); ph[P] += t_now - t_last; t_last = t_now; }
+#ifdef FIL_ATTN_STAMPS_POST      // breakdown of the per-sample phases instead: the whole block loop in slot 1, FIL_STAMP_POST(k) in 2..6
+#define FIL_STAMP(P) FIL_STAMP_AT(((P) >= 1 && (P) <= 5) ? 1 : (P))
+#define FIL_STAMP_POST(P) FIL_STAMP_AT(P)
+#else
+#define FIL_STAMP(P) FIL_STAMP_AT(P)
+#define FIL_STAMP_POST(P)
+#endif
 #else
 #define FIL_STAMP(P)
+#define FIL_STAMP_POST(P)
 #endif               // elements per 16-row tile
   constexpr bool XL = F16 && NC <= FIL_ATTN_XL_MAXNC;   // x image in LDS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -610,10 +697,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   if constexpr (DXL) dxs = reinterpret_cast<float*>(sp + (F16 ? (size_t)3 * NH * NC * 256 * sizeof(_Float16) : 0));
   row_write<F16>(kimg, d.FP + c, g, to_op<F16>(f32x4{0.f, 0.f, 0.f, 0.f}));   // the zero tile (never written again)
   __shared__ __attribute__((aligned(16))) float gamma_s[16];      // re-read per block: 4 registers less than keeping it
+  __shared__ float x_scrap[64];                                    // where prefetch_x_lines drops its dwords (never read)
   if (threadIdx.x < 16) gamma_s[threadIdx.x] = (use_ln && (int)threadIdx.x < d.A) ? gamma[threadIdx.x] : 0.f;
-  bool aval[4];
+  bool aval[4];     // (A16: all true at compile time)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) aval[s] = 4 * g + s < d.A;
+  for (int s = 0; s < 4; ++s) aval[s] = A16 || 4 * g + s < d.A;
   f32x4 dWq[NC], dWk[NC], dWr[NC];
 #pragma unroll
   for (int cc = 0; cc < NC; ++cc) dWq[cc] = dWk[cc] = dWr[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -630,12 +718,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     }
   }
 
+  // f16 mode, when one pass of the staging loop covers the whole image (every BASELINE shape): the NEXT sample's x is requested
+  // right after this sample's last use of the image (dWk) and converted into it at the top of the next sample -- the round trip
+  // (12 % of the K = 64 kernel as a serial phase) runs under the dk part of dx, and ahead of this sample's dx stores in the queue.
+  // (The loads are issued for every sample, out of range when they do not apply: a conditionally written xpre would be live
+  // through the block loop.)
+  const bool x_early = XL && (d.xcw & 3) == 0 && (d.K & 3) == 0 && NC * d.FP * 4 <= XStage<NC>::U * (int)blockDim.x;
+  f32x4 xpre[XStage<NC>::U];
   for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
     FIL_STAMP(7)
     lds_barrier();   // weight table built / the previous sample's k (dk) images and x image are no longer read
     if constexpr (XL) {
-      stage_x_f16(x, xs16, d, b, blockDim.x);
+      if (x_early && b != (int)blockIdx.x) {
+        stage_x_write<NC>(xs16, d, threadIdx.x, blockDim.x, xpre);   // requested after the previous sample's dWk (below)
+      } else {
+        stage_x_f16<NC>(x, xs16, d, b, blockDim.x);
+      }
       lds_barrier();
+      FIL_STAMP_POST(6)    // x staged
     } else {
       xsrc.set_sample(d, b);
     }
@@ -650,7 +750,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
 
     // block inputs are fetched one query block ahead (they come from HBM)
     // (dres_in of the unfused mode is read at use: one more prefetched tensor would cost the fused mode a wave per SIMD)
-    f32x4 n_dy = sl.load(r_dy, 16 * sub + c), n_y = sl.load(r_ys, 16 * sub + c), n_av = sl.load(r_avs, 16 * sub + c);
+    f32x4 n_dy = sl.template load_t<A16>(r_dy, 16 * sub + c), n_y = sl.template load_t<A16>(r_ys, 16 * sub + c), n_av = sl.template load_t<A16>(r_avs, 16 * sub + c);
 
     {
       Op wk[NC];
@@ -669,22 +769,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
 #pragma unroll
     for (int j = 0; j < NB; ++j) dk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (the first block's inputs, requested before the k projection: waited for once, here, so that the block loop is entered
-    // with nothing pending -- see the end of the block body)
+    // with nothing pending -- see the end of phase E)
     settle4(n_dy);
     settle4(n_y);
     settle4(n_av);
     FIL_STAMP(0)
-    for (int step = 0; step * WPH < d.nblk; ++step) {
-      const int i = step * WPH + sub, par = step & 1;
-      if (WPH == 1 || i < d.nblk) {     // (wave-uniform; with two waves per head and an odd block count the last step is one wave's)
+    // ---- The block loop.  A query block i goes through four phases:
+    //   P(i)  LayerNorm / ReLU backward of the block's rows, q_i in both orientations; requests the inputs of the wave's next block
+    //   T(i)  the score tiles (all key tiles against the block; dk accumulates in registers, dq_i in dqT)
+    //   E(i)  dq_i / dres_i into the wave's hand-over tiles, dW += x_i^T (dq_i | dres_i)
+    //   X     dx_i = sum over the heads of dq Wq^T + dres Wr^T, from the hand-over tiles of all heads, behind a workgroup barrier
+    // With two waves per head (WPH = 2) step `st` runs blocks 2 st and 2 st + 1 side by side.
+    // (Tried in round 5 and dropped, DESIGN.md section 4.4: the next block's P cut into pieces between the current block's tiles; the
+    // two waves of a head in alternating phases ("slots": T beside E + X + P); the odd last block's key tiles split between the
+    // head's two waves -- all slower or equal: the SIMDs are issue-bound in every phase, so moving instructions between phases or
+    // waves buys nothing and every extra select, test or barrier costs.)
+    Op qn, qc, dav_r, dav_c, dr_r;     // P -> T, E
+    f32x4 dqT = {0.f, 0.f, 0.f, 0.f};  // T -> E
+    auto phase_p = [&](const int i) __attribute__((always_inline)) {
       f32x4 dz = n_dy, dr = {0.f, 0.f, 0.f, 0.f};
-      if (use_dr) dr = sl.load(r_dr, 16 * i + c);
+      if (use_dr) dr = sl.template load_t<A16>(r_dr, 16 * i + c);
       const f32x4 yv = n_y, avv = n_av;
       {
         const int fn = 16 * (i + WPH) + c;  // past the last block every lane is out of range and reads zeros
-        n_dy = sl.load(r_dy, fn);
-        n_y = sl.load(r_ys, fn);
-        n_av = sl.load(r_avs, fn);
+        n_dy = sl.template load_t<A16>(r_dy, fn);
+        n_y = sl.template load_t<A16>(r_ys, fn);
+        n_av = sl.template load_t<A16>(r_avs, fn);
       }
       // ---- LayerNorm / ReLU backward of query block i: lane (g,c) owns row f = 16i+c, a = 4g..4g+3
       if (fuse_relu) {
@@ -723,11 +833,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
 #pragma unroll
         for (int s = 0; s < 4; ++s) dav[s] = aval[s] ? rstd * (dxh[s] - m1 - xh[s] * m2) : 0.f;
       }
-      const Op dav_r = to_op<F16>(dav);     // row fragments: [query c][a 4g+s]
-      const Op dr_r = to_op<F16>(dr);
-      row_write<F16>(tiles, c, g, dav_r);                       // tile 0
-      if (has_res) row_write<F16>(tiles + (3 + 2 * par) * TS, c, g, dr_r);
-      const Op dav_c = tr_read<F16>(tiles, 0, lane);            // column fragment [query 4g+s][a c]
+      dav_r = to_op<F16>(dav);     // row fragments: [query c][a 4g+s]
+      dr_r = to_op<F16>(dr);
+      row_write<F16>(tiles, c, g, dav_r);                       // tile 0 (free: the wave's last tile phase is over)
+      dav_c = tr_read<F16>(tiles, 0, lane);                     // column fragment [query 4g+s][a c]
       // ---- q_i in both orientations
       f32x4 qT = {0.f, 0.f, 0.f, 0.f}, qD = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -737,10 +846,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         qT = mma<F16>(wq, xr, qT);   // [a 4g+r][query c] -> row fragment of q_i
         qD = mma<F16>(xr, wq, qD);   // [query 4g+r][a c] -> column fragment of q_i
       }
-      const Op qn = to_op<F16>(qT * qs);     // scores come out as -log2(e) * scale * q.k
-      const Op qc = to_op<F16>(qD * scale);  // dk += dP^T (scale q)
-      FIL_STAMP(1)
-      f32x4 dqT = {0.f, 0.f, 0.f, 0.f};
+      qn = to_op<F16>(qT * qs);     // scores come out as -log2(e) * scale * q.k
+      qc = to_op<F16>(qD * scale);  // dk += dP^T (scale q)
+    };
+    auto phase_t = [&]() __attribute__((always_inline)) {
+      dqT = f32x4{0.f, 0.f, 0.f, 0.f};
       // ---- the score tiles, software-pipelined over three tiles: [LDS reads of tile j+1] [sigmoid + dk of tile j]
       // [S, dS of tile j+1] [dq of tile j-1].  The k image carries one zero tile behind the last key block, so the reads
       // and products of tile j+1 need no guard; leaving the unrolled loop with `break` keeps the exit test scalar.
@@ -784,7 +894,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
       asm volatile("" : "+s"(nb_s));
 #define FIL_TILE(J)                                             \
   if constexpr (J < NB) {                                       \
-    if (J >= nb_s) goto tiles_done;                             \
+    if (FIL_ATTN_EXIT_TEST(J)) goto tiles_done;                 \
     tile_step(std::integral_constant<int, J>{});                \
   }
       FIL_TILE(0) FIL_TILE(1) FIL_TILE(2) FIL_TILE(3) FIL_TILE(4) FIL_TILE(5) FIL_TILE(6) FIL_TILE(7)
@@ -797,13 +907,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         const Op dpT = tr_read<F16>(tiles + ((d.nblk - 1) & 1) * TS, 0, lane);
         dqT = mma<F16>(kT_prev, dpT, dqT);
       }
-      FIL_STAMP(2)
+    };
+    auto phase_e = [&](const int i, const int par) __attribute__((always_inline)) {
       const Op dq_r = to_op<F16>(dqT * scale);                // row fragment of dq_i
       Elem* t_dq = tiles + (2 + 2 * par) * TS;
       row_write<F16>(t_dq, c, g, dq_r);
+      if (has_res) row_write<F16>(t_dq + TS, c, g, dr_r);
       const Op dq_c = tr_read<F16>(t_dq, 0, lane);
       Op dr_c = dr_r;
-      if (has_res) dr_c = tr_read<F16>(tiles + (3 + 2 * par) * TS, 0, lane);
+      if (has_res) dr_c = tr_read<F16>(t_dq + TS, 0, lane);
       // ---- dW += x_i^T d*
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) {
@@ -811,34 +923,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         dWq[cc] = mma<F16>(xc, dq_c, dWq[cc]);                // [kin 4g+r][a c]
         if (has_res) dWr[cc] = mma<F16>(xc, dr_c, dWr[cc]);
       }
-      // The next block's inputs (requested at the top of this block) are waited for HERE, where they have long arrived.
-      // Left to the compiler the wait lands at their first use in the next block's prologue, behind the loads that block
-      // issues for ITS successor (SlabLane::load has two forms, and across that branch the wait count degrades to
-      // vmcnt(0)): every block then waited for a full HBM round trip of loads it had just issued -- the "prologue" phase
-      // of the stamp profile, a quarter of the kernel.
-      settle4(n_dy);
-      settle4(n_y);
-      settle4(n_av);
-      FIL_STAMP(3)
-      }
-      lds_barrier();   // every wave's dq / dres tile of this step is in LDS
-      FIL_STAMP(4)
-      // ---- dx_i[:, 16cc..] = sum_heads dq Wq^T + dres Wr^T for the step's blocks: job q = (sub', cc) belongs to wave
-      // (q + step) mod nw: the owner rotates with the step, so the extra work (and the arrival skew it causes at the next
-      // barrier) is spread over the waves instead of landing on wave 0 every step
-      for (int q = (w + nw - step % nw) % nw; q < WPH * NC; q += nw) {
-        const int qs_ = q / NC, cc = q - qs_ * NC, bi = step * WPH + qs_;
+    };
+    // X of step st: job q = (qs', cc) -- block WPH st + qs', chunk cc of its dx -- belongs to wave (q + st) mod nw (rotw = st mod nw,
+    // kept by the loop): the owner rotates with the step, so the work -- and the arrival skew it causes at the next barrier -- is
+    // spread over the waves.
+    auto phase_x = [&](const int st, const int rotw) __attribute__((always_inline)) {
+      const int par = st & 1;
+      for (int q = w >= rotw ? w - rotw : w - rotw + nw; q < WPH * NC; q += nw) {
+        const int qs_ = q / NC, cc = q - qs_ * NC, bi = st * WPH + qs_;
         if (bi < d.nblk) {
+          // DXL: the TRANSPOSED tile, D[kin 4g+r][query c] = W d^T -- a lane then holds four consecutive kin of one row, one 16-byte
+          // LDS access (and, after the block loop, one 16-byte global store) instead of four 4-byte ones
           f32x4 px = {0.f, 0.f, 0.f, 0.f};
-          for (int hh = 0; hh < NH; ++hh) {
+          auto head_part = [&](const int hh) __attribute__((always_inline)) {
             const Elem* th = tiles0 + ((hh * WPH + qs_) * 6 + 2 + 2 * par) * TS;
-            px = mma<F16>(row_read<F16>(th, c, g), wt.arole(0, hh, cc, lane), px);
-            if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), wt.arole(2, hh, cc, lane), px);
+            if constexpr (DXL) {
+              px = mma<F16>(wt.arole(0, hh, cc, lane), row_read<F16>(th, c, g), px);
+              if (has_res) px = mma<F16>(wt.arole(2, hh, cc, lane), row_read<F16>(th + TS, c, g), px);
+            } else {
+              px = mma<F16>(row_read<F16>(th, c, g), wt.arole(0, hh, cc, lane), px);
+              if (has_res) px = mma<F16>(row_read<F16>(th + TS, c, g), wt.arole(2, hh, cc, lane), px);
+            }
+          };
+          if (NH == 4) {      // (the common head count, straight-line: all eight operand reads in flight before the first product)
+            head_part(0); head_part(1); head_part(2); head_part(3);
+          } else {
+            for (int hh = 0; hh < NH; ++hh) head_part(hh);
           }
           const int kin = 16 * cc + c;
           if constexpr (DXL) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dxs[(cc * d.FP + 16 * bi + 4 * g + r) * 16 + c] = px[r];
+            *reinterpret_cast<f32x4*>(dxs + (cc * d.FP + 16 * bi + c) * 16 + 4 * g) = px;
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -848,9 +962,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
           }
         }
       }
-      FIL_STAMP(5)
+    };
+    {
+      int rotw = 0;
+      for (int st = 0; st * WPH < d.nblk; ++st) {
+        const int i = st * WPH + sub;
+        if (WPH == 1 || i < d.nblk) {     // (wave-uniform; with two waves per head and an odd block count the last step is one wave's)
+          phase_p(i);
+          FIL_STAMP(1)
+          phase_t();
+          FIL_STAMP(2)
+          phase_e(i, st & 1);
+          // The next block's inputs (requested in P) are waited for HERE, where they have long arrived.  Left to the compiler the
+          // wait lands at their first use in the next block's P, behind the loads that block issues for ITS successor
+          // (SlabLane::load has two forms, and across that branch the wait count degrades to vmcnt(0)): every block then waited
+          // for a full HBM round trip of loads it had just issued.
+          settle4(n_dy);
+          settle4(n_y);
+          settle4(n_av);
+          FIL_STAMP(3)
+        }
+        lds_barrier();   // every wave's dq / dres tile of this step is in LDS
+        FIL_STAMP(4)
+        phase_x(st, rotw);
+        rotw = rotw + 1 == nw ? 0 : rotw + 1;
+        FIL_STAMP(5)
+      }
     }
-    FIL_STAMP(5)
+    // the next sample's x rows on their way into L2 while this one finishes (its staging is a serial HBM round trip otherwise:
+    // 12 % of the K = 64 kernel by the phase stamps, with the whole workgroup -- the only one on its CU -- waiting)
+    if constexpr (XL) prefetch_x_lines<NC>(x, x_scrap, d, b + (int)gridDim.x, blockDim.x);
     // ---- dk of this head: accumulators -> the (now dead) k image as row fragments [key][a]
     // (two waves per head: each holds the sum over its own query blocks; the second wave's part goes through the image)
     if constexpr (WPH > 1) {
@@ -871,77 +1012,89 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
       for (int j = 0; j < NB; ++j)
         if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
     }
+    if constexpr (!DXL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the X phases' dx stores, before other waves read them back
     lds_barrier();
+    FIL_STAMP_POST(2)      // dk merge
     for (int j = sub; j < d.nblk; j += WPH) {
       const Op dk_c = tr_read<F16>(kimg, 16 * j, lane);       // dk[key 4g+s][a c]
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) dWk[cc] = mma<F16>(xsrc.col(j, cc, lane), dk_c, dWk[cc]);
     }
-    // dx += dk Wk^T (summed over the heads), by the lanes that wrote the dq part of the same elements.  All of a chunk's
-    // read-backs are issued before the first is used (they come from L2 / the Infinity Cache; the dk accumulators'
-    // registers are free by now).
-    // (job (block j = WPH step + sub', chunk cc) belongs to wave (sub' NC + cc + step) % nw, as in the block loop: the same
-    // lanes revisit the same elements; this wave's job of step `st` in round m is q = ((w - st) mod nw) + m nw)
-    for (int m = 0; m * nw < WPH * NC; ++m) {
+    if constexpr (XL) {
+      const int bn = b + (int)gridDim.x;
+      stage_x_load<NC, true>(make_rsrc(x, (long)d.B * d.F * d.K * 4), d, bn, threadIdx.x, blockDim.x, x_early && bn < d.B, xpre);
+    }
+    FIL_STAMP_POST(3)      // dWk
+    // dx += dk Wk^T (summed over the heads): jobs (block j, chunk cc), q = j NC + cc, dealt to the waves round robin
+    {
+      const int njobs = d.nblk * NC;
       if constexpr (DXL) {
-        // (the dq part is in the LDS image: read, add the dk part, write back -- no batch of global read-backs to keep in registers)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const int q = (w + nw - (j / WPH) % nw) % nw + m * nw, cc = q - (j % WPH) * NC;
-          if (j < d.nblk && cc >= 0 && cc < NC) {
-            float* pe = dxs + (cc * d.FP + 16 * j + 4 * g) * 16 + c;
-            f32x4 px = {pe[0], pe[16], pe[32], pe[48]};
-            for (int hh = 0; hh < NH; ++hh)
-              px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pe[16 * r] = px[r];
+        // (the dq part is in the LDS image as transposed tiles: a lane reads its four kin of one row, adds the dk part and stores the
+        // finished 16 bytes straight to dx -- 1 KiB contiguous per wave instruction in the head-major layout; no write-back, no
+        // barrier, no separate pass over the image, and the stores leave spread over the jobs instead of in one burst.
+        // Two jobs per pass, interleaved: a job is a chain of LDS read -> H dependent products -> store, and a wave has 6-7 of them;
+        // the second job of the last pass repeats the first and is not stored)
+        const bool vecx = (d.xcw & 3) == 0 && (d.K & 3) == 0;
+        for (int q = w; q < njobs; q += 2 * nw) {
+          const bool two = q + nw < njobs;
+          const int qB = two ? q + nw : q;
+          const int jA = q / NC, ccA = q - jA * NC, jB = qB / NC, ccB = qB - jB * NC;
+          f32x4 pxA = *reinterpret_cast<const f32x4*>(dxs + (ccA * d.FP + 16 * jA + c) * 16 + 4 * g);
+          f32x4 pxB = *reinterpret_cast<const f32x4*>(dxs + (ccB * d.FP + 16 * jB + c) * 16 + 4 * g);
+          auto head_part = [&](const int hh) __attribute__((always_inline)) {
+            pxA = mma<F16>(wt.arole(1, hh, ccA, lane), row_read<F16>(kimg0 + hh * KIS, 16 * jA + c, g), pxA);
+            pxB = mma<F16>(wt.arole(1, hh, ccB, lane), row_read<F16>(kimg0 + hh * KIS, 16 * jB + c, g), pxB);
+          };
+          if (NH == 4) {
+            head_part(0); head_part(1); head_part(2); head_part(3);
+          } else {
+            for (int hh = 0; hh < NH; ++hh) head_part(hh);
           }
+          auto put = [&](const int j, const int cc, const f32x4& px, const bool on) __attribute__((always_inline)) {
+            const int f = 16 * j + c, k0 = 16 * cc + 4 * g;
+            if (vecx) {
+              buf_store4(r_dx, (on && f < d.F && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB, px);
+            } else {
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) buf_store1(r_dx, (on && f < d.F && k0 + s4 < d.K) ? 4 * x_off(d, b, f, k0 + s4) : kOOB, px[s4]);
+            }
+          };
+          put(jA, ccA, pxA, true);
+          put(jB, ccB, pxB, two);
         }
       } else {
-      f32x4 old[NB];
+        // (the dq part went to global memory: all read-backs of a batch of jobs are issued before the first is used -- they come
+        // from L2 / the Infinity Cache; the dk accumulators' registers are free by now)
+        constexpr int kBatch = 8;
+        for (int q0 = w; q0 < njobs; q0 += kBatch * nw) {
+          f32x4 old[kBatch];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int q = (w + nw - (j / WPH) % nw) % nw + m * nw, cc = q - (j % WPH) * NC, kin = 16 * cc + c;
+          for (int u = 0; u < kBatch; ++u) {
+            const int q = q0 + u * nw, j = q / NC, cc = q - j * NC, kin = 16 * cc + c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = 16 * j + 4 * g + r;
-          old[j][r] = buf_load1(r_dx, (cc >= 0 && cc < NC && f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
-        }
-      }
+            for (int r = 0; r < 4; ++r) {
+              const int f = 16 * j + 4 * g + r;
+              old[u][r] = buf_load1(r_dx, (q < njobs && f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB);
+            }
+          }
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int q = (w + nw - (j / WPH) % nw) % nw + m * nw, cc = q - (j % WPH) * NC, kin = 16 * cc + c;
-        if (j < d.nblk && cc >= 0 && cc < NC) {
-          f32x4 px = old[j];
-          for (int hh = 0; hh < NH; ++hh)
-            px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
+          for (int u = 0; u < kBatch; ++u) {
+            const int q = q0 + u * nw, j = q / NC, cc = q - j * NC, kin = 16 * cc + c;
+            if (q < njobs) {
+              f32x4 px = old[u];
+              for (int hh = 0; hh < NH; ++hh)
+                px = mma<F16>(row_read<F16>(kimg0 + hh * KIS, 16 * j + c, g), wt.arole(1, hh, cc, lane), px);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int f = 16 * j + 4 * g + r;
-            buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);
+              for (int r = 0; r < 4; ++r) {
+                const int f = 16 * j + 4 * g + r;
+                buf_store1(r_dx, (f < d.F && kin < d.K) ? 4 * x_off(d, b, f, kin) : kOOB, px[r]);
+              }
+            }
           }
         }
       }
-      }
     }
-    if constexpr (DXL) {
-      // the finished dx image leaves as 16-byte pieces, 1 KiB contiguous per wave instruction (the barrier at the top of the
-      // next sample keeps the image from being overwritten before every wave has stored its share)
-      lds_barrier();
-      const bool vec = (d.xcw & 3) == 0 && (d.K & 3) == 0;
-      const int per_ch = d.FP * 4, total = d.NC * per_ch;
-      for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int ch = idx / per_ch, rem = idx - ch * per_ch;
-        const int f = rem >> 2, k0 = 16 * ch + 4 * (rem & 3);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(dxs + (ch * d.FP + f) * 16 + 4 * (rem & 3));
-        if (vec) {
-          buf_store4(r_dx, (f < d.F && k0 < d.K) ? 4 * x_off(d, b, f, k0) : kOOB, v);
-        } else {
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) buf_store1(r_dx, (f < d.F && k0 + s4 < d.K) ? 4 * x_off(d, b, f, k0 + s4) : kOOB, v[s4]);
-        }
-      }
-    }
+    FIL_STAMP_POST(4)      // dx += dk Wk^T
   }
   FIL_STAMP(6)
 #ifdef FIL_ATTN_STAMPS
@@ -977,45 +1130,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   }
 }
 
-// out_j[i] = sum_p part[(p*NJ + j)*n + i]  (fixed order): 64 outputs per workgroup, the 4 waves take every 4th partial
-__global__ __launch_bounds__(256) void attn_reduce_dw_kernel(const float* __restrict__ part, float* __restrict__ o0,
-                                                             float* __restrict__ o1, float* __restrict__ o2, int n, int parts) {
-  __shared__ float red[4][64];
+// One launch sums every per-workgroup partial of the backward in a fixed order (1024 threads = 16 waves per workgroup):
+//   workgroups [0, 3 nx):   out_j[i] = sum_p part[(p 3 + j) n + i], 64 outputs each (nx = ceil(n / 64)); wave v takes the partials
+//                           v, v + 16, ... (four independent sums), the 16 wave sums are added in wave order
+//   workgroups [3 nx, +32): dgamma / dbeta [a] = sum over the [blocks][2][16] partials, strided sums + a fixed tree
+// (rounds 1-4: two launches of 256 threads; 16 us of a 0.8 ms layer step, half of it the second launch's latency)
+__global__ __launch_bounds__(1024) void attn_reduce_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ o2, int n, int parts, const float* __restrict__ gb_part,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int gb_blocks, int A) {
+  __shared__ float red[1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane, j = blockIdx.y;
-  float* out = j == 0 ? o0 : (j == 1 ? o1 : o2);
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-  if (i < n) {
-    const float* p0 = part + (long)j * n + i;
-    const long ps = 3L * n;
-    int p = wave;
-    for (; p + 12 < parts; p += 16) {
-      t0 += p0[(long)p * ps];
-      t1 += p0[(long)(p + 4) * ps];
-      t2 += p0[(long)(p + 8) * ps];
-      t3 += p0[(long)(p + 12) * ps];
+  const int nx = (n + 63) / 64;
+  if ((int)blockIdx.x < 3 * nx) {
+    const int j = blockIdx.x / nx, i = (blockIdx.x - j * nx) * 64 + lane;
+    float* out = j == 0 ? o0 : (j == 1 ? o1 : o2);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (i < n) {
+      const float* p0 = part + (long)j * n + i;
+      const long ps = 3L * n;
+      int p = wave;
+      for (; p + 48 < parts; p += 64) {
+        t0 += p0[(long)p * ps];
+        t1 += p0[(long)(p + 16) * ps];
+        t2 += p0[(long)(p + 32) * ps];
+        t3 += p0[(long)(p + 48) * ps];
+      }
+      for (; p < parts; p += 16) t0 += p0[(long)p * ps];
     }
-    for (; p < parts; p += 4) t0 += p0[(long)p * ps];
-  }
-  red[wave][lane] = (t0 + t1) + (t2 + t3);
-  __syncthreads();
-  if (wave == 0 && i < n && out != nullptr) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-}
-
-// dgamma/dbeta: sum the [blocks][2][16] partials; one workgroup per output, strided partial sums + fixed-order tree
-__global__ __launch_bounds__(256) void attn_reduce_gb_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int blocks, int A) {
-  __shared__ float red[256];
-  const int which = blockIdx.x >> 4, a = blockIdx.x & 15;
-  float t = 0.f;
-  for (int p = threadIdx.x; p < blocks; p += 256) t += part[((long)p * 2 + which) * 16 + a];
-  red[threadIdx.x] = t;
-  __syncthreads();
-  for (int s2 = 128; s2 > 0; s2 >>= 1) {
-    if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    red[wave * 64 + lane] = (t0 + t1) + (t2 + t3);
     __syncthreads();
+    if (wave == 0 && i < n && out != nullptr) {
+      float t = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) t += red[v * 64 + lane];
+      out[i] = t;
+    }
+  } else {
+    if (dgamma == nullptr) return;
+    const int q = blockIdx.x - 3 * nx, which = q >> 4, a = q & 15;
+    float t = 0.f;
+    for (int p = threadIdx.x; p < gb_blocks; p += 1024) t += gb_part[((long)p * 2 + which) * 16 + a];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+      if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && a < A) (which == 0 ? dgamma : dbeta)[a] = red[0];
   }
-  if (threadIdx.x == 0 && a < A) (which == 0 ? dgamma : dbeta)[a] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------- host
@@ -1102,6 +1264,15 @@ static int resident_blocks(KernelT kernel, int threads, size_t sh) {
 }
 
 // CALL(NC, F16) for the runtime (NC, precision) pair; `f16` must be in scope
+#ifdef FIL_ATTN_DEV
+// experiment builds (tools/abl_build.py ... -DFIL_ATTN_DEV): only the instantiations BASELINE config 5 runs (f16, K = 16 and 64,
+// F = 200) -- a tenth of the compile time; everything else falls through to "unsupported"
+#define FIL_ATTN_NC(NCV, CALL)                    \
+  switch (NCV) {                                  \
+    case 1: { if (f16) { CALL(1, true); } } break; \
+    case 4: { if (f16) { CALL(4, true); } } break; \
+  }
+#else
 #define FIL_ATTN_NC(NCV, CALL)                                               \
   switch (NCV) {                                                             \
     case 1: { if (f16) { CALL(1, true); } else { CALL(1, false); } } break;  \
@@ -1109,6 +1280,7 @@ static int resident_blocks(KernelT kernel, int threads, size_t sh) {
     case 3: { if (f16) { CALL(3, true); } else { CALL(3, false); } } break;  \
     case 4: { if (f16) { CALL(4, true); } else { CALL(4, false); } } break;  \
   }
+#endif
 
 // diagnostic builds (-DFIL_ATTN_STAMPS): device buffer the backward writes its per-phase clocks to (fil_attn_debug_stamps)
 static long long* g_attn_stamps = nullptr;
@@ -1120,13 +1292,16 @@ static int launch_fwd(const float* x, const float* Wq, const float* Wk, const fl
   if (sh > kLdsCap) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_fwd: F=%d K=%d H=%d needs %zu bytes of LDS (> 160 KiB)", d.F, d.K, d.H, sh);
   const dim3 grid(d.B), block(64 * d.H);
   int rc = FIL_OK;
-#define CALL_FWD(N, P)                                                                                                     \
-  rc = allow_lds_attn(attn_fwd_kernel<N, P>, sh);                                                                          \
-  if (rc == FIL_OK)                                                                                                        \
-    hipLaunchKernelGGL((attn_fwd_kernel<N, P>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, d,   \
+#define CALL_FWD_A(N, P, AV)                                                                                                  \
+  rc = allow_lds_attn(attn_fwd_kernel<N, P, AV>, sh);                                                                         \
+  if (rc == FIL_OK)                                                                                                           \
+    hipLaunchKernelGGL((attn_fwd_kernel<N, P, AV>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, d,  \
                        scale, eps, fuse_relu)
+#define CALL_FWD(N, P) \
+  if (d.A == 16) { CALL_FWD_A(N, P, true); } else { CALL_FWD_A(N, P, false); }
   FIL_ATTN_NC(d.NC, CALL_FWD)
 #undef CALL_FWD
+#undef CALL_FWD_A
   if (rc != FIL_OK) return fail(rc, "fil_attn_fwd: cannot reserve %zu bytes of LDS", sh);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
@@ -1246,34 +1421,41 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     ProfScope ps("attn_bwd", st, (double)B * H * (10.0 * F * (double)F * A + 2.0 * F * K * A * (has_res ? 9 : 7)));
     const dim3 block(64 * H * wph);
     int lrc = FIL_OK;
-#define CALL_BWD_NBD(N, P, NBV, WV, DX)                                                                                         \
-  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV, WV, DX>, sh);                                                                 \
-  if (lrc == FIL_OK) {                                                                                                          \
-    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV, WV, DX>, 64 * H * WV, sh), WV);                                  \
-    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV, WV, DX>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, \
-                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                                 \
+#define CALL_BWD_NBDA(N, P, NBV, WV, DX, AV)                                                                                        \
+  lrc = allow_lds_attn(attn_bwd_kernel<N, P, NBV, WV, DX, AV>, sh);                                                                 \
+  if (lrc == FIL_OK) {                                                                                                              \
+    G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV, WV, DX, AV>, 64 * H * WV, sh), WV);                                  \
+    hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV, WV, DX, AV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, \
+                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                                     \
   }
+// (the attention_dim == 16 form -- one 16-byte access per row piece, no column masks -- exists for the large-F instantiations, where
+// the per-block prologue is a measurable part of the kernel; small shapes take the general form)
+#define CALL_BWD_NBD(N, P, NBV, WV, DX) \
+  if (NBV >= 13 && d.A == 16) { CALL_BWD_NBDA(N, P, NBV, WV, DX, (NBV >= 13)); } else { CALL_BWD_NBDA(N, P, NBV, WV, DX, false); }
 #define CALL_BWD_NB(N, P, NBV, WV) \
   if (dx_lds) { CALL_BWD_NBD(N, P, NBV, WV, true); } else { CALL_BWD_NBD(N, P, NBV, WV, false); }
   // (the two-waves-per-head form exists for the large-F instantiations only: smaller shapes fit two workgroups per CU)
+#ifdef FIL_ATTN_DEV
+#define CALL_BWD(N, P) \
+  if (d.nblk > 8 && d.nblk <= 13 && dx_lds) { if (wph == 2) { CALL_BWD_NBD(N, P, 13, 2, true); } else { CALL_BWD_NBD(N, P, 13, 1, true); } }
+#else
 #define CALL_BWD(N, P)                                                                     \
   if (d.nblk <= 4) { CALL_BWD_NB(N, P, 4, 1); }                                            \
   else if (d.nblk <= 8) { CALL_BWD_NB(N, P, 8, 1); }                                       \
   else if (d.nblk <= 13) { if (wph == 2) { CALL_BWD_NB(N, P, 13, 2); } else { CALL_BWD_NB(N, P, 13, 1); } } \
   else { if (wph == 2) { CALL_BWD_NB(N, P, 32, 2); } else { CALL_BWD_NB(N, P, 32, 1); } }
+#endif
     FIL_ATTN_NC(d.NC, CALL_BWD)
 #undef CALL_BWD
 #undef CALL_BWD_NB
 #undef CALL_BWD_NBD
+#undef CALL_BWD_NBDA
     if (lrc != FIL_OK) return fail(lrc, "fil_attn_bwd: cannot reserve %zu bytes of LDS", sh);
     FIL_CHECK_LAUNCH();
   }
   const int n = K * H * A;
-  hipLaunchKernelGGL(attn_reduce_dw_kernel, dim3(cdiv(n, 64), 3), dim3(256), 0, st, wpart, dWq, dWk, dWr, n, G * wph);
+  hipLaunchKernelGGL(attn_reduce_kernel, dim3(3 * cdiv(n, 64) + (gamma != nullptr ? 32 : 0)), dim3(1024), 0, st, wpart, dWq, dWk, dWr, n,
+                     G * wph, gb_part, gamma != nullptr ? dgamma : nullptr, dbeta, G * H * wph, A);
   FIL_CHECK_LAUNCH();
-  if (gamma != nullptr) {
-    hipLaunchKernelGGL(attn_reduce_gb_kernel, dim3(32), dim3(256), 0, st, gb_part, dgamma, dbeta, G * H * wph, A);
-    FIL_CHECK_LAUNCH();
-  }
   return FIL_OK;
 }

@@ -32,5 +32,9 @@ s = buf.cpu().numpy().reshape(-1, 8)
 s = s[s.sum(1) > 0]
 tot = s.sum(1)
 print("waves %d  total cycles/wave mean %.0f (min %.0f max %.0f) -- layer with K_in=%d" % (len(s), tot.mean(), tot.min(), tot.max(), KIN))
+import os
+if os.environ.get("FIL_STAMPS_POST"):
+    names = ["0 k projection (+ first inputs)", "1 the whole block loop", "2 dk merge (2 barriers)", "3 dWk", "4 dx += dk Wk^T", "5 barrier before the dx store",
+             "6 x staging (+ the last sample's dx store)", "7 dx store + barrier at the top of the next sample"]
 for i, n in enumerate(names):
     print("  %-45s %9.0f cycles  %5.1f %%" % (n, s[:, i].mean(), 100 * s[:, i].mean() / tot.mean()))
