@@ -236,6 +236,9 @@ def test_bench_strong_scaling_with_an_uneven_shard(tmp_path):
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["global_batch"] == 13
     assert res["value"] == pytest.approx(13 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"]), rel=1e-6)
     rc = res["rccl"]
+    # five windows of the same K steps: the first IS the headline, the others only give the spread
+    w = res["ms_per_step_windows"]
+    assert len(w) == 5 and w[0] == res["ms_per_step"] and res["ms_per_step_min"] <= res["ms_per_step_median"] <= res["ms_per_step_max"]
     assert rc["world_size_seen"] == 2 and len(rc["ms_per_step_per_rank"]) == 2
     assert rc["ms_per_step_min_rank"] <= rc["ms_per_step_max_rank"] and "exposed_allreduce_ms" in rc and rc["allreduce_alone_ms"] > 0
     from tests import bench_stub
