@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 210
+#define FIL_ABI_VERSION 211
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -229,6 +229,12 @@ int fil_embed_row_ids(const int64_t* offsets, const int64_t* sizes, const unsign
                       int64_t* row_ids, int B, int F, void* stream);
 int fil_embed_segment_sum(const float* g, const int64_t* perm, const int64_t* starts, const int64_t* rows_out, float* values,
                           float* dtable, long U, int K, void* stream);
+/* row ids AND their sort in one launch, for fil_embed_run_sum: field f's B entries sorted by (row id, position) -- a stable sort
+ * within the field -- land in sorted_ids / perm [f*B, (f+1)*B) (perm[j] = b*F + f); skipped entries (-1) lead each field's segment.
+ * Equal row ids are adjacent and in position order, which is all the run sum needs (rows of different fields cannot be equal), but
+ * the list as a whole is sorted only if offsets[] ascends.  B <= 8192 (one workgroup sorts a field in LDS), ids < 2^32 - 1. */
+int fil_embed_sort_fields(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,
+                          int64_t* sorted_ids, int64_t* perm, int B, int F, void* stream);
 /* the same sums without any data-dependent size (HIP-graph capturable): sorted_ids [R] = the stably sorted row ids, perm [R]
  * the sorting permutation; the run of every distinct id >= 0 is summed in sorted order into the (pre-zeroed) dense dtable. */
 int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, void* stream);

@@ -825,7 +825,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
       const int nb1 = cdiv(H[0], 64);
       const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + ddense_w | ddense_b from the head's block partials
-      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F) * 4 + nb1 + nh), dim3(256), 0, st, part, dp.pairs, F, symD, H[0], Hpp, dW[0], qt_dT,
+      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F + 3) / 4 + nb1 + nh), dim3(256), 0, st, part, dp.pairs, F, symD, H[0], Hpp, dW[0], qt_dT,
                          vlast, small, ncol, dbias[0], nb1, qt_hpart, qt_ndc, (int)LK, ddense_w, ddense_b);
     }
     FIL_CHECK_LAUNCH();

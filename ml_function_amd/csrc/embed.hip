@@ -94,6 +94,52 @@ __global__ __launch_bounds__(256) void embed_row_ids_kernel(const int64_t* __res
   }
 }
 
+// The sort of the deterministic gradient without a library sort: the global row ids of DIFFERENT fields never collide (offsets[f]
+// separate them), so equal ids only have to be adjacent WITHIN a field.  One workgroup per field sorts the field's B pairs
+// (local id + 1 or 0 for a skipped entry, position b) as 64-bit composites -- unique, so the order among equal ids is by position,
+// i.e. stable -- with a bitonic network in LDS, and writes them as the field's segment [f B, (f+1) B) of sorted_ids / perm
+// (perm = b F + f, the flat position torch.sort would report).  fil_embed_run_sum only needs equal ids adjacent, in a fixed order.
+// (torch.sort on 160 k keys is eight merge launches + casts: ~75 us of a 1.4 ms xDeepFM step; this is one ~10 us launch.)
+__global__ __launch_bounds__(1024) void embed_sort_fields_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
+                                                                 const unsigned char* __restrict__ frozen, const int64_t* __restrict__ idx,
+                                                                 int64_t* __restrict__ sorted_ids, int64_t* __restrict__ perm, int B, int F, int N) {
+  extern __shared__ unsigned long long skeys[];
+  const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const bool live = frozen == nullptr || !frozen[f];
+  const int64_t vf = sizes != nullptr ? sizes[f] : (int64_t)0x7fffffff;
+  for (int i = tid; i < N; i += nt) {
+    unsigned long long c = ~0ull;            // padding sorts last
+    if (i < B) {
+      const int64_t id = idx[(long)i * F + f];
+      const bool ok = live && id >= 0 && id < vf;
+      c = ((unsigned long long)(ok ? (unsigned)id + 1u : 0u) << 32) | (unsigned)i;
+    }
+    skeys[i] = c;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (N >> 1); t += nt) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const bool up = (i & k) == 0;
+        const unsigned long long a = skeys[i], b = skeys[l];
+        if ((a > b) == up) {
+          skeys[i] = b;
+          skeys[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int64_t off = offsets[f];
+  for (int i = tid; i < B; i += nt) {
+    const unsigned long long c = skeys[i];
+    const unsigned key = (unsigned)(c >> 32);
+    sorted_ids[(long)f * B + i] = key != 0u ? off + (int64_t)(key - 1u) : -1;
+    perm[(long)f * B + i] = (int64_t)(unsigned)c * F + f;
+  }
+}
+
 // One wave per unique row u: values[u,:] = sum_{j in [starts[u], starts[u+1])} g[perm[j], :], contributions taken in sorted
 // order, C = 64 / KQ of them in parallel (lane = c * KQ + kq, kq = 4 consecutive k), folded with a fixed xor tree.
 // rows_out[u] < 0 (the out-of-range bucket) is skipped.  dtable != NULL: the sum is also stored to dtable[rows_out[u], :]
@@ -202,15 +248,45 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
       pending &= pending - 1;
       const long js = j0 + ll / KQ;
       const int64_t rl = sorted_ids[js];
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c < C) {
-        for (long jj = js + c; jj < R && sorted_ids[jj] == rl; jj += C) {
-          const float* src = g + perm[jj] * K + kq * 4;
+      // the end of the run first, 64 ids per look (one ballot): the sums below then run over a KNOWN range, so that their loads do
+      // not hang on an id compare per element -- a field of 10 values in a batch of 4096 is ten runs of ~400, and a loop of three
+      // dependent loads per 64 / KQ elements was ~25 us of the 29 us launch
+      long je = js + 1;
+      for (;;) {
+        const long pp = je + lane;
+        const unsigned long long same = __ballot(pp < R && sorted_ids[pp < R ? pp : R - 1] == rl);
+        if (same == ~0ull) {
+          je += 64;
+          continue;
+        }
+        je += __builtin_ctzll(~same);
+        break;
+      }
+      // lane group c takes elements js + c, + C, ...: four at a time into four accumulators (independent loads), folded as
+      // (a0 + a1) + (a2 + a3) -- the order depends on the run's length only, so repeats stay bit-identical
+      float acc4[4][4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (kq * 4 + i < K) acc[i] += src[i];
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc4[u][i] = 0.f;
+      if (c < C) {
+        for (long jj = js + c; jj < je; jj += 4L * C) {
+          long pr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pr[u] = perm[jj + (long)u * C < je ? jj + (long)u * C : jj];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* src = g + pr[u] * K + kq * 4;
+            const bool on = jj + (long)u * C < je;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (on && kq * 4 + i < K) acc4[u][i] += src[i];
+          }
         }
       }
+      float acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = (acc4[0][i] + acc4[1][i]) + (acc4[2][i] + acc4[3][i]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) my[lane * 4 + i] = acc[i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -298,6 +374,26 @@ extern "C" int fil_embed_row_ids(const int64_t* offsets, const int64_t* sizes, c
   const long rows = (long)B * F;
   hipLaunchKernelGGL(embed_row_ids_kernel, dim3((int)std::min<long>((rows + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, offsets, sizes,
                      frozen, idx, row_ids, rows, F);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" int fil_embed_sort_fields(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,
+                                     int64_t* sorted_ids, int64_t* perm, int B, int F, void* stream) {
+  FIL_CHECK_ARG(B >= 0 && F >= 1);
+  if (B == 0) return FIL_OK;
+  FIL_CHECK_ARG(offsets && idx && sorted_ids && perm);
+  if (B > 8192) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_sort_fields: B=%d > 8192 pairs per field (64 KiB of LDS); sort the row ids of fil_embed_row_ids instead", B);
+  int N = 2;
+  while (N < B) N <<= 1;
+  const size_t sh = (size_t)N * sizeof(unsigned long long);
+  if (sh > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(embed_sort_fields_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FIL_ERR_HIP, "fil_embed_sort_fields: cannot reserve %zu bytes of LDS", sh);
+  }
+  hipLaunchKernelGGL(embed_sort_fields_kernel, dim3(F), dim3(N >= 2048 ? 1024 : std::max(64, N / 2)), sh, (hipStream_t)stream, offsets, sizes, frozen, idx,
+                     sorted_ids, perm, B, F, N);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

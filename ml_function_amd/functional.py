@@ -475,18 +475,29 @@ def product_attention(q, k, v, use_scale=False, mask=None, mask_mod=1):
 _SORT_CACHE = []
 
 
-def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None):
+def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None, per_field=False):
     """layout_key: a hashable description of (offsets, sizes, frozen) -- two tables with the same field layout (SparseEmbed
     passes its word sizes / frozen flags) share the sort even though their offset tensors are different objects."""
     lib = _lib.load()
     layout = layout_key if layout_key is not None else (
         offsets.data_ptr(), offsets._version, sizes.data_ptr() if sizes is not None else 0,
         frozen.data_ptr() if frozen is not None else 0)
-    key = (idx.data_ptr(), idx._version, tuple(idx.shape), layout, torch.cuda.current_stream().cuda_stream)
+    key = (idx.data_ptr(), idx._version, tuple(idx.shape), layout, torch.cuda.current_stream().cuda_stream, bool(per_field))
     for k, _, out in _SORT_CACHE:
         if k == key:
             return out
     B, F = idx.shape
+    if per_field and 0 < B <= 8192 and (n_rows is None or n_rows < 2 ** 31):
+        # the dense (run-sum) gradient only needs equal row ids adjacent and in a fixed order, and ids of different fields never
+        # collide: one launch sorts every field's (id, position) pairs in LDS (fil.h fil_embed_sort_fields) -- no library sort
+        sorted_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
+        perm = torch.empty(B * F, dtype=torch.int64, device=idx.device)
+        check(lib.fil_embed_sort_fields(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(sorted_ids), ptr(perm), B, F, stream_ptr()),
+              "fil_embed_sort_fields")
+        out = (sorted_ids, perm)
+        _SORT_CACHE.insert(0, (key, (idx, offsets, sizes, frozen), out))
+        del _SORT_CACHE[2:]
+        return out
     row_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
     check(lib.fil_embed_row_ids(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(row_ids), B, F, stream_ptr()), "fil_embed_row_ids")
     # (n_rows = rows of the concatenated table: when the global row ids fit 31 bits, 32-bit keys halve the radix passes of the sort)
@@ -569,7 +580,7 @@ class _EmbedFn(torch.autograd.Function):
             dtable = torch.sparse_coo_tensor(rows.unsqueeze(0), values, table_shape)
         else:               # dense table, deterministic, no data-dependent shapes (HIP-graph capturable)
             lib = _lib.load()
-            sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key, table_shape[0])
+            sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key, table_shape[0], per_field=True)
             dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
             check(lib.fil_embed_run_sum(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, stream_ptr()), "fil_embed_run_sum")
         return dtable, None, None, None, None, None, None, None, None, None

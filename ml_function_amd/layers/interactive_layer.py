@@ -216,7 +216,26 @@ class CrossLayer(Layer):
     def call(self, inputs, **kwargs):
         w = torch.cat([k.t() for k in self.kernel], dim=0)  # [L,D]
         b = torch.cat([k.t() for k in self.bias], dim=0)
+        if not self.fits_kernel_menu(inputs):
+            return self._composed(inputs, w, b).unsqueeze(-1)
         return Fn.dcn_cross(inputs, w, b).unsqueeze(-1)
+
+    def fits_kernel_menu(self, x):
+        """fil_dcn_*'s limits (include/fil.h): D <= 4096 (a sample's row lives in one wave's registers), cross_hidden <= 6.  The
+        reference has none (:255-282): a layer outside them takes the composed path below instead of raising."""
+        return x.shape[-1] <= 4096 and self.cross_hidden <= 6
+
+    def _composed(self, x, w, b):
+        """The reference's recurrence (:275-282) on the GPU with plain torch ops (autograd for the backward), layer by layer:
+        s_l = K.dot(x_l^T, w_l)  [B,1];  x_{l+1} = K.batch_dot(x0, s_l) + x_l + b_l.  Five passes over [B,D] per layer where the fused
+        kernel makes two for the whole stack -- it exists so that a reference-legal layer never raises."""
+        Fn._require_cuda(x)          # (torch ops would run on a CPU tensor: there is no CPU path in this package)
+        x0 = x.to(torch.float32)
+        xl = x0
+        for l in range(self.cross_hidden):
+            s = torch.matmul(xl, w[l].unsqueeze(-1))                # [B,1]
+            xl = x0 * s + xl + b[l]
+        return xl
 
 
 class CIN(Layer):

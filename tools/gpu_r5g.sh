@@ -8,5 +8,5 @@ d=json.load(open("gpurun_out/r5g/cin_fork$f.json"))
 print("fork=$f cin ms/step %.4f graph %s gpu_kernel %.4f"%(d["ms_per_step"], d.get("hipgraph_replay_ms_per_step"), d["gpu_kernel_ms_per_step"]), {k:round(v["avg_ms"],4) for k,v in d["kernels"].items()})
 PY
 done
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_dp_gpu.py -x -q -m gpu -k "test_cin_at_the_benchmark_shape or test_dp or capturable or graph" > gpurun_out/r5g/test.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_dp_gpu.py -x -q -m gpu -k "test_cin_at_the_benchmark_shape or test_dp or capturable or graph or test_cin_fused_tail or embed" > gpurun_out/r5g/test.log 2>&1
 tail -4 gpurun_out/r5g/test.log

@@ -10,9 +10,9 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --no-side --no-graph-replay > $out/bench_profiled.json 2> $out/stats.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_write.log
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_sq.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_write.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_sq.log
 # bench.py --steps 3 --warmup 1 runs 1 warm-up + 2 (pre-pass that picks the dominant kernel) + 3 timed + 3 (per-kernel table pass)
 # + 2 split warm-up + 3 split timed + 2 (full-table pass) step iterations; the exact-fp32 instantiations are launched in
 # 1 + 2 + 3 + 3 + 2 = 11 of them (the quadratic tail launches each first-layer GEMM kernel twice per step: slots #0 / #1)
