@@ -319,6 +319,8 @@ def side_workloads(args):
             a.steps, a.warmup = 200, 50      # more than ten steps to settle (10 steps read 0.06-0.33 ms on one box)
         elif a.workload in ("deepfm", "xdeepfm"):
             a.steps, a.warmup = 30, 10
+        elif a.workload == "autoint":        # (its inputs are drawn on the host first: the device idles, and the first ~20 ms after a
+            a.steps, a.warmup = 20, 10       # pause run a few % slow -- see the headline's warm-up note)
         try:
             r = deepfm_benchmark(a) if a.workload in ("deepfm", "xdeepfm") else side_benchmark(a)
             e = {"workload": r["config"]["workload"], "ms_per_step": round(r["ms_per_step"], 4), "samples_per_s": round(r["value"], 1),
