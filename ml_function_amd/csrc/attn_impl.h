@@ -1218,7 +1218,9 @@ static size_t bwd_lds(const AttnDims& d, bool f16, int wph = 1, bool dx_img = fa
   }
   return ((size_t)d.H * (d.FP + 16) * 20 + (size_t)d.H * wph * 6 * 320) * sizeof(float) + dxb;   // no weight table in the f32 mode
 }
-constexpr size_t kLdsCap = 160 * 1024;
+// dynamic LDS a backward / forward launch may ask for: the CU's 160 KiB less the kernels' static arrays (gamma_s, x_scrap: 320 bytes),
+// rounded to the allocation granule -- a shape within 320 bytes of the limit must take the smaller configuration, not fail at launch
+constexpr size_t kLdsCap = 160 * 1024 - 512;
 constexpr int kMaxBwdGrid = 1024;   // persistent workgroups (the workspace holds this many partial sums)
 
 // persistent backward grid: `per_cu` resident workgroups on each of the 256 CUs, sized so that every workgroup takes the

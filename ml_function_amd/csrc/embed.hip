@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void embed_row_ids_kernel(const int64_t* __res
 // (local id + 1 or 0 for a skipped entry, position b) as 64-bit composites -- unique, so the order among equal ids is by position,
 // i.e. stable -- with a bitonic network in LDS, and writes them as the field's segment [f B, (f+1) B) of sorted_ids / perm
 // (perm = b F + f, the flat position torch.sort would report).  fil_embed_run_sum only needs equal ids adjacent, in a fixed order.
-// (torch.sort on 160 k keys is eight merge launches + casts: ~75 us of a 1.4 ms xDeepFM step; this is one ~10 us launch.)
+// (torch.sort on 160 k keys is eight merge launches + casts: ~75 us of a 1.4 ms xDeepFM step; this is one 43 us launch -- 78 compare-exchange
+// steps of 64 KB of LDS traffic and a 16-wave barrier each; 32-bit composites and in-register small strides would halve it again)
 __global__ __launch_bounds__(1024) void embed_sort_fields_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
                                                                  const unsigned char* __restrict__ frozen, const int64_t* __restrict__ idx,
                                                                  int64_t* __restrict__ sorted_ids, int64_t* __restrict__ perm, int B, int F, int N) {

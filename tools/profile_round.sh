@@ -13,11 +13,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 be
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_write.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-side --no-graph-replay > /dev/null 2> $out/pmc_sq.log
-# bench.py --steps 3 --warmup 1 runs 1 warm-up + 2 (pre-pass that picks the dominant kernel) + 3 timed + 3 (per-kernel table pass)
-# + 2 split warm-up + 3 split timed + 2 (full-table pass) step iterations; the exact-fp32 instantiations are launched in
-# 1 + 2 + 3 + 3 + 2 = 11 of them (the quadratic tail launches each first-layer GEMM kernel twice per step: slots #0 / #1)
-python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json 11 > $out/pmc_traffic.txt
-python3 tools/mfma_util.py $out/pmc_sq $out/mfma_util.json 11 > $out/mfma_util.txt
+# bench.py --steps 3 --warmup 1 --windows 1 runs 1 warm-up + 2 (pre-pass that picks the dominant kernel) + 3 (per-kernel table pass) + 1 (warm-up in
+# front of the timed steps) + 3 timed + 2 (full-table pass) = 12 step iterations, each launching every kernel of the merged tail once
+python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json 12 > $out/pmc_traffic.txt
+python3 tools/mfma_util.py $out/pmc_sq $out/mfma_util.json 12 > $out/mfma_util.txt
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 # raw traces are large; keep the summaries
 find $out -name "*kernel_trace.csv" -delete
