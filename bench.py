@@ -279,7 +279,13 @@ def side_benchmark(args):
                                    "kernel": dom, "cycles_per_tile": cyc_tile, "tiles_per_launch": tiles,
                                    "floor_ms": floor_ms, "measured_ms": {k: v["avg_ms"] for k, v in ks.items()},
                                    "frac": floor_ms[dom] / d["avg_ms"],
-                                   "frac_per_kernel": {k: floor_ms[k] / v["avg_ms"] for k, v in ks.items() if k in floor_ms}},
+                                   "frac_per_kernel": {k: floor_ms[k] / v["avg_ms"] for k, v in ks.items() if k in floor_ms},
+                                   # the same mixes MEASURED on the chip (tools/probe_tile.hip, profiles/r05_probe_tile.txt: no memory, no
+                                   # LDS, 2-4 waves per SIMD -- occupancy does not change them): a transcendental is 10.7-12.4 cycles per
+                                   # wave instruction and SIMD, not 8, and the MFMAs' issue does not hide; f16 mode only
+                                   "probe_cycles_per_tile": {"attn_fwd": 115.0, "attn_bwd": 200.0},
+                                   "frac_of_probe_floor": {k: tiles * c / (1024 * 2.4e9) * 1e3 / ks[k]["avg_ms"]
+                                                           for k, c in (("attn_fwd", 115.0), ("attn_bwd", 200.0)) if k in ks} if f16 else None},
                  "mfma_tflops": {k: v["work"] / (v["avg_ms"] * 1e-3) / 1e12 for k, v in ks.items()},
                  "mfma_frac_of_peak": {k: v["work"] / (v["avg_ms"] * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS)
                                        for k, v in ks.items()},
