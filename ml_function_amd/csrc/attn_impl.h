@@ -1490,6 +1490,14 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     return e != nullptr ? atoi(e) : 0;
   }();
   int wph = (2 * sh > kLdsCap && d.nblk > 8) ? 2 : 1;
+  // ... and also where two one-wave-per-head workgroups do fit but only WITHOUT the LDS dx image, while one two-waves-per-head
+  // workgroup fits with it: the image is worth more than the second workgroup (K = 64, F = 160, f16: 0.435 ms against 0.462 --
+  // tools/attn_occ_probe.py; the dx part through global memory is a read-modify-write of 2 x |dx| per launch)
+  if (wph == 1 && d.nblk > 8 && H <= 4) {
+    const size_t sh1d = bwd_lds(d, f16, 1, true), sh2d = bwd_lds(d, f16, 2, true);
+    const bool dx_with_1 = sh1d <= kLdsCap && kLdsCap / sh1d >= std::min<size_t>(kLdsCap / sh, 2);
+    if (!dx_with_1 && sh2d <= kLdsCap) wph = 2;
+  }
   if (wph_knob == 1 || wph_knob == 2) wph = d.nblk > 8 ? wph_knob : 1;
   if (wph == 2 && (H > 4 || bwd_lds(d, f16, 2) > kLdsCap || d.nblk < 2)) wph = 1;
   sh = bwd_lds(d, f16, wph);
