@@ -1,17 +1,17 @@
 # A/B of experiment builds of the attention kernels: per-kernel times from rocprofv3 (one run per variant)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5e
+mkdir -p gpurun_out/attn_ab
 export TMPDIR=/tmp
 for v in ${VARIANTS}; do
   export FIL_LIB_PATH=$GRAFT_REPO_ROOT/ml_function_amd/abl/libfil_$v.so
   rm -rf /tmp/prof_$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -o p -- python3 bench.py --workload autoint --precision f16_mfma --layers 3 --steps 20 --warmup 5 > gpurun_out/r5e/autoint_$v.json 2> gpurun_out/r5e/autoint_$v.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -o p -- python3 bench.py --workload autoint --precision f16_mfma --layers 3 --steps 20 --warmup 5 > gpurun_out/attn_ab/autoint_$v.json 2> gpurun_out/attn_ab/autoint_$v.err
   f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)
-  cp $f gpurun_out/r5e/stats_$v.csv
+  cp $f gpurun_out/attn_ab/stats_$v.csv
   python3 - <<PY
 import csv,json
-d=json.load(open("gpurun_out/r5e/autoint_$v.json"))
-rows=list(csv.DictReader(open("gpurun_out/r5e/stats_$v.csv")))
+d=json.load(open("gpurun_out/attn_ab/autoint_$v.json"))
+rows=list(csv.DictReader(open("gpurun_out/attn_ab/stats_$v.csv")))
 out=[]
 for r in rows:
     n=r["Name"]
@@ -23,6 +23,6 @@ PY
 done
 if [ -n "$TESTV" ]; then
 export FIL_LIB_PATH=$GRAFT_REPO_ROOT/ml_function_amd/abl/libfil_${TESTV}.so
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${TESTK:-(test_attn_at_the_benchmark_shape and f16) or (test_attn_two_waves_per_head and f16)}" > gpurun_out/r5e/test.log 2>&1
-tail -3 gpurun_out/r5e/test.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${TESTK:-(test_attn_at_the_benchmark_shape and f16) or (test_attn_two_waves_per_head and f16)}" > gpurun_out/attn_ab/test.log 2>&1
+tail -3 gpurun_out/attn_ab/test.log
 fi

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5c
+mkdir -p gpurun_out/attn_stamps
 for v in ${VARIANTS}; do
   export FIL_LIB_PATH=$GRAFT_REPO_ROOT/ml_function_amd/abl/libfil_$v.so
   for K in 64 16; do
