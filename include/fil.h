@@ -232,9 +232,11 @@ int fil_embed_segment_sum(const float* g, const int64_t* perm, const int64_t* st
 /* row ids AND their sort in one launch, for fil_embed_run_sum: field f's B entries sorted by (row id, position) -- a stable sort
  * within the field -- land in sorted_ids / perm [f*B, (f+1)*B) (perm[j] = b*F + f); skipped entries (-1) lead each field's segment.
  * Equal row ids are adjacent and in position order, which is all the run sum needs (rows of different fields cannot be equal), but
- * the list as a whole is sorted only if offsets[] ascends.  B <= 8192 (one workgroup sorts a field in LDS), ids < 2^32 - 1. */
+ * the list as a whole is sorted only if offsets[] ascends.  B <= 8192 (one workgroup sorts a field in LDS), ids < 2^32 - 1.
+ * max_vocab: an upper bound of every field's vocabulary (the concatenated table's row count will do), 0 = unknown: when
+ * (max_vocab + 1) * 2^ceil(log2 B) fits 32 bits the sort runs on 32-bit composites (half the LDS traffic). */
 int fil_embed_sort_fields(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,
-                          int64_t* sorted_ids, int64_t* perm, int B, int F, void* stream);
+                          int64_t* sorted_ids, int64_t* perm, int B, int F, int64_t max_vocab, void* stream);
 /* the same sums without any data-dependent size (HIP-graph capturable): sorted_ids [R] = the stably sorted row ids, perm [R]
  * the sorting permutation; the run of every distinct id >= 0 is summed in sorted order into the (pre-zeroed) dense dtable. */
 int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, void* stream);

@@ -47,7 +47,7 @@ SIGNATURES = {
     "fil_embed_gather_xt": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_scatter_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_row_ids": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
-    "fil_embed_sort_fields": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fil_embed_sort_fields": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _c.c_int64, _P]),
     "fil_embed_segment_sum": (_I, [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
     "fil_embed_run_sum": (_I, [_P, _P, _P, _P, _c.c_long, _I, _P]),
 }

@@ -100,20 +100,25 @@ __global__ __launch_bounds__(256) void embed_row_ids_kernel(const int64_t* __res
 // i.e. stable -- with a bitonic network in LDS, and writes them as the field's segment [f B, (f+1) B) of sorted_ids / perm
 // (perm = b F + f, the flat position torch.sort would report).  fil_embed_run_sum only needs equal ids adjacent, in a fixed order.
 // (torch.sort on 160 k keys is eight merge launches + casts: ~75 us of a 1.4 ms xDeepFM step; this is one 43 us launch -- 78 compare-exchange
-// steps of 64 KB of LDS traffic and a 16-wave barrier each; 32-bit composites and in-register small strides would halve it again)
+// steps of 64 KB of LDS traffic and a 16-wave barrier each with 64-bit composites; 32-bit ones where the vocabulary allows)
+// KeyT = unsigned: the composite is (id + 1) << log2(N) | position in 32 bits -- half the LDS traffic of a step -- when every id + 1
+// fits the bits the positions leave (the host checks max_vocab); unsigned long long: (id + 1) << 32 | position.
+template <typename KeyT>
 __global__ __launch_bounds__(1024) void embed_sort_fields_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
                                                                  const unsigned char* __restrict__ frozen, const int64_t* __restrict__ idx,
-                                                                 int64_t* __restrict__ sorted_ids, int64_t* __restrict__ perm, int B, int F, int N) {
-  extern __shared__ unsigned long long skeys[];
+                                                                 int64_t* __restrict__ sorted_ids, int64_t* __restrict__ perm, int B, int F, int N,
+                                                                 int pos_bits) {
+  extern __shared__ unsigned long long skeys_raw[];
+  KeyT* skeys = reinterpret_cast<KeyT*>(skeys_raw);
   const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const bool live = frozen == nullptr || !frozen[f];
   const int64_t vf = sizes != nullptr ? sizes[f] : (int64_t)0x7fffffff;
   for (int i = tid; i < N; i += nt) {
-    unsigned long long c = ~0ull;            // padding sorts last
+    KeyT c = ~(KeyT)0;            // padding sorts last
     if (i < B) {
       const int64_t id = idx[(long)i * F + f];
       const bool ok = live && id >= 0 && id < vf;
-      c = ((unsigned long long)(ok ? (unsigned)id + 1u : 0u) << 32) | (unsigned)i;
+      c = ((KeyT)(ok ? (unsigned)id + 1u : 0u) << pos_bits) | (KeyT)(unsigned)i;
     }
     skeys[i] = c;
   }
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(1024) void embed_sort_fields_kernel(const int64_t* 
       for (int t = tid; t < (N >> 1); t += nt) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
         const bool up = (i & k) == 0;
-        const unsigned long long a = skeys[i], b = skeys[l];
+        const KeyT a = skeys[i], b = skeys[l];
         if ((a > b) == up) {
           skeys[i] = b;
           skeys[l] = a;
@@ -133,11 +138,12 @@ __global__ __launch_bounds__(1024) void embed_sort_fields_kernel(const int64_t* 
     }
   }
   const int64_t off = offsets[f];
+  const KeyT pos_mask = ((KeyT)1 << pos_bits) - 1;
   for (int i = tid; i < B; i += nt) {
-    const unsigned long long c = skeys[i];
-    const unsigned key = (unsigned)(c >> 32);
+    const KeyT c = skeys[i];
+    const unsigned key = (unsigned)(c >> pos_bits);
     sorted_ids[(long)f * B + i] = key != 0u ? off + (int64_t)(key - 1u) : -1;
-    perm[(long)f * B + i] = (int64_t)(unsigned)c * F + f;
+    perm[(long)f * B + i] = (int64_t)(unsigned)(c & pos_mask) * F + f;
   }
 }
 
@@ -380,21 +386,31 @@ extern "C" int fil_embed_row_ids(const int64_t* offsets, const int64_t* sizes, c
 }
 
 extern "C" int fil_embed_sort_fields(const int64_t* offsets, const int64_t* sizes, const unsigned char* frozen, const int64_t* idx,
-                                     int64_t* sorted_ids, int64_t* perm, int B, int F, void* stream) {
-  FIL_CHECK_ARG(B >= 0 && F >= 1);
+                                     int64_t* sorted_ids, int64_t* perm, int B, int F, int64_t max_vocab, void* stream) {
+  FIL_CHECK_ARG(B >= 0 && F >= 1 && max_vocab >= 0);
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(offsets && idx && sorted_ids && perm);
   if (B > 8192) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_sort_fields: B=%d > 8192 pairs per field (64 KiB of LDS); sort the row ids of fil_embed_row_ids instead", B);
-  int N = 2;
-  while (N < B) N <<= 1;
-  const size_t sh = (size_t)N * sizeof(unsigned long long);
-  if (sh > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(embed_sort_fields_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+  int N = 2, bits = 1;
+  while (N < B) {
+    N <<= 1;
+    ++bits;
+  }
+  // 32-bit composites when every id + 1 (<= max_vocab, an upper bound of every field's vocabulary; 0 = unknown) fits above the position bits
+  const bool narrow = max_vocab > 0 && ((max_vocab + 1) << bits) <= (int64_t)0xffffffffLL;
+  const size_t sh = (size_t)N * (narrow ? sizeof(unsigned) : sizeof(unsigned long long));
+  const void* kern = narrow ? reinterpret_cast<const void*>(embed_sort_fields_kernel<unsigned>)
+                            : reinterpret_cast<const void*>(embed_sort_fields_kernel<unsigned long long>);
+  if (sh > 48 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
     (void)hipGetLastError();
     return fail(FIL_ERR_HIP, "fil_embed_sort_fields: cannot reserve %zu bytes of LDS", sh);
   }
-  hipLaunchKernelGGL(embed_sort_fields_kernel, dim3(F), dim3(N >= 2048 ? 1024 : std::max(64, N / 2)), sh, (hipStream_t)stream, offsets, sizes, frozen, idx,
-                     sorted_ids, perm, B, F, N);
+  const dim3 block(N >= 2048 ? 1024 : std::max(64, N / 2));
+  if (narrow)
+    hipLaunchKernelGGL(embed_sort_fields_kernel<unsigned>, dim3(F), block, sh, (hipStream_t)stream, offsets, sizes, frozen, idx, sorted_ids, perm, B, F, N, bits);
+  else
+    hipLaunchKernelGGL(embed_sort_fields_kernel<unsigned long long>, dim3(F), block, sh, (hipStream_t)stream, offsets, sizes, frozen, idx, sorted_ids, perm, B,
+                       F, N, 32);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

@@ -492,8 +492,8 @@ def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None, p
         # collide: one launch sorts every field's (id, position) pairs in LDS (fil.h fil_embed_sort_fields) -- no library sort
         sorted_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
         perm = torch.empty(B * F, dtype=torch.int64, device=idx.device)
-        check(lib.fil_embed_sort_fields(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(sorted_ids), ptr(perm), B, F, stream_ptr()),
-              "fil_embed_sort_fields")
+        check(lib.fil_embed_sort_fields(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(sorted_ids), ptr(perm), B, F,
+                                        int(n_rows) if n_rows is not None else 0, stream_ptr()), "fil_embed_sort_fields")
         out = (sorted_ids, perm)
         _SORT_CACHE.insert(0, (key, (idx, offsets, sizes, frozen), out))
         del _SORT_CACHE[2:]

@@ -682,14 +682,15 @@ def test_embed_sort_fields_is_a_stable_sort_within_each_field(B):
     ids = torch.tensor(idx, device="cuda")
     s_ids = torch.empty(B * F, dtype=torch.int64, device="cuda")
     perm = torch.empty(B * F, dtype=torch.int64, device="cuda")
-    assert lib.fil_embed_sort_fields(ptr(offsets), ptr(sizes), ptr(frozen), ptr(ids), ptr(s_ids), ptr(perm), B, F, stream_ptr()) == 0
-    s_ids, perm = s_ids.cpu().numpy().reshape(F, B), perm.cpu().numpy().reshape(F, B)
     off = offsets.cpu().numpy()
-    for f in range(F):
-        ok = (idx[:, f] >= 0) & (idx[:, f] < vocab[f]) & (f != 3)
-        row = np.where(ok, off[f] + idx[:, f], -1)
-        order = np.argsort(row, kind="stable")
-        assert np.array_equal(s_ids[f], row[order]) and np.array_equal(perm[f], order * F + f)
+    for max_vocab in (0, sum(vocab)):        # 64-bit composites (bound unknown) and 32-bit ones
+        assert lib.fil_embed_sort_fields(ptr(offsets), ptr(sizes), ptr(frozen), ptr(ids), ptr(s_ids), ptr(perm), B, F, max_vocab, stream_ptr()) == 0
+        got_ids, got_perm = s_ids.cpu().numpy().reshape(F, B), perm.cpu().numpy().reshape(F, B)
+        for f in range(F):
+            ok = (idx[:, f] >= 0) & (idx[:, f] < vocab[f]) & (f != 3)
+            row = np.where(ok, off[f] + idx[:, f], -1)
+            order = np.argsort(row, kind="stable")
+            assert np.array_equal(got_ids[f], row[order]) and np.array_equal(got_perm[f], order * F + f)
 
 
 def test_sparse_embed_layer_options():
