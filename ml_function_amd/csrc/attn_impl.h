@@ -545,15 +545,32 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     }
     const Op qn = to_op<F16>(qT * qs);
     f32x4 avT = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < d.nblk; ++t) {
-      const Op kA = row_read<F16>(kimg, 16 * t + c, g);
-      const Op kT = tr_read<F16>(kimg, 16 * t, lane);
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-      sc = mma<F16>(kA, qn, sc);                                                  // [key 4g+r][query c], times -log2e*scale
-      f32x4 sg;
+    // straight-line tiles with a scalar exit test each (F <= 512: at most 32): the tile index is a compile-time constant, so the
+    // two LDS reads of a tile use immediate offsets -- as a counted loop every tile paid two vector adds for its addresses, two of
+    // the ~21 vector-issue slots of a tile in a loop that is bound by them
+    {
+      auto fwd_tile = [&](auto Tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(Tc)::value;
+        const Op kA = row_read<F16>(kimg, 16 * t + c, g);
+        const Op kT = tr_read<F16>(kimg, 16 * t, lane);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = mma<F16>(kA, qn, sc);                                                  // [key 4g+r][query c], times -log2e*scale
+        f32x4 sg;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sg[r] = sigmoid_from_neg_log2(sc[r]);
-      avT = mma<F16>(kT, to_op<F16>(sg), avT);                                    // [a 4g+r][query c]
+        for (int r = 0; r < 4; ++r) sg[r] = sigmoid_from_neg_log2(sc[r]);
+        avT = mma<F16>(kT, to_op<F16>(sg), avT);                                    // [a 4g+r][query c]
+      };
+      int nb_s = d.nblk;
+      asm volatile("" : "+s"(nb_s));
+#define FIL_FWD_TILE(T)                                  \
+  if (T >= nb_s) goto fwd_tiles_done;                    \
+  fwd_tile(std::integral_constant<int, T>{});
+      FIL_FWD_TILE(0) FIL_FWD_TILE(1) FIL_FWD_TILE(2) FIL_FWD_TILE(3) FIL_FWD_TILE(4) FIL_FWD_TILE(5) FIL_FWD_TILE(6) FIL_FWD_TILE(7)
+      FIL_FWD_TILE(8) FIL_FWD_TILE(9) FIL_FWD_TILE(10) FIL_FWD_TILE(11) FIL_FWD_TILE(12) FIL_FWD_TILE(13) FIL_FWD_TILE(14) FIL_FWD_TILE(15)
+      FIL_FWD_TILE(16) FIL_FWD_TILE(17) FIL_FWD_TILE(18) FIL_FWD_TILE(19) FIL_FWD_TILE(20) FIL_FWD_TILE(21) FIL_FWD_TILE(22) FIL_FWD_TILE(23)
+      FIL_FWD_TILE(24) FIL_FWD_TILE(25) FIL_FWD_TILE(26) FIL_FWD_TILE(27) FIL_FWD_TILE(28) FIL_FWD_TILE(29) FIL_FWD_TILE(30) FIL_FWD_TILE(31)
+#undef FIL_FWD_TILE
+    fwd_tiles_done:;
     }
     // lane (g,c): av[query 16i+c][a 4g..4g+3]
     const int f = 16 * i + c;
