@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 211
+#define FIL_ABI_VERSION 212
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -154,9 +154,11 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       y = LN(sigmoid(scale * q k^T) k),  res_out [H,B,F,A] = x Wr (may be NULL).
  *   bwd: dy [H,B,F,A] (and, when fuse_relu == 0 and Wr != NULL, dres_in [H,B,F,A] = gradient of res_out)
  *        -> dx [B,F,K], dWq, dWk, dWr [K,H,A], dgamma, dbeta [A].
- *   av_out (fwd, optional) [H,B,F,A]: the attention output before LayerNorm, saved for the backward (its LayerNorm
- *       backward needs it; the fused ReLU mask is y > 0, so pass the forward's y back as y_saved).  If either is NULL the
- *       backward first re-runs the forward into its workspace (fil_attn_bwd_workspace_bytes(.., have_saved = 0)).
+ *   av_out [H,B,F,A] + rstd_out [H,B,F] (fwd, optional, both or neither; used with gamma): the LayerNorm input saved for the
+ *       backward, NORMALISED -- (av - mean) / sqrt(var + eps) -- with the rows' 1 / sqrt(var + eps) beside it, so that the
+ *       backward's LayerNorm gradient does not derive the statistics of every row again (av_saved + rstd_saved).  The fused
+ *       ReLU mask is y > 0: pass the forward's y back as y_saved.  If any of them is NULL the backward first re-runs the
+ *       forward into its workspace (fil_attn_bwd_workspace_bytes(.., have_saved = 0)); same gradients bit for bit.
  *   x_chunk: 0 = x (and dx) are [B,F,K].  c > 0 = head-major [K/c][B][F][c], i.e. the [H',B,F,A'] output of a previous
  *       interacting layer read in place as its head-concat [B,F,H'*A'] (ESULayer's convention, behavior_layer.py:973):
  *       a stack of interacting layers (BASELINE config 5: 3 layers) needs no transposes, and dx IS the dy of the layer below.
@@ -175,12 +177,12 @@ enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);
 size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A, int have_saved);
 int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                 const float* beta, float* y, float* res_out, float* av_out, int B, int F, int K, int H, int A,
-                 float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
+                 const float* beta, float* y, float* res_out, float* av_out, float* rstd_out, int B, int F, int K, int H,
+                 int A, float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
                  size_t workspace_bytes, void* stream);
 int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                  const float* beta, const float* dy, const float* dres_in, const float* y_saved, const float* av_saved,
-                 float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H,
+                 const float* rstd_saved, float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta, int B, int F, int K, int H,
                  int A, float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
                  size_t workspace_bytes, void* stream);
 

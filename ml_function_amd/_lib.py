@@ -39,8 +39,8 @@ SIGNATURES = {
     "fil_cin_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _Z, _P]),
     "fil_attn_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "fil_attn_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "fil_attn_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
-    "fil_attn_bwd": (_I, [_P] * 16 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
+    "fil_attn_fwd": (_I, [_P] * 10 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
+    "fil_attn_bwd": (_I, [_P] * 17 + [_I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
     "fil_pattn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_pattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_embed_gather": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

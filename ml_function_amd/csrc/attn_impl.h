@@ -481,8 +481,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
                                                         const float* __restrict__ Wk, const float* __restrict__ Wr,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, float* __restrict__ res_out,
-                                                        float* __restrict__ av_out, AttnDims d, float scale, float eps,
-                                                        int fuse_relu) {
+                                                        float* __restrict__ av_out, float* __restrict__ rstd_out, AttnDims d,
+                                                        float scale, float eps, int fuse_relu) {
   typedef typename Prec<F16>::Elem Elem;
   typedef typename Prec<F16>::Op Op;
   constexpr int RS = Prec<F16>::RS;
@@ -530,8 +530,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
   const long slab = ((long)h * d.B + b) * d.F * d.A;   // this (head, sample)'s [F][A] rows
   const long slab_bytes = (long)d.F * d.A * 4;
   const __amdgpu_buffer_rsrc_t r_y = make_rsrc(y + slab, slab_bytes);
-  const __amdgpu_buffer_rsrc_t r_av = make_rsrc(av_out != nullptr ? av_out + slab : y, av_out != nullptr ? slab_bytes : 0);
+  // the rows kept for the backward are the NORMALISED ones, with their 1/sigma beside them (rstd_out): its LayerNorm gradient starts
+  // from them instead of deriving mean and variance of every row again
+  const bool keep_stats = use_ln && rstd_out != nullptr;
+  const __amdgpu_buffer_rsrc_t r_av = make_rsrc(keep_stats ? av_out + slab : y, keep_stats ? slab_bytes : 0);
   const __amdgpu_buffer_rsrc_t r_res = make_rsrc(res_out != nullptr ? res_out + slab : y, res_out != nullptr ? slab_bytes : 0);
+  const __amdgpu_buffer_rsrc_t r_rs = make_rsrc(keep_stats ? rstd_out + ((long)h * d.B + b) * d.F : y, keep_stats ? (long)d.F * 4 : 0);
   for (int i = 0; i < d.nblk; ++i) {
     Op xr[NC];
 #pragma unroll
@@ -589,9 +593,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
       }
       const float rstd = __builtin_amdgcn_rsqf(groups_sum(sq) * inv_a + eps);   // v_rsq_f32, 1 ulp
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ln[s] = dv[s] * rstd * gam[s] + bet[s];
+      for (int s = 0; s < 4; ++s) {
+        dv[s] *= rstd;
+        ln[s] = dv[s] * gam[s] + bet[s];
+      }
+      sl.template store_t<A16>(r_av, f, dv);                  // zero-size descriptors drop the stores when nothing is kept
+      buf_store1(r_rs, 4 * f + (g == 0 ? 0 : kOOB), rstd);
     }
-    sl.template store_t<A16>(r_av, f, avT);          // a zero-size descriptor drops the stores when av is not kept
     if (fuse_relu) {
       f32x4 o;
 #pragma unroll
@@ -632,8 +640,8 @@ template <int NC, bool F16, int NB, int WPH, bool DXL, bool A16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BWD_WPE(NC, F16)))) void attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wr,
     const float* __restrict__ gamma, const float* __restrict__ dy, const float* __restrict__ dres_in,
-    const float* __restrict__ y_s, const float* __restrict__ av_s, float* __restrict__ dx, float* __restrict__ wpart,
-    float* __restrict__ gb_part, AttnDims d, float scale, float eps, int fuse_relu, long long* __restrict__ stamps) {
+    const float* __restrict__ y_s, const float* __restrict__ av_s, const float* __restrict__ rstd_s, float* __restrict__ dx,
+    float* __restrict__ wpart, float* __restrict__ gb_part, AttnDims d, float scale, float eps, int fuse_relu, long long* __restrict__ stamps) {
   typedef typename Prec<F16>::Elem Elem;
   typedef typename Prec<F16>::Op Op;
   constexpr int RS = Prec<F16>::RS;
@@ -767,10 +775,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     const __amdgpu_buffer_rsrc_t r_ys = make_rsrc(fuse_relu ? y_s + slab : dy, fuse_relu ? slab_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_avs = make_rsrc(use_ln ? av_s + slab : dy, use_ln ? slab_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_dr = make_rsrc(use_dr ? dres_in + slab : dy, use_dr ? slab_bytes : 0);
+    // av_s: the NORMALISED LayerNorm input rows, rstd_s their 1/sigma, as the forward leaves them (the statistics are not derived again)
+    const __amdgpu_buffer_rsrc_t r_rs = make_rsrc(use_ln ? rstd_s + ((long)h * d.B + b) * d.F : dy, use_ln ? (long)d.F * 4 : 0);
 
     // block inputs are fetched one query block ahead (they come from HBM)
     // (dres_in of the unfused mode is read at use: one more prefetched tensor would cost the fused mode a wave per SIMD)
     f32x4 n_dy = sl.template load_t<A16>(r_dy, 16 * sub + c), n_y = sl.template load_t<A16>(r_ys, 16 * sub + c), n_av = sl.template load_t<A16>(r_avs, 16 * sub + c);
+    float n_rs = buf_load1(r_rs, 4 * (16 * sub + c));
 
     {
       Op wk[NC];
@@ -793,6 +804,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     settle4(n_dy);
     settle4(n_y);
     settle4(n_av);
+    asm volatile("" : "+v"(n_rs));
     FIL_STAMP(0)
     // ---- The block loop.  A query block i goes through four phases:
     //   P(i)  LayerNorm / ReLU backward of the block's rows, q_i in both orientations; requests the inputs of the wave's next block
@@ -810,11 +822,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
       f32x4 dz = n_dy, dr = {0.f, 0.f, 0.f, 0.f};
       if (use_dr) dr = sl.template load_t<A16>(r_dr, 16 * i + c);
       const f32x4 yv = n_y, avv = n_av;
+      const float rsv = n_rs;
       {
         const int fn = 16 * (i + WPH) + c;  // past the last block every lane is out of range and reads zeros
         n_dy = sl.template load_t<A16>(r_dy, fn);
         n_y = sl.template load_t<A16>(r_ys, fn);
         n_av = sl.template load_t<A16>(r_avs, fn);
+        n_rs = buf_load1(r_rs, 4 * fn);
       }
       // ---- LayerNorm / ReLU backward of query block i: lane (g,c) owns row f = 16i+c, a = 4g..4g+3
       if (fuse_relu) {
@@ -825,24 +839,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
       }
       f32x4 dav = dz;
       if (use_ln) {
-        float sum = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sum += aval[s] ? avv[s] : 0.f;
-        const float mu = groups_sum(sum) * inv_a;
         f32x4 xh;
-        float sq = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          xh[s] = aval[s] ? avv[s] - mu : 0.f;
-          sq = fmaf(xh[s], xh[s], sq);
-        }
-        const float rstd = __builtin_amdgcn_rsqf(groups_sum(sq) * inv_a + eps);   // v_rsq_f32, 1 ulp
+        for (int s = 0; s < 4; ++s) xh[s] = aval[s] ? avv[s] : 0.f;
+        const float rstd = rsv;
         float s1 = 0.f, s2 = 0.f;
         f32x4 dxh;
         const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma_s + 4 * g);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          xh[s] *= rstd;
           dgam[s] = fmaf(dz[s], xh[s], dgam[s]);
           dbet[s] += dz[s];
           dxh[s] = dz[s] * gam[s];
@@ -1000,6 +1005,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
           settle4(n_dy);
           settle4(n_y);
           settle4(n_av);
+          asm volatile("" : "+v"(n_rs));
           FIL_STAMP(3)
         }
         lds_barrier();   // every wave's dq / dres tile of this step is in LDS
@@ -1252,7 +1258,8 @@ static size_t attn_bwd_ws(const AttnDims& d, bool have_saved) {
   const long G = std::min<long>(kMaxBwdGrid, 2L * std::max(d.B, 1));   // partial sets: workgroups x waves per head
   size_t t = align_up((size_t)G * 3 * d.K * d.H * d.A * sizeof(float), 256);       // dW partials
   t += align_up((size_t)G * d.H * 32 * sizeof(float), 256);                         // dgamma/dbeta partials
-  if (!have_saved) t += 2 * align_up((size_t)d.H * d.B * d.F * d.A * sizeof(float), 256);   // av / y recomputed
+  if (!have_saved)                                                                  // av, y and rstd recomputed
+    t += 2 * align_up((size_t)d.H * d.B * d.F * d.A * sizeof(float), 256) + align_up((size_t)d.H * d.B * d.F * sizeof(float), 256);
   return t;
 }
 
@@ -1311,7 +1318,7 @@ static int resident_blocks(KernelT kernel, int threads, size_t sh) {
 // ---- the backward's instantiations, one translation unit per precision (attn_bwd_f16.hip / attn_bwd_f32.hip: they compile beside
 // attn.hip instead of behind it -- the f16 set alone is 80 kernels)
 struct AttnBwdLaunch {
-  const float *x, *Wq, *Wk, *Wr, *gamma, *dy, *dres_in, *y_saved, *av_saved;
+  const float *x, *Wq, *Wk, *Wr, *gamma, *dy, *dres_in, *y_saved, *av_saved, *rstd_saved;
   float *dx, *wpart, *gb_part;
   AttnDims d;
   float scale, eps;
@@ -1333,7 +1340,7 @@ int attn_launch_bwd_f16(const AttnBwdLaunch& a, int* G_out) {
 int attn_launch_bwd_f32(const AttnBwdLaunch& a, int* G_out) {
 #endif
   const float *x = a.x, *Wq = a.Wq, *Wk = a.Wk, *Wr = a.Wr, *gamma = a.gamma, *dy = a.dy, *dres_in = a.dres_in, *y_saved = a.y_saved,
-              *av_saved = a.av_saved;
+              *av_saved = a.av_saved, *rstd_saved = a.rstd_saved;
   float *dx = a.dx, *wpart = a.wpart, *gb_part = a.gb_part;
   const AttnDims& d = a.d;
   const float scale = a.scale, eps = a.eps;
@@ -1368,7 +1375,7 @@ int attn_launch_bwd_f32(const AttnBwdLaunch& a, int* G_out) {
   if (lrc == FIL_OK) {                                                                                                              \
     G = bwd_grid(d, resident_blocks(attn_bwd_kernel<N, P, NBV, WV, DX, AV>, 64 * H * WV, sh), WV);                                  \
     hipLaunchKernelGGL((attn_bwd_kernel<N, P, NBV, WV, DX, AV>), dim3(G), block, sh, st, x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, \
-                       av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                                     \
+                       av_saved, rstd_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps);                         \
   }
 // (the attention_dim == 16 form -- one 16-byte access per row piece, no column masks -- exists for the large-F instantiations, where
 // the per-block prologue is a measurable part of the kernel; small shapes take the general form)
@@ -1408,8 +1415,8 @@ namespace fil {
 static long long* g_attn_stamps = nullptr;
 
 static int launch_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma, const float* beta,
-                      float* y, float* res_out, float* av_out, const AttnDims& d, float scale, float eps, int fuse_relu,
-                      bool f16, hipStream_t st) {
+                      float* y, float* res_out, float* av_out, float* rstd_out, const AttnDims& d, float scale, float eps,
+                      int fuse_relu, bool f16, hipStream_t st) {
   const size_t sh = fwd_lds(d, f16);
   if (sh > kLdsCap) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_fwd: F=%d K=%d H=%d needs %zu bytes of LDS (> 160 KiB)", d.F, d.K, d.H, sh);
   const dim3 grid(d.B), block(64 * d.H);
@@ -1417,8 +1424,8 @@ static int launch_fwd(const float* x, const float* Wq, const float* Wk, const fl
 #define CALL_FWD_A(N, P, AV)                                                                                                  \
   rc = allow_lds_attn(attn_fwd_kernel<N, P, AV>, sh);                                                                         \
   if (rc == FIL_OK)                                                                                                           \
-    hipLaunchKernelGGL((attn_fwd_kernel<N, P, AV>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, d,  \
-                       scale, eps, fuse_relu)
+    hipLaunchKernelGGL((attn_fwd_kernel<N, P, AV>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out,     \
+                       rstd_out, d, scale, eps, fuse_relu)
 #define CALL_FWD(N, P) \
   if (d.A == 16) { CALL_FWD_A(N, P, true); } else { CALL_FWD_A(N, P, false); }
   FIL_ATTN_NC(d.NC, CALL_FWD)
@@ -1446,8 +1453,8 @@ extern "C" size_t fil_attn_bwd_workspace_bytes(int B, int F, int K, int H, int A
 }
 
 extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
-                            const float* beta, float* y, float* res_out, float* av_out, int B, int F, int K, int H, int A,
-                            float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
+                            const float* beta, float* y, float* res_out, float* av_out, float* rstd_out, int B, int F, int K,
+                            int H, int A, float scale, float eps, int fuse_relu, int precision, int x_chunk, void* workspace,
                             size_t workspace_bytes, void* stream) {
   (void)workspace; (void)workspace_bytes;
   AttnDims d;
@@ -1458,16 +1465,17 @@ extern "C" int fil_attn_fwd(const float* x, const float* Wq, const float* Wk, co
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && Wq && Wk && y);
   FIL_CHECK_ARG((gamma == nullptr) == (beta == nullptr));
+  FIL_CHECK_ARG((av_out == nullptr) == (rstd_out == nullptr));   // kept together or not at all
   hipStream_t st = (hipStream_t)stream;
   // algorithmic flops: projections 2*F*K*A*(2 or 3) + scores and weighted sum 2*2*F*F*A, per (b,h)
   ProfScope ps("attn_fwd", st, (double)B * H * (2.0 * F * K * A * (Wr ? 3 : 2) + 4.0 * F * (double)F * A));
-  return launch_fwd(x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, d, scale, eps, fuse_relu, f16, st);
+  return launch_fwd(x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out, rstd_out, d, scale, eps, fuse_relu, f16, st);
 }
 
 extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma,
                             const float* beta, const float* dy, const float* dres_in, const float* y_saved,
-                            const float* av_saved, float* dx, float* dWq, float* dWk, float* dWr, float* dgamma, float* dbeta,
-                            int B, int F, int K, int H, int A, float scale, float eps, int fuse_relu, int precision,
+                            const float* av_saved, const float* rstd_saved, float* dx, float* dWq, float* dWk, float* dWr,
+                            float* dgamma, float* dbeta, int B, int F, int K, int H, int A, float scale, float eps, int fuse_relu, int precision,
                             int x_chunk, void* workspace, size_t workspace_bytes, void* stream) {
   AttnDims d;
   int rc = make_dims("fil_attn_bwd", B, F, K, H, A, x_chunk, d);
@@ -1478,6 +1486,7 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
   FIL_CHECK_ARG((gamma == nullptr) == (beta == nullptr));
   FIL_CHECK_ARG(gamma == nullptr || (dgamma && dbeta));
   FIL_CHECK_ARG(Wr == nullptr || dWr != nullptr);
+  FIL_CHECK_ARG((av_saved == nullptr) == (rstd_saved == nullptr));
   hipStream_t st = (hipStream_t)stream;
   const size_t wsz = (size_t)K * H * A * sizeof(float);
   if (B == 0) {
@@ -1541,16 +1550,21 @@ extern "C" int fil_attn_bwd(const float* x, const float* Wq, const float* Wk, co
     float* av_ws = ws.take<float>(nact);
     float* y_ws = ws.take<float>(nact);
     ProfScope ps("attn_bwd_recompute", st, (double)B * H * (2.0 * F * K * A * 3 + 4.0 * F * (double)F * A));
-    rc = launch_fwd(x, Wq, Wk, Wr, gamma, beta, y_ws, nullptr, need_av ? av_ws : nullptr, d, scale, eps, fuse_relu, f16, st);
+    float* rstd_ws = ws.take<float>((size_t)H * B * F);
+    rc = launch_fwd(x, Wq, Wk, Wr, gamma, beta, y_ws, nullptr, need_av ? av_ws : nullptr, need_av ? rstd_ws : nullptr, d, scale, eps,
+                    fuse_relu, f16, st);
     if (rc != FIL_OK) return rc;
-    if (need_av) av_saved = av_ws;
+    if (need_av) {
+      av_saved = av_ws;
+      rstd_saved = rstd_ws;
+    }
     if (need_y) y_saved = y_ws;
   }
   {
     // algorithmic flops of the score pass: S, dS, dq, 2 x dk = 5 products of 2*F*F*A, plus projections and their gradients
     ProfScope ps("attn_bwd", st, (double)B * H * (10.0 * F * (double)F * A + 2.0 * F * K * A * (has_res ? 9 : 7)));
     int lrc = FIL_OK;
-    const AttnBwdLaunch la{x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, av_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps,
+    const AttnBwdLaunch la{x, Wq, Wk, Wr, gamma, dy, dres_in, y_saved, av_saved, rstd_saved, dx, wpart, gb_part, d, scale, eps, fuse_relu, g_attn_stamps,
                            wph, dx_lds, sh, st};
     lrc = f16 ? attn_launch_bwd_f16(la, &G) : attn_launch_bwd_f32(la, &G);
     if (lrc != FIL_OK) return fail(lrc, "fil_attn_bwd: cannot reserve %zu bytes of LDS", sh);

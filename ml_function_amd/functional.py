@@ -311,17 +311,20 @@ class _AttnFn(torch.autograd.Function):
         res = None
         if not fuse_relu and Wr is not None:
             res = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
-        # av (attention output before LayerNorm) is kept for the backward's LayerNorm gradient (H*B*F*A floats);
-        # FIL_ATTN_SAVE_AV=0 drops it and makes the backward re-run the forward into its workspace instead
-        av = None
+        # the LayerNorm input is kept for the backward's LayerNorm gradient, normalised, with the rows' 1/sigma beside it
+        # (H*B*F*(A+1) floats: the backward does not derive the statistics again); FIL_ATTN_SAVE_AV=0 drops both and makes the
+        # backward re-run the forward into its workspace instead
+        av = rstd = None
         if gamma is not None and _SAVE_AV:
             av = torch.empty((H, B, F, A), dtype=torch.float32, device=x.device)
-        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), ptr(av), B, F, K, H, A,
+            rstd = torch.empty((H, B, F), dtype=torch.float32, device=x.device)
+        check(lib.fil_attn_fwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(y), ptr(res), ptr(av), ptr(rstd),
+                               B, F, K, H, A,
                                float(scale), float(eps), int(bool(fuse_relu)), int(precision), x_chunk, None, 0, stream_ptr()),
               "fil_attn_fwd")
         keep_y = bool(fuse_relu) and (av is not None or gamma is None)   # the fused ReLU mask is y > 0
         ctx.save_for_backward(x, Wq, Wk, *[t for t in (Wr, gamma, beta) if t is not None],
-                              *([av] if av is not None else []), *([y] if keep_y else []))
+                              *([av, rstd] if av is not None else []), *([y] if keep_y else []))
         ctx.extra = (av is not None, keep_y)
         ctx.cfg = (Wr is not None, gamma is not None, float(scale), float(eps), bool(fuse_relu), int(precision), x_chunk,
                    (B, F, K))
@@ -342,6 +345,7 @@ class _AttnFn(torch.autograd.Function):
         beta = rest.pop(0) if has_ln else None
         has_av, has_y = ctx.extra
         av_saved = rest.pop(0) if has_av else None
+        rstd_saved = rest.pop(0) if has_av else None
         y_saved = rest.pop(0) if has_y else None
         _, H, A = Wq.shape
         lib = _lib.load()
@@ -358,7 +362,7 @@ class _AttnFn(torch.autograd.Function):
         nws = lib.fil_attn_bwd_workspace_bytes(B, F, K, H, A, have_saved)
         ws = _scratch(nws, x.device, "attn_bwd")
         check(lib.fil_attn_bwd(ptr(x), ptr(Wq), ptr(Wk), ptr(Wr), ptr(gamma), ptr(beta), ptr(dy), ptr(dres_in), ptr(y_saved),
-                               ptr(av_saved), ptr(dx),
+                               ptr(av_saved), ptr(rstd_saved), ptr(dx),
                                ptr(dWq), ptr(dWk), ptr(dWr), ptr(dgamma), ptr(dbeta), B, F, K, H, A, scale, eps,
                                int(fuse_relu), precision, x_chunk, ptr(ws), nws, stream_ptr()), "fil_attn_bwd")
         return dx, dWq, dWk, dWr, dgamma, dbeta, None, None, None, None, None

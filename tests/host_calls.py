@@ -67,13 +67,13 @@ def run(lib):
     assert lib.fil_cin_grad_ready_points(4096, 39, 16, 3, H3, 0, None) == -1
     assert lib.fil_cin_grad_ready_points(4096, 65, 16, 3, H3, 0, pts) == -4
     # attention
-    nul9 = [None] * 9
+    nul9 = [None] * 10
     expect(lib.fil_attn_fwd(*nul9, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, 0, None, 0, None), -4)
     expect(lib.fil_attn_fwd(*nul9, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, 0, None, 0, None), -1)
     expect(lib.fil_attn_fwd(*nul9, 4, 200, 64, 4, 16, 0.25, 1e-3, 1, 0, 24, None, 0, None), -1)
     expect(lib.fil_attn_fwd(*nul9, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -4)
     expect(lib.fil_attn_fwd(*nul9, 4, 600, 16, 4, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -4, b"512")
-    expect(lib.fil_attn_bwd(*([None] * 16), 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -1)
+    expect(lib.fil_attn_bwd(*([None] * 17), 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -1)
     small = lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 1)
     assert 0 < small < 1 << 20 and lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 0) >= small + 2 * 4 * 16 * 200 * 16 * 4
     assert lib.fil_attn_bwd_workspace_bytes(0, 200, 16, 4, 16, 1) == 0

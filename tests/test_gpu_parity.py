@@ -929,22 +929,24 @@ def test_attn_at_the_benchmark_shape(precision, kink_free):
     assert not bad, bad
 
 
-def test_attn_backward_without_saved_tensors():
-    """fil_attn_bwd with av_saved = y_saved = NULL re-runs the forward into its workspace: same gradients, bit for bit."""
+@pytest.mark.parametrize("shape,precision", [((5, 39, 16, 3, 8), "f32"), ((3, 230, 64, 4, 16), "f16_mfma"), ((4, 200, 16, 4, 16), "f16_mfma")])
+def test_attn_backward_without_saved_tensors(shape, precision):
+    """fil_attn_bwd with av_saved = rstd_saved = y_saved = NULL re-runs the forward into its workspace: same gradients, bit for bit."""
     from ml_function_amd import functional as Fn
-    c = synth.attn_case(5, 39, 16, 3, 8, dist="normal")
+    c = synth.attn_case(*shape, dist="normal")
     res = []
+    old = Fn._SAVE_AV
     for save in (True, False):
-        old = Fn._SAVE_AV
         Fn._SAVE_AV = save
         try:
             t = {n: dev(c[n]).requires_grad_() for n in ["x", "Wq", "Wk", "Wr", "gamma", "beta"]}
-            Fn.autoint_interact(t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"]).backward(dev(c["dy"]))
+            Fn.autoint_interact(t["x"], t["Wq"], t["Wk"], t["Wr"], t["gamma"], t["beta"], precision=precision).backward(dev(c["dy"]))
             res.append([t[n].grad for n in t])
         finally:
             Fn._SAVE_AV = old
-    for a, b2 in zip(*res):
-        assert torch.equal(a, b2)
+    for other in res[1:]:
+        for a, b2 in zip(res[0], other):
+            assert torch.equal(a, b2)
 
 
 def test_attn_repeatable_and_batch_independent():

@@ -43,12 +43,12 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 9, H, 1, 0, None, 0, None) == -4
     Hbig = _lib.int_array([300])
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 1, Hbig, 1, 0, None, 0, None) == -4
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 32, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
     # unknown precision code
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, 0, None, 0, None) == -1
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, None, 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 7, 0, None, 0, None) == -1
     # head-major input: the chunk width must divide K; more than 8 heads is outside the one-wave-per-head design
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 64, 4, 16, 0.25, 1e-3, 1, 0, 24, None, 0, None) == -1
-    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, None, 4, 200, 64, 4, 16, 0.25, 1e-3, 1, 0, 24, None, 0, None) == -1
+    assert lib.fil_attn_fwd(None, None, None, None, None, None, None, None, None, None, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None) == -4
 
 
 def test_every_entry_point_validates_its_arguments(lib):
