@@ -106,7 +106,7 @@ def deepfm_benchmark(args):
     gather, FM layer on bf16 embeddings, MLP under bf16 autocast, softmax head, BCE, backward incl. the embedding
     scatter-add).  xdeepfm = the north-star layer inside its model (models.XDeepFM: linear + CIN 3x128 + 256-128-64 MLP,
     fp32).  Eager and replayed from a HIP graph."""
-    from ml_function_amd import models
+    from ml_function_amd import losses, models
     dev = torch.device("cuda", 0)
     B = args.batch or 4096
     rng = np.random.default_rng(2020)
@@ -141,7 +141,7 @@ def deepfm_benchmark(args):
         for p in params:
             p.grad = None
         out = model(dense, idx)
-        torch.nn.functional.binary_cross_entropy(out[:, -1].clamp(1e-6, 1 - 1e-6), y).backward()
+        losses.binary_crossentropy(out[:, -1], y, eps=1e-6).backward()
 
     for _ in range(args.warmup):
         step()

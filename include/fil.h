@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 212
+#define FIL_ABI_VERSION 213
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -242,6 +242,21 @@ int fil_embed_sort_fields(const int64_t* offsets, const int64_t* sizes, const un
 /* the same sums without any data-dependent size (HIP-graph capturable): sorted_ids [R] = the stably sorted row ids, perm [R]
  * the sorting permutation; the run of every distinct id >= 0 is summed in sorted order into the (pre-zeroed) dense dtable. */
 int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * N2  The score head and the loss behind the interaction layers (all tensors fp32, n = batch rows).
+ *   ScoreLayer(use_add=True).call (kon/model/ctr_model/layer/core_layer/core_layer.py:58-84): keras Add over the [B,1] parts,
+ *   then sigmoid.  fil_score_add_sigmoid_fwd: out[i] = sigmoid(((a[i] + b[i]) + c[i]) + d[i]) -- left to right like the
+ *   reference's Add; b, c, d may be NULL.  _bwd: dsum[i] = dout[i] * out[i] * (1 - out[i]), the gradient of EVERY part.
+ *   fil_bce_mean_fwd: binary cross-entropy on probabilities as the reference compiles it (example/ctr_example/un_seq.py:61,
+ *   model.compile(loss=tf.losses.binary_crossentropy); TensorFlow 2.1 keras/backend.py): pc = clip(p, eps, 1 - eps),
+ *   loss[0] = mean(-(y log(pc + eps) + (1 - y) log(1 - pc + eps))); dp (may be NULL) [n] = d loss / d p (0 where the clip is
+ *   active).  Keras' eps is 1e-7.  One workgroup, fixed summation order: repeats are
+ *   bit-identical.  Meant for training batches (n up to ~1e5); n >= 1.
+ */
+int fil_score_add_sigmoid_fwd(const float* a, const float* b, const float* c, const float* d, float* out, int n, void* stream);
+int fil_score_add_sigmoid_bwd(const float* out, const float* dout, float* dsum, int n, void* stream);
+int fil_bce_mean_fwd(const float* p, const float* y, float eps, float* loss, float* dp, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -479,6 +479,70 @@ def product_attention(q, k, v, use_scale=False, mask=None, mask_mod=1):
 _SORT_CACHE = []
 
 
+class _ScoreAddSigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *parts):
+        _require_cuda(*parts)
+        shape = parts[0].shape
+        parts = [_f32c(t) for t in parts]
+        n = parts[0].numel()
+        out = torch.empty(shape, dtype=torch.float32, device=parts[0].device)
+        pp = [ptr(t) for t in parts] + [None] * (4 - len(parts))
+        check(_lib.load().fil_score_add_sigmoid_fwd(*pp, ptr(out), n, stream_ptr()), "fil_score_add_sigmoid_fwd")
+        ctx.save_for_backward(out)
+        ctx.n_parts = len(parts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = _f32c(g)
+        dsum = torch.empty_like(out)
+        check(_lib.load().fil_score_add_sigmoid_bwd(ptr(out), ptr(g), ptr(dsum), out.numel(), stream_ptr()),
+              "fil_score_add_sigmoid_bwd")
+        return (dsum,) * ctx.n_parts
+
+
+def score_add_sigmoid(parts):
+    """sigmoid(((p0 + p1) + p2) + p3) over 1..4 fp32 tensors of ONE shape (ScoreLayer(use_add=True), core_layer.py:58-84): one launch
+    forward, one backward (every part receives the same gradient tensor)."""
+    parts = list(parts)
+    if not 1 <= len(parts) <= 4:
+        raise FilError("score_add_sigmoid takes 1..4 parts, got %d" % len(parts))
+    if any(t.shape != parts[0].shape for t in parts):
+        raise FilError("score_add_sigmoid: the parts must have one shape, got %s" % [tuple(t.shape) for t in parts])
+    return _ScoreAddSigmoidFn.apply(*parts)
+
+
+class _BceMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, y, eps):
+        _require_cuda(p, y)
+        if p.shape != y.shape:
+            raise FilError("binary_crossentropy: p is %s, y is %s" % (tuple(p.shape), tuple(y.shape)))
+        p, y = _f32c(p), _f32c(y)
+        if p.numel() == 0:
+            raise FilError("binary_crossentropy of an empty batch")
+        loss = torch.empty((1,), dtype=torch.float32, device=p.device)
+        dp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        check(_lib.load().fil_bce_mean_fwd(ptr(p), ptr(y), float(eps), ptr(loss), ptr(dp), p.numel(), stream_ptr()), "fil_bce_mean_fwd")
+        if dp is not None:
+            ctx.save_for_backward(dp)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g, None, None
+
+
+def binary_crossentropy(p, y, eps=1e-7):
+    """mean(-(y log(pc + eps) + (1 - y) log(1 - pc + eps))), pc = clip(p, eps, 1 - eps): tf.losses.binary_crossentropy on
+    probabilities as TensorFlow 2.1 computes it (the reference compiles its CTR models with it, example/ctr_example/un_seq.py:61;
+    eps = the Keras backend epsilon), as one launch that also leaves d loss / d p; deterministic."""
+    return _BceMeanFn.apply(p, y, eps)
+
+
 def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None, per_field=False):
     """layout_key: a hashable description of (offsets, sizes, frozen) -- two tables with the same field layout (SparseEmbed
     passes its word sizes / frozen flags) share the sort even though their offset tensors are different objects."""

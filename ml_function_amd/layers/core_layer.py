@@ -6,6 +6,7 @@ import warnings
 
 import torch
 
+from .. import functional as F
 from .base import Layer, merge_packed_views, glorot_uniform_
 from .behavior_layer import MultHeadAttentionLayer
 from .interactive_layer import InnerLayer
@@ -92,6 +93,11 @@ class ScoreLayer(Layer):
         super().build(input_shape)
 
     def call(self, inputs, **kwargs):
+        if self.use_add and not self.use_global and not self.use_inner:
+            parts = list(inputs)
+            # the common head (xDeepFM, NFM-style sums of [B,1] scores): Add + sigmoid as ONE launch each way
+            if (1 <= len(parts) <= 4 and all(t.is_cuda and t.dtype == torch.float32 and t.shape == parts[0].shape for t in parts)):
+                return F.score_add_sigmoid(parts)
         if self.use_add:
             inputs = keras_add(list(inputs))
             if self.use_global:

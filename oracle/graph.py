@@ -223,3 +223,27 @@ def attention_base_layer(inputs, kernel_w, kernel_b, mlp_kernel, out_w, out_b):
     score_w = torch.softmax(score_, dim=-1)
     atten_inputs = torch.sum(score_w * x, dim=1)
     return torch.matmul(atten_inputs, out_w) + out_b
+
+
+# --------------------------------------------------------------------------- score head and loss (N2)
+def score_layer(inputs, use_add=True):
+    """ScoreLayer.call, core_layer/core_layer.py:58-84 (use_inner=False, use_global=False): keras Add over the inputs when
+    use_add, then tf.sigmoid."""
+    x = keras_add(list(inputs)) if use_add else inputs
+    return torch.sigmoid(x)
+
+
+def binary_crossentropy(y_true, y_pred, eps=1e-7):
+    """tf.losses.binary_crossentropy on probabilities, the loss the reference compiles its CTR models with
+    (example/ctr_example/un_seq.py:61).  TensorFlow is a third-party dependency absent from /root/reference (README badge:
+    tensorflow v2.1); restated from TF 2.1 keras/backend.py binary_crossentropy(from_logits=False):
+        output = clip_by_value(output, eps, 1 - eps);  bce = -(target log(output + eps) + (1 - target) log(1 - output + eps))
+    then the mean over the batch.  (In graph mode TF 2.1 short-cuts an output that comes straight from a Sigmoid op to
+    sigmoid_cross_entropy_with_logits -- the same function of the logits without the clip; the clipped form is what runs on
+    probabilities, e.g. the softmax head's column.)  The clip bounds are rounded to the dtype of y_pred's SOURCE (fp32) as TF
+    rounds them."""
+    lo = float(torch.tensor(eps, dtype=torch.float32))
+    hi = float(torch.tensor(1.0, dtype=torch.float32) - torch.tensor(eps, dtype=torch.float32))
+    out = torch.clamp(y_pred, lo, hi)
+    bce = -(y_true * torch.log(out + eps) + (1 - y_true) * torch.log(1 - out + eps))
+    return bce.mean()

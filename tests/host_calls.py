@@ -74,6 +74,11 @@ def run(lib):
     expect(lib.fil_attn_fwd(*nul9, 4, 200, 16, 9, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -4)
     expect(lib.fil_attn_fwd(*nul9, 4, 600, 16, 4, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -4, b"512")
     expect(lib.fil_attn_bwd(*([None] * 17), 4, 200, 16, 4, 16, 0.25, 1e-3, 1, 0, 0, None, 0, None), -1)
+    expect(lib.fil_score_add_sigmoid_fwd(None, None, None, None, None, 4, None), -1, b"bad argument")
+    expect(lib.fil_score_add_sigmoid_fwd(None, None, None, None, None, 0, None), 0)
+    expect(lib.fil_score_add_sigmoid_bwd(None, None, None, 4, None), -1)
+    expect(lib.fil_bce_mean_fwd(None, None, 1e-7, None, None, 0, None), -1)
+    expect(lib.fil_bce_mean_fwd(None, None, 0.7, None, None, 8, None), -1, b"eps")
     small = lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 1)
     assert 0 < small < 1 << 20 and lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 0) >= small + 2 * 4 * 16 * 200 * 16 * 4
     assert lib.fil_attn_bwd_workspace_bytes(0, 200, 16, 4, 16, 1) == 0

@@ -1255,3 +1255,67 @@ def test_embed_gather_xt_and_cin_transposed_input():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------------------------- score head and loss (N2)
+@pytest.mark.parametrize("n_parts,shape", [(1, (7, 1)), (2, (333, 1)), (3, (4096, 1)), (4, (1000,)), (3, (65537, 1))])
+def test_score_add_sigmoid_matches_the_oracle(n_parts, shape):
+    """ScoreLayer(use_add=True): Add over the parts + sigmoid as one launch each way, against the fp64 graph under autograd."""
+    from oracle import graph
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(7 + n_parts)
+    parts = [(3.0 * rng.standard_normal(shape)).astype(np.float32) for _ in range(n_parts)]
+    g = rng.standard_normal(shape).astype(np.float32)
+    tp = [torch.tensor(p, dtype=torch.float64, requires_grad=True) for p in parts]
+    want = graph.score_layer(tp, use_add=True)
+    want.backward(torch.tensor(g, dtype=torch.float64))
+    dp = [dev(p).requires_grad_() for p in parts]
+    got = Fn.score_add_sigmoid(dp)
+    got.backward(dev(g))
+    assert got.shape == tuple(shape)
+    check("score", got, want.detach().numpy(), 2e-6)
+    for i in range(n_parts):
+        check("dpart%d" % i, dp[i].grad, tp[i].grad.numpy(), 2e-6)
+
+
+def test_score_layer_takes_the_fused_head_and_agrees_with_the_torch_path():
+    from ml_function_amd import layers
+    rng = np.random.default_rng(11)
+    parts = [dev(rng.standard_normal((512, 1))) for _ in range(3)]
+    fused = layers.ScoreLayer(use_add=True)(parts)
+    plain = torch.sigmoid((parts[0] + parts[1]) + parts[2])
+    assert torch.allclose(fused, plain, rtol=0, atol=2e-7)
+    # shapes that broadcast (a [B,1] part against a [1] bias) keep the general path
+    assert layers.ScoreLayer(use_add=True)([parts[0], dev(np.ones(1))]).shape == (512, 1)
+    with pytest.raises(Exception):
+        from ml_function_amd import functional as Fn
+        Fn.score_add_sigmoid([torch.zeros(4, 1)])          # a CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("n,eps", [(1, 1e-7), (5, 1e-7), (4096, 1e-7), (4096, 1e-6), (100003, 1e-7)])
+def test_binary_crossentropy_matches_the_oracle(n, eps):
+    """tf.losses.binary_crossentropy on probabilities (clip, log(p + eps), mean) and its gradient, incl. saturated entries where the
+    clip is active (zero gradient); repeats are bit-identical."""
+    from oracle import graph
+    from ml_function_amd import losses
+    rng = np.random.default_rng(n)
+    p = rng.uniform(0.001, 0.999, n).astype(np.float32)
+    if n >= 5:
+        p[:4] = [0.0, 1.0, 1e-9, 0.99999999]
+    y = rng.integers(0, 2, n).astype(np.float32)
+    tp = torch.tensor(p, dtype=torch.float64, requires_grad=True)
+    want = graph.binary_crossentropy(torch.tensor(y, dtype=torch.float64), tp, eps)
+    want.backward()
+    dpv = dev(p).requires_grad_()
+    got = losses.binary_crossentropy(dpv, dev(y), eps=eps)
+    (2.0 * got).backward()
+    assert got.shape == ()
+    check("loss", got.reshape(1), want.detach().numpy().reshape(1), 1e-5)
+    inside = (p >= np.float32(eps)) & (p <= np.float32(1) - np.float32(eps))
+    gw = 2.0 * tp.grad.numpy()
+    ga = dpv.grad.cpu().numpy().astype(np.float64)
+    assert np.all(ga[~inside] == 0.0)
+    scale = np.abs(gw[inside]).max() if inside.any() else 1.0
+    assert np.abs(ga[inside] - gw[inside]).max() <= 1e-5 * scale
+    again = losses.binary_crossentropy(dev(p), dev(y), eps=eps)
+    assert torch.equal(again, got.detach())
