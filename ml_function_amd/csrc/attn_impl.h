@@ -716,6 +716,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   } else {
     wt.init(Wq, Wk, Wr, d);
   }
+  // XFIX (K = 64, two waves per head, four heads: eight dx jobs per step on eight waves): wave w always takes job w -- block
+  // 2 st + w / 4, chunk w % 4 -- so the eight weight fragments of its chunk stay in registers instead of being read from the LDS
+  // table in every step (rotating the owner spreads nothing when every wave has exactly one job)
+  // (only where the sixteen registers exist: the attention_dim == 16, NB = 13 instantiation -- the c5 stack's -- has them; the general
+  // column-masked form and NB = 32 spill 17-50 more)
+  constexpr bool XFIX = F16 && DXL && WPH == 2 && NC == 4 && A16 && NB <= 13;
+  const bool xfix = XFIX && NH == 4;
+  Op xwq[4], xwr[4];
+  if constexpr (XFIX) {
+    lds_barrier();   // the weight table is complete
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      xwq[hh] = wt.arole(0, xfix ? hh : 0, w & 3, lane);
+      xwr[hh] = wt.arole(2, xfix ? hh : 0, w & 3, lane);
+    }
+  }
   // dx of the sample being processed, fp32 [NC][FP][16] (chunk-major like the head-major global layout), when the footprint
   // allows (dx_lds): the heads' dq / dres parts are summed into it block by block, the dk part is added after the block loop,
   // and it leaves once, as whole 1-KB rows.  Without it the dq part goes to global memory and is read back for the dk part
@@ -954,6 +970,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     // spread over the waves.
     auto phase_x = [&](const int st, const int rotw) __attribute__((always_inline)) {
       const int par = st & 1;
+      if constexpr (XFIX) {
+        if (xfix) {
+          const int qs_ = w >> 2, cc = w & 3, bi = st * WPH + qs_;
+          if (bi < d.nblk) {
+            f32x4 px = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+              const Elem* th = tiles0 + ((hh * WPH + qs_) * 6 + 2 + 2 * par) * TS;
+              px = mma<F16>(xwq[hh], row_read<F16>(th, c, g), px);
+              if (has_res) px = mma<F16>(xwr[hh], row_read<F16>(th + TS, c, g), px);
+            }
+            *reinterpret_cast<f32x4*>(dxs + (cc * d.FP + 16 * bi + c) * 16 + 4 * g) = px;
+          }
+          return;
+        }
+      }
       for (int q = w >= rotw ? w - rotw : w - rotw + nw; q < WPH * NC; q += nw) {
         const int qs_ = q / NC, cc = q - qs_ * NC, bi = st * WPH + qs_;
         if (bi < d.nblk) {
@@ -1061,6 +1093,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
         // Two jobs per pass, interleaved: a job is a chain of LDS read -> H dependent products -> store, and a wave has 6-7 of them;
         // the second job of the last pass repeats the first and is not stored)
         const bool vecx = (d.xcw & 3) == 0 && (d.K & 3) == 0;
+        // (with XFIX every job of a wave is chunk w % 4 here too; keeping its four Wk fragments in registers as well was measured:
+        // 3 spilled registers, 535 -> 547 us)
         for (int q = w; q < njobs; q += 2 * nw) {
           const bool two = q + nw < njobs;
           const int qB = two ? q + nw : q;
