@@ -490,7 +490,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // ================================================================================================= forward
 // grid = B, block = 64 H.  y[h,b,f,a] = fuse_relu ? relu(res + ln) : ln ; res_out (optional, !fuse_relu) = x Wr
-template <int NC, bool F16, bool A16>
+// KR > 0 (f16 mode, at most KR key tiles): the head's k fragments live in REGISTERS, in both orientations -- the projection's
+// transposed product D[a][f] IS the row fragment of a k tile, the product with the operands swapped is its column fragment
+// (as the backward does for q) -- 4 KR registers instead of an LDS image that every query block re-reads tile by tile: two of a
+// tile's ~21 instructions and both of its LDS waits are gone (the kernel has the registers: 44-74 of 512 / waves).
+template <int NC, bool F16, bool A16, int KR = 0>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wq,
                                                         const float* __restrict__ Wk, const float* __restrict__ Wr,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -504,14 +508,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
   const int c = lane & 15, g = lane >> 4;
-  Elem* kimg;
+  static_assert(KR == 0 || F16, "register k fragments are an f16-mode form");
+  Elem* kimg = nullptr;
   XSrc<F16, F16> xsrc;
   if constexpr (F16) {
     _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);
     stage_x_f16<NC>(x, xs, d, b, blockDim.x);
     xsrc.xs = xs;
     xsrc.FP = d.FP;
-    kimg = xs + d.NC * d.FP * 16 + h * d.FP * RS;
+    if constexpr (KR == 0) kimg = xs + d.NC * d.FP * 16 + h * d.FP * RS;
     __syncthreads();
   } else {
     xsrc.init(x, d);
@@ -536,9 +541,27 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
       bet[s] = beta[4 * g + s];
     }
   }
-  project_k<NC, F16>(xsrc, kimg, wk, 0, 1, d.nblk, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  Op kRow[KR > 0 ? KR : 1], kCol[KR > 0 ? KR : 1];   // k[key c][a 4g..], k[key 4g..][a c] of tile t
+  if constexpr (KR > 0) {
+#pragma unroll
+    for (int t = 0; t < KR; ++t) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      if (t < d.nblk) {
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          const Op xr = xsrc.row(t, cc, lane);
+          a0 = mma<F16>(wk[cc], xr, a0);     // D[a 4g+r][key c]
+          a1 = mma<F16>(xr, wk[cc], a1);     // D[key 4g+r][a c]
+        }
+      }
+      kRow[t] = to_op<F16>(a0);
+      kCol[t] = to_op<F16>(a1);
+    }
+  } else {
+    project_k<NC, F16>(xsrc, kimg, wk, 0, 1, d.nblk, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 
   const float qs = -scale * 1.4426950408889634f;
   const long slab = ((long)h * d.B + b) * d.F * d.A;   // this (head, sample)'s [F][A] rows
@@ -569,8 +592,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     {
       auto fwd_tile = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int t = decltype(Tc)::value;
-        const Op kA = row_read<F16>(kimg, 16 * t + c, g);
-        const Op kT = tr_read<F16>(kimg, 16 * t, lane);
+        if constexpr (KR > 0 && t >= KR) return;      // (never reached: nblk <= KR)
+        Op kA, kT;
+        if constexpr (KR > 0) {
+          kA = kRow[t < KR ? t : 0];
+          kT = kCol[t < KR ? t : 0];
+        } else {
+          kA = row_read<F16>(kimg, 16 * t + c, g);
+          kT = tr_read<F16>(kimg, 16 * t, lane);
+        }
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
         sc = mma<F16>(kA, qn, sc);                                                  // [key 4g+r][query c], times -log2e*scale
         f32x4 sg;
@@ -1465,20 +1495,29 @@ static long long* g_attn_stamps = nullptr;
 static int launch_fwd(const float* x, const float* Wq, const float* Wk, const float* Wr, const float* gamma, const float* beta,
                       float* y, float* res_out, float* av_out, float* rstd_out, const AttnDims& d, float scale, float eps,
                       int fuse_relu, bool f16, hipStream_t st) {
-  const size_t sh = fwd_lds(d, f16);
+  // f16 mode, up to 13 key tiles: the k fragments live in registers (no k image in LDS; FIL_ATTN_KREG=0 keeps the image)
+  static const int kreg_knob = [] {
+    const char* e = getenv("FIL_ATTN_KREG");
+    return e != nullptr ? atoi(e) : 1;
+  }();
+  const bool kreg = f16 && d.nblk <= 13 && kreg_knob != 0;
+  const size_t sh = kreg ? (size_t)d.NC * d.FP * 16 * sizeof(_Float16) : fwd_lds(d, f16);
   if (sh > kLdsCap) return fail(FIL_ERR_UNSUPPORTED, "fil_attn_fwd: F=%d K=%d H=%d needs %zu bytes of LDS (> 160 KiB)", d.F, d.K, d.H, sh);
   const dim3 grid(d.B), block(64 * d.H);
   int rc = FIL_OK;
-#define CALL_FWD_A(N, P, AV)                                                                                                  \
-  rc = allow_lds_attn(attn_fwd_kernel<N, P, AV>, sh);                                                                         \
+#define CALL_FWD_K(...)                                                                                                       \
+  rc = allow_lds_attn(attn_fwd_kernel<__VA_ARGS__>, sh);                                                                      \
   if (rc == FIL_OK)                                                                                                           \
-    hipLaunchKernelGGL((attn_fwd_kernel<N, P, AV>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out,     \
+    hipLaunchKernelGGL((attn_fwd_kernel<__VA_ARGS__>), grid, block, sh, st, x, Wq, Wk, Wr, gamma, beta, y, res_out, av_out,  \
                        rstd_out, d, scale, eps, fuse_relu)
+#define CALL_FWD_A(N, P, AV) \
+  if (kreg) { CALL_FWD_K(N, P, AV, (P ? 13 : 0)); } else { CALL_FWD_K(N, P, AV, 0); }
 #define CALL_FWD(N, P) \
   if (d.A == 16) { CALL_FWD_A(N, P, true); } else { CALL_FWD_A(N, P, false); }
   FIL_ATTN_NC(d.NC, CALL_FWD)
 #undef CALL_FWD
 #undef CALL_FWD_A
+#undef CALL_FWD_K
   if (rc != FIL_OK) return fail(rc, "fil_attn_fwd: cannot reserve %zu bytes of LDS", sh);
   FIL_CHECK_LAUNCH();
   return FIL_OK;

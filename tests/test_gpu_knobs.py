@@ -22,3 +22,18 @@ def test_cin_parity_subset_with_one_knob_off(knob):
     tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-15:])
     assert r.returncode == 0, "%s=0:\n%s" % (knob, tail)
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["FIL_ATTN_KREG", "FIL_ATTN_DX_LDS"])
+def test_attn_parity_subset_with_one_knob_off(knob):
+    """The attention kernels' forms behind knobs: FIL_ATTN_KREG=0 = the forward with its k image in LDS at the shapes whose k fragments
+    fit registers (up to 13 key tiles, f16 mode), FIL_ATTN_DX_LDS=0 = the backward's dx part through global memory (second visit).
+    A fresh child runs the two-waves-per-head shapes (F = 170..300, both precisions) against the closed forms."""
+    env = dict(os.environ)
+    env[knob] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py::test_attn_two_waves_per_head", "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-15:])
+    assert r.returncode == 0, "%s=0:\n%s" % (knob, tail)
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
