@@ -509,6 +509,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
   const int c = lane & 15, g = lane >> 4;
   static_assert(KR == 0 || F16, "register k fragments are an f16-mode form");
+  // (several chunks: the weight fragments are requested first, their round trip to L2 runs under the staging of x -- K = 64 forward
+  // 187.4 -> 182.5 us; with one chunk the order made the kernel 1 % slower, 152.4 -> 154.2 us, and stays as it was)
+  Op wq[NC], wk[NC], wr[NC];
+  if constexpr (NC >= 2) {
+    load_w_kin<NC, F16>(Wq, h, d, lane, wq);
+    load_w_kin<NC, F16>(Wk, h, d, lane, wk);
+    load_w_kin<NC, F16>(Wr, h, d, lane, wr);
+  }
   Elem* kimg = nullptr;
   XSrc<F16, F16> xsrc;
   if constexpr (F16) {
@@ -523,10 +531,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     xsrc.set_sample(d, b);
     kimg = reinterpret_cast<float*>(smem_raw) + h * d.FP * RS;
   }
-  Op wq[NC], wk[NC], wr[NC];
-  load_w_kin<NC, F16>(Wq, h, d, lane, wq);
-  load_w_kin<NC, F16>(Wk, h, d, lane, wk);
-  load_w_kin<NC, F16>(Wr, h, d, lane, wr);
+  if constexpr (NC < 2) {
+    load_w_kin<NC, F16>(Wq, h, d, lane, wq);
+    load_w_kin<NC, F16>(Wk, h, d, lane, wk);
+    load_w_kin<NC, F16>(Wr, h, d, lane, wr);
+  }
   const bool use_ln = gamma != nullptr;
   SlabLane sl;
   sl.init(d.A, 4 * g);
