@@ -721,7 +721,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;   // == H * WPH
   const int NH = d.H;
-  const int h = w / WPH, sub = w % WPH;   // this wave's head; its query blocks are i = WPH * step + sub
+  // this wave's head; its query blocks are i = WPH * step + sub.  Two waves per head: wave w is (head w mod H, sub w / H), so that the
+  // two waves of a head share a SIMD (waves of a workgroup go to the SIMDs round robin, H = 4): when only the sub-0 waves have work
+  // -- the single-handed last step of an odd block count, each half of the dk merge -- every SIMD has ONE busy wave instead of two
+  // SIMDs having two and two having none (head-major numbering, w = 2 h + sub, did that)
+  const int sub = (WPH > 1 && w >= NH) ? 1 : 0, h = w - sub * NH;
+  auto wave_of = [&](const int hh, const int s_) __attribute__((always_inline)) { return WPH > 1 ? s_ * NH + hh : hh; };
   const int c = lane & 15, g = lane >> 4;
   unsigned char* sp = smem_raw;
   XSrc<F16, XL> xsrc;
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
             f32x4 px = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
-              const Elem* th = tiles0 + ((hh * WPH + qs_) * 6 + 2 + 2 * par) * TS;
+              const Elem* th = tiles0 + (wave_of(hh, qs_) * 6 + 2 + 2 * par) * TS;
               px = mma<F16>(xwq[hh], row_read<F16>(th, c, g), px);
               if (has_res) px = mma<F16>(xwr[hh], row_read<F16>(th + TS, c, g), px);
             }
@@ -1046,7 +1051,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
           // LDS access (and, after the block loop, one 16-byte global store) instead of four 4-byte ones
           f32x4 px = {0.f, 0.f, 0.f, 0.f};
           auto head_part = [&](const int hh) __attribute__((always_inline)) {
-            const Elem* th = tiles0 + ((hh * WPH + qs_) * 6 + 2 + 2 * par) * TS;
+            const Elem* th = tiles0 + (wave_of(hh, qs_) * 6 + 2 + 2 * par) * TS;
             if constexpr (DXL) {
               px = mma<F16>(wt.arole(0, hh, cc, lane), row_read<F16>(th, c, g), px);
               if (has_res) px = mma<F16>(wt.arole(2, hh, cc, lane), row_read<F16>(th + TS, c, g), px);

@@ -37,3 +37,17 @@ def test_attn_parity_subset_with_one_knob_off(knob):
     tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-15:])
     assert r.returncode == 0, "%s=0:\n%s" % (knob, tail)
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
+
+
+@pytest.mark.gpu
+def test_attn_two_waves_per_head_forced_on_fewer_heads():
+    """FIL_ATTN_WPH=2 forces the two-waves-per-head backward wherever there are more than 8 query blocks: test_attn_fused's
+    (2, 230, 16, 2, 16) then runs it with TWO heads (wave w = head w mod 2, sub w / 2), fp32 -- the strict bar -- with and without the
+    residual / LayerNorm branches; the shapes with up to 8 blocks keep one wave per head."""
+    env = dict(os.environ)
+    env["FIL_ATTN_WPH"] = "2"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py::test_attn_fused", "-x", "-q", "-m", "gpu", "-k", "230 or 200",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-15:])
+    assert r.returncode == 0, "FIL_ATTN_WPH=2:\n%s" % tail
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
