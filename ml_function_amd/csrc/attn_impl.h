@@ -1111,19 +1111,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FIL_ATTN_BW
     // ---- dk of this head: accumulators -> the (now dead) k image as row fragments [key][a]
     // (two waves per head: each holds the sum over its own query blocks; the second wave's part goes through the image)
     if constexpr (WPH > 1) {
-      if (sub == 1) {
+      // (the merge is split by key tile: wave `sub` hands its partner the tiles of the other parity, then adds the partner's part to
+      // its own tiles and leaves the sums in the image -- half the chain of 13 round trips per wave; one wave writing everything and
+      // the other reading, adding and writing everything back was 7 % of the K = 64 kernel)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
-      }
+      for (int j = 0; j < NB; ++j)
+        if (j < d.nblk && (j & 1) != sub) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
       lds_barrier();
-      if (sub == 0) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (j < d.nblk) dk[j] += from_op<F16>(row_read<F16>(kimg, 16 * j + c, g));
-      }
-    }
-    if (sub == 0) {
+      for (int j = 0; j < NB; ++j)
+        if (j < d.nblk && (j & 1) == sub) {
+          dk[j] += from_op<F16>(row_read<F16>(kimg, 16 * j + c, g));
+          row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
+        }
+    } else {
 #pragma unroll
       for (int j = 0; j < NB; ++j)
         if (j < d.nblk) row_write<F16>(kimg, 16 * j + c, g, to_op<F16>(dk[j]));
