@@ -12,11 +12,13 @@
 // tensors and (b) sigmoid passes; the matrix pipe is nowhere near busy.  Two kernels:
 //
 //   attn_fwd_kernel   one workgroup = one sample, one wave = one head.  x is staged once for all heads; the wave projects
-//                     its k (== v) into a private LDS image and walks the 16x16 score tiles:
+//                     its k (== v) -- into registers, both orientations, for up to 13 key tiles in the f16 mode, else into a
+//                     private LDS image -- and walks the 16x16 score tiles:
 //                         S'[key][query] = sigmoid(scale k_t q_i^T)      accumulator: key on (lane>>4, reg), query on lane&15
 //                         av^T[a][query] += k_t^T S'                     the S' accumulator IS the B operand, no LDS trip
 //                     av^T leaves the MFMA as [query on the lane][4 consecutive a] = one 16-byte store per lane, so y
-//                     and the saved av are written as whole 1-KB rows; LayerNorm + residual + ReLU in the epilogue.
+//                     and the saved rows are written as whole 1-KB rows; LayerNorm + residual + ReLU in the epilogue (the
+//                     rows kept for the backward are the NORMALISED ones, with their 1/sigma beside them).
 //   attn_bwd_kernel   ONE pass over the scores for the whole backward (the round-1 code made three).  Same
 //                     decomposition; the wave keeps dk of ALL its key tiles in accumulators (13 x 4 registers at F=200)
 //                     while it loops over the query blocks:
@@ -24,12 +26,12 @@
 //                         dk_t^T[a][key] += q_i^T dP + dav_i^T S          S and dP accumulators are the B operands
 //                         dq_i^T[a][query] += k_t^T dP^T                  dP crosses LDS once (8-byte write + transposing
 //                                                                         ds_read_b64_tr_b16 in the f16 mode)
-//                     The LayerNorm/ReLU backward (from the saved av and y) is the prologue of each query block, and
+//                     The LayerNorm/ReLU backward (from the saved normalised rows, 1/sigma and y) is the prologue of each query block, and
 //                     the projection gradients are folded in: dW* accumulate in registers across the samples of a
 //                     persistent workgroup, dx of the heads is summed in an LDS tile (fixed order) and written once.
 //                     HBM traffic: x, av, y, dy in; dx out -- no dav/dq/dk/dres round trips.  Where the LDS footprint
 //                     allows one workgroup per CU only (K = 64, the f32 mode at large F) a head gets TWO waves that take
-//                     alternate query blocks (WPH = 2; nothing is computed twice).
+//                     alternate query blocks (WPH = 2; nothing is computed twice; wave w = head w mod H, so the pair shares a SIMD).
 //
 // precision F32: every product on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains; 1e-5 parity mode), x fragments read from
 // global/L2.  F16_MFMA (BASELINE config 5): operands rounded to fp16 once when they enter LDS / registers, products on
