@@ -115,3 +115,29 @@ def test_independent_stream_runs_beside_the_compute_stream():
     torch.cuda.synchronize()
     assert start.elapsed_time(done) < 0.5 * start.elapsed_time(busy)      # the side work finished under the long compute kernel
     assert float(t.sum()) == float(2 << 20)
+
+
+def test_bench_line_accounting():
+    """bench.py's derived fields against each other (the dominant scope's record covers W + K launches, and dividing
+    it by K printed 1.25 launches per step and an executed fraction 8 % high): every GEMM scope runs once per step, the step's
+    executed flops are the three merged GEMM launches (2 * 65,536 rows * 780 pairs * 256 columns each, + 1 % for the shortcut columns),
+    and executed_frac / roofline.frac follow from the printed times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "3", "--windows", "2", "--no-side",
+                        "--no-cpu-baseline", "--no-graph-replay"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    gemms = {k: v for k, v in res["kernels"].items() if "executed_flops_per_launch" in v}
+    assert len(gemms) == 3 and all(abs(v["launches_per_step"] - 1.0) < 1e-9 for v in gemms.values()), gemms
+    per_gemm = 2.0 * 65536 * 780 * 256
+    assert 3 * per_gemm <= res["executed_flops_per_step"] <= 3 * per_gemm * 1.01
+    assert res["executed_flops_per_step"] == pytest.approx(sum(v["executed_flops_per_launch"] for v in gemms.values()), rel=1e-12)
+    assert res["executed_frac"] == pytest.approx(res["executed_flops_per_step"] / (res["ms_per_step"] * 1e-3) / (res["roofline"]["peak"] * 1e12), rel=1e-9)
+    rf = res["roofline"]
+    assert rf["frac"] == pytest.approx(rf["flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12 / rf["peak"], rel=1e-9)
+    assert rf["avg_launch_ms"] < res["ms_per_step"] and res["executed_frac"] < rf["frac"] + 0.1
+    assert res["value"] == pytest.approx(4096 / (res["ms_per_step"] * 1e-3), rel=1e-9)
