@@ -7,6 +7,8 @@ import ctypes
 
 import os
 
+import time
+
 import torch
 
 from . import _lib
@@ -37,6 +39,8 @@ def _workspace(nbytes, device):
 # allocator round trip per direction.  Under stream capture the cache is left alone (a block allocated there belongs to the graph's
 # private pool): the call allocates as before.
 _WS_CACHE = {}
+_WS_LAST_USE = {}      # (device, stream) -> monotonic time of the last _scratch() call on that stream
+_WS_IDLE_S = 2.0       # another stream's workspaces are dropped once that stream has not asked for scratch for this long
 
 
 def _scratch(nbytes, device, tag):
@@ -45,13 +49,18 @@ def _scratch(nbytes, device, tag):
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
     cur = stream_ptr()
     key = (device, cur, tag)
+    now = time.monotonic()
+    _WS_LAST_USE[(device, cur)] = now
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
-        # a (re)allocation is also the moment to let go of what OTHER streams of this device left behind: warm-up side streams
+        # a (re)allocation is also the moment to let go of what IDLE streams of this device left behind: warm-up side streams
         # (capture_step, bench.py) would otherwise keep hundreds of MB at headline shapes alive for good, invisible to
-        # torch.cuda.empty_cache().  Work still queued on such a stream keeps its bytes: the caching allocator does not hand a
-        # block out again before the stream it was allocated on has passed the free.
-        for k in [k for k in _WS_CACHE if k[0] == device and k[1] != cur]:
+        # torch.cuda.empty_cache().  A stream that is still in use (two model replicas on two streams, a side-stream warm-up
+        # followed by main-stream eager steps) keeps its workspaces: only streams that have not asked for scratch for _WS_IDLE_S
+        # are evicted, so two live streams no longer free each other's hot buffers on every call.  Work still queued on an
+        # evicted stream keeps its bytes: the caching allocator does not hand a block out again before the stream it was
+        # allocated on has passed the free.
+        for k in [k for k in _WS_CACHE if k[0] == device and k[1] != cur and now - _WS_LAST_USE.get((k[0], k[1]), 0.0) > _WS_IDLE_S]:
             del _WS_CACHE[k]
         ws = _WS_CACHE[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws
@@ -60,6 +69,7 @@ def _scratch(nbytes, device, tag):
 def release_scratch():
     """Drop every cached scratch workspace (they are re-created on demand)."""
     _WS_CACHE.clear()
+    _WS_LAST_USE.clear()
 
 
 # --------------------------------------------------------------------------------------------- A1  FM
@@ -543,6 +553,31 @@ def binary_crossentropy(p, y, eps=1e-7):
     return _BceMeanFn.apply(p, y, eps)
 
 
+_DISJOINT_CACHE = {}
+
+
+def _fields_disjoint(offsets, sizes, layout_key):
+    """True when every field owns its own row range of the concatenated table: offsets ascending and offsets[f] + sizes[f] <=
+    offsets[f + 1].  Only then are equal row ids adjacent after a PER-FIELD sort; two fields that share or overlap a table
+    (offsets[f] == offsets[g], or no `sizes` to bound the ids) put one row into two runs, and fil_embed_run_sum STORES each run's sum
+    -- one would overwrite the other.  Such layouts keep the global sort.  Checked once per layout (one small device -> host copy),
+    never during a stream capture (an unchecked layout then takes the global sort)."""
+    if sizes is None:
+        return False
+    key = layout_key if layout_key is not None else (offsets.data_ptr(), offsets._version, sizes.data_ptr(), sizes._version,
+                                                     int(offsets.numel()))
+    hit = _DISJOINT_CACHE.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        o, z = offsets.detach().cpu().to(torch.int64), sizes.detach().cpu().to(torch.int64)
+        hit = bool(o.numel() == z.numel() and (o.numel() < 2 or bool(((o[:-1] + z[:-1]) <= o[1:]).all())) and bool((z >= 0).all()))
+        if len(_DISJOINT_CACHE) > 64:
+            _DISJOINT_CACHE.clear()
+        _DISJOINT_CACHE[key] = hit
+    return hit
+
+
 def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None, per_field=False):
     """layout_key: a hashable description of (offsets, sizes, frozen) -- two tables with the same field layout (SparseEmbed
     passes its word sizes / frozen flags) share the sort even though their offset tensors are different objects."""
@@ -550,14 +585,15 @@ def _sorted_row_ids(offsets, sizes, frozen, idx, layout_key=None, n_rows=None, p
     layout = layout_key if layout_key is not None else (
         offsets.data_ptr(), offsets._version, sizes.data_ptr() if sizes is not None else 0,
         frozen.data_ptr() if frozen is not None else 0)
+    per_field = per_field and _fields_disjoint(offsets, sizes, layout_key)
     key = (idx.data_ptr(), idx._version, tuple(idx.shape), layout, torch.cuda.current_stream().cuda_stream, bool(per_field))
     for k, _, out in _SORT_CACHE:
         if k == key:
             return out
     B, F = idx.shape
     if per_field and 0 < B <= 8192 and (n_rows is None or n_rows < 2 ** 31):
-        # the dense (run-sum) gradient only needs equal row ids adjacent and in a fixed order, and ids of different fields never
-        # collide: one launch sorts every field's (id, position) pairs in LDS (fil.h fil_embed_sort_fields) -- no library sort
+        # the dense (run-sum) gradient only needs equal row ids adjacent and in a fixed order, and ids of fields with disjoint row
+        # ranges (checked above) never collide: one launch sorts every field's (id, position) pairs in LDS (fil.h fil_embed_sort_fields) -- no library sort
         sorted_ids = torch.empty(B * F, dtype=torch.int64, device=idx.device)
         perm = torch.empty(B * F, dtype=torch.int64, device=idx.device)
         check(lib.fil_embed_sort_fields(ptr(offsets), ptr(sizes), ptr(frozen), ptr(idx), ptr(sorted_ids), ptr(perm), B, F,

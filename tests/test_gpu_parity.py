@@ -383,6 +383,13 @@ def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
 
 
 @pytest.mark.parametrize("B,F,K,conv", TAIL_VARIANT_SHAPES)
+def test_cin_fused_tail_pooled_output_without_the_quadratic_tail(B, F, K, conv):
+    """output_dim = 2 (the pooled blocks are the output, no dense head) on the F+1-column fused tail (FIL_CIN_NOQTAIL): the column of
+    test_cin_fused_tail that round 5 pruned, kept on a subset of the shapes."""
+    _tail_case(B, F, K, conv, 2, 64 | 256)
+
+
+@pytest.mark.parametrize("B,F,K,conv", TAIL_VARIANT_SHAPES)
 # launch-shape variants on a subset of the shapes: | 4 the 64-row waves large batches get, | 128 one wave per row block instead of the
 # small-batch reduction split, | 8 no pair-symmetric kernels (the fused tail with a general first layer)
 @pytest.mark.parametrize("mode", [64 | 4, 64 | 128, 64 | 256 | 4, 64 | 512 | 4, 64 | 8])
@@ -666,6 +673,40 @@ def test_embed_gather_bit_exact():
     out.backward(dev(g))
     want = np.concatenate(closed.embed_scatter_add(idx, g, vocab), 0)
     check("embed dtable", table.grad, want, tol=1e-6)
+
+
+def test_embed_fields_sharing_a_table_keep_the_global_sort():
+    """Two fields looking up ONE table (offsets[f] == offsets[g]) and a layout without `sizes`: the same row then appears under
+    two fields, and the per-field sort (fil_embed_sort_fields) would leave it as two runs, of which fil_embed_run_sum keeps one.
+    functional._fields_disjoint sends such layouts down the global sort: dense deterministic gradient == the atomic scatter-add ==
+    the NumPy sum, and a disjoint layout still takes the per-field sort."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(5)
+    K, B = 8, 257
+    V = [7, 50, 50, 3]                      # fields 1 and 2 share the 50-row table
+    offs = [0, 7, 7, 57]
+    table_np = rng.standard_normal((60, K)).astype(np.float32)
+    idx_np = np.stack([rng.integers(0, v, B) for v in V], 1)
+    g_np = rng.standard_normal((B, 4, K)).astype(np.float32)
+    want = np.zeros((60, K), np.float64)
+    for f in range(4):
+        np.add.at(want, offs[f] + idx_np[:, f], g_np[:, f].astype(np.float64))
+    offsets, sizes = torch.tensor(offs, device="cuda"), torch.tensor(V, device="cuda")
+    idx, g = torch.tensor(idx_np, device="cuda"), dev(g_np)
+    assert not Fn._fields_disjoint(offsets, sizes, None)
+    assert not Fn._fields_disjoint(offsets, None, None)                                   # no sizes: ids are unbounded
+    assert Fn._fields_disjoint(torch.tensor([0, 7, 57, 107], device="cuda"), sizes, None)
+    for kw in (dict(sizes=sizes), dict(), dict(sizes=sizes, atomic=True)):
+        table = dev(table_np).requires_grad_()
+        Fn.embed_gather(table, offsets, idx, **kw).backward(g)
+        check("shared-table embedding gradient %s" % sorted(kw), table.grad, want, tol=1e-6)
+    # determinism of the global-sort path on the shared layout
+    a, b = [], []
+    for dst in (a, b):
+        table = dev(table_np).requires_grad_()
+        Fn.embed_gather(table, offsets, idx, sizes=sizes).backward(g)
+        dst.append(table.grad.clone())
+    assert torch.equal(a[0], b[0])
 
 
 def test_embed_out_of_range_ids_and_determinism():
@@ -1143,7 +1184,7 @@ def test_cin_layer_outside_the_kernel_menu_takes_the_composed_path(B, F, K, conv
         lay(torch.tensor(c["x"]))     # a CPU tensor: no CPU path
 
 
-@pytest.mark.parametrize("B,D,L", [(8, 6400, 8), (5, 130, 7), (4, 4100, 2)])
+@pytest.mark.parametrize("B,D,L", [(8, 6400, 8), (5, 130, 7), (4, 4100, 2), (6, 4096, 6), (6, 3416, 6)])
 def test_cross_layer_outside_the_kernel_menu_takes_the_composed_path(B, D, L):
     """D > 4096 or cross_hidden > 6: the reference has no such limits (interactive_layer.py:255-282).  The HIP entry point refuses the
     shape (FIL_ERR_UNSUPPORTED), the CrossLayer does not: it runs the reference's recurrence with torch ops on the GPU."""
