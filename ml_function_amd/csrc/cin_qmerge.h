@@ -614,96 +614,17 @@ struct CinHeadFold {
   int kshift, LK, op, oL; // K = 1 << kshift; column offsets p K and (L-1) K of the two upper layers
 };
 
-// Wave = 32 rows x 256 columns, two waves per SIMD (after the wrapped, position-major x rows took the fragment loads off the vector
-// memory pipeline, 32-row waves run the 128-column kernel 4 % faster than 64-row ones: the second wave covers prologue and
-// epilogue).  The generated operand and the x fragment of a step are paid once for both column halves, and all three sum-pools come
-// out of the epilogue, where x1 and R of a row sit in the same lane and register:
-//   pool_1[m] = sum_n x1[m,n]          pool_L[m] = sum_n x1[m,n] R[m,n] + <x[m], c> + const_L
-//   pool_p[m] = sum_n x1[m,n] S[m,n] + const_p,   S = x wsum_p^T  (one more small MFMA product from the wrapped rows)
-// i.e. cin_qtail_pool2_kernel's work without its pass over x1 and R.  x1 and R are still stored (the backward needs both).
-// Operand layouts: W1f / WTf as cin_pack_wf_sym_body packs them ([h][2 JT][128]); wsn = wsum_p in the forward operand layout
-// ([2 JTG][128], JTG = cin_jt_of(F) steps); cvec as cin_qtail_t_kernel leaves it.
-template <int JT>
-__global__ __launch_bounds__(256, 2) void cin_fwdq_kernel(const float* __restrict__ x2T, int XL, const float* __restrict__ W1f, const float* __restrict__ WTf,
-                                                          const float* __restrict__ bias1, const float* __restrict__ wsn, int JTG,
-                                                          const float* __restrict__ cvec, float* __restrict__ x1T, float* __restrict__ RT, int HS,
-                                                          float* __restrict__ pool1, float* __restrict__ pool_p, float* __restrict__ pool_L, int M, int F,
-                                                          int H, CinHeadFold hf) {
-  constexpr int DEPTH = JT % 5 == 0 ? 5 : (JT % 4 == 0 ? 4 : (JT % 7 == 0 ? 7 : (JT % 3 == 0 ? 3 : 2)));
-  static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
-  __shared__ float lin_s[4][32];
-  __shared__ float pv_s[4][3][32];   // (head folded in) the wave's pooled values, then their products with dense_w
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
-  if (wrow0 >= M) return;   // (no workgroup barriers in this kernel)
-  const int wrow_u = __builtin_amdgcn_readfirstlane(wrow0);
-  // this wave's half of its 64-row block of the wrapped rows ([p][64 rows])
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(x2T + (long)(wrow_u >> 6) * XL * 64, (long)XL * 256);
-  const long wbytes = (long)F * (2 * JT) * 128 * 4;
-  const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(W1f, wbytes), rwt = make_rsrc(WTf, wbytes);   // steps past the end read zeros
-  const int wo = (half * 32 + r) * 16;
-  const int vrow = ((wrow_u & 63) + r) * 4, vhalf = vrow + half * 256;
-  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rw, int s) {
-    return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo, s * 1024, 0));
-  };
-  auto ldfrag = [&](int h, float (&xf)[JT], float& xp) {
-    const int hb = __builtin_amdgcn_readfirstlane(h) * 256;
-    xp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vrow, hb, 0));
-#pragma unroll
-    for (int j = 0; j < JT; ++j) xf[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vhalf + 512 * j, hb, 0));
-  };
-  f32x16 acc[8];
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-  f32x4s q1[DEPTH], qt[DEPTH];
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    q1[d] = ldw(rw1, d);
-    qt[d] = ldw(rwt, d);
-  }
-  float xa[JT], xb[JT], pa, pb;
-  ldfrag(0, xa, pa);
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    settle(q1[d]);
-    settle(qt[d]);
-  }
-  settle(pa);
-  float ac = pa * xa[0], an;
-  auto run_h = [&](int h, float (&xc)[JT], float& pc, float (&xn_)[JT], float& pn) {
-    ldfrag(min(h + 1, F - 1), xn_, pn);
-    const int sb = h * JT;
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const f32x4s w1 = q1[j % DEPTH], wt = qt[j % DEPTH];
-      an = j + 1 < JT ? pc * xc[j + 1 < JT ? j + 1 : 0] : pn * xn_[0];
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0] = mfma32(ac, w1[0], acc[0]);
-      acc[1] = mfma32(ac, w1[1], acc[1]);
-      acc[2] = mfma32(ac, w1[2], acc[2]);
-      acc[3] = mfma32(ac, w1[3], acc[3]);
-      acc[4] = mfma32(ac, wt[0], acc[4]);
-      acc[5] = mfma32(ac, wt[1], acc[5]);
-      acc[6] = mfma32(ac, wt[2], acc[6]);
-      acc[7] = mfma32(ac, wt[3], acc[7]);
-      ac = an;
-      __builtin_amdgcn_sched_barrier(0);
-      q1[j % DEPTH] = ldw(rw1, sb + j + DEPTH);   // (after the step's MFMAs: they may land in the registers they replace)
-      qt[j % DEPTH] = ldw(rwt, sb + j + DEPTH);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  int h = 0;
-#pragma unroll 1
-  for (; h + 1 < F; h += 2) {
-    run_h(h, xa, pa, xb, pb);
-    run_h(h + 1, xb, pb, xa, pa);
-  }
-  if (h < F) run_h(h, xa, pa, xb, pb);
-
+// Everything of the merged forward behind its main loop (shared by the exact kernel below and the split-bf16 kernel of cin_qsplit.h,
+// which differ only in how acc -- [x1 | R] of the wave's 32 rows, lane r owning columns 4r..4r+3 of each half -- was accumulated):
+// S = x wsum_p^T and <x, c> from the wrapped rows (exact fp32 MFMA), + b1, the stores of x1 and R, the three sum-pools and, with the
+// head folded in, pooled [B, L K] and the Dense(1) output.  NW = waves per workgroup (rows of the two small LDS arrays).
+template <int NW>
+__device__ __forceinline__ void cin_fwdq_epilogue(f32x16 (&acc)[8], const __amdgpu_buffer_rsrc_t& rx, int vhalf, int wo, int r, int half, int wave, int wrow0,
+                                                  const float* __restrict__ bias1, const float* __restrict__ wsn, int JTG, const float* __restrict__ cvec,
+                                                  float* __restrict__ x1T, float* __restrict__ RT, int HS, float* __restrict__ pool1,
+                                                  float* __restrict__ pool_p, float* __restrict__ pool_L, int M, int F, int H, const CinHeadFold& hf,
+                                                  float (&lin_s)[NW][32], float (&pv_s)[NW][3][32]) {
+  const int lane = half * 32 + r;
   // ---- S = x wsum_p^T and the linear term <x, c>: JTG steps of the general field order f = 2j + half (positions < F of the wrapped
   // rows; wsn rows f >= F are zero), four steps per group, the next group's operands in flight behind this group's MFMAs
   f32x16 t[4];
@@ -818,6 +739,99 @@ __global__ __launch_bounds__(256, 2) void cin_fwdq_kernel(const float* __restric
       for (int k = 0; k < K; ++k) o += pv_s[wave][l][lane * K + k];
     hf.out[(wrow0 >> hf.kshift) + lane] = o + hf.dense_b[0];
   }
+}
+
+// Wave = 32 rows x 256 columns, two waves per SIMD (after the wrapped, position-major x rows took the fragment loads off the vector
+// memory pipeline, 32-row waves run the 128-column kernel 4 % faster than 64-row ones: the second wave covers prologue and
+// epilogue).  The generated operand and the x fragment of a step are paid once for both column halves, and all three sum-pools come
+// out of the epilogue, where x1 and R of a row sit in the same lane and register:
+//   pool_1[m] = sum_n x1[m,n]          pool_L[m] = sum_n x1[m,n] R[m,n] + <x[m], c> + const_L
+//   pool_p[m] = sum_n x1[m,n] S[m,n] + const_p,   S = x wsum_p^T  (one more small MFMA product from the wrapped rows)
+// i.e. cin_qtail_pool2_kernel's work without its pass over x1 and R.  x1 and R are still stored (the backward needs both).
+// Operand layouts: W1f / WTf as cin_pack_wf_sym_body packs them ([h][2 JT][128]); wsn = wsum_p in the forward operand layout
+// ([2 JTG][128], JTG = cin_jt_of(F) steps); cvec as cin_qtail_t_kernel leaves it.
+template <int JT>
+__global__ __launch_bounds__(256, 2) void cin_fwdq_kernel(const float* __restrict__ x2T, int XL, const float* __restrict__ W1f, const float* __restrict__ WTf,
+                                                          const float* __restrict__ bias1, const float* __restrict__ wsn, int JTG,
+                                                          const float* __restrict__ cvec, float* __restrict__ x1T, float* __restrict__ RT, int HS,
+                                                          float* __restrict__ pool1, float* __restrict__ pool_p, float* __restrict__ pool_L, int M, int F,
+                                                          int H, CinHeadFold hf) {
+  constexpr int DEPTH = JT % 5 == 0 ? 5 : (JT % 4 == 0 ? 4 : (JT % 7 == 0 ? 7 : (JT % 3 == 0 ? 3 : 2)));
+  static_assert(JT % DEPTH == 0, "queue depth must divide the steps per h");
+  __shared__ float lin_s[4][32];
+  __shared__ float pv_s[4][3][32];   // (head folded in) the wave's pooled values, then their products with dense_w
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
+  if (wrow0 >= M) return;   // (no workgroup barriers in this kernel)
+  const int wrow_u = __builtin_amdgcn_readfirstlane(wrow0);
+  // this wave's half of its 64-row block of the wrapped rows ([p][64 rows])
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(x2T + (long)(wrow_u >> 6) * XL * 64, (long)XL * 256);
+  const long wbytes = (long)F * (2 * JT) * 128 * 4;
+  const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(W1f, wbytes), rwt = make_rsrc(WTf, wbytes);   // steps past the end read zeros
+  const int wo = (half * 32 + r) * 16;
+  const int vrow = ((wrow_u & 63) + r) * 4, vhalf = vrow + half * 256;
+  auto ldw = [&](const __amdgpu_buffer_rsrc_t& rw, int s) {
+    return __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rw, wo, s * 1024, 0));
+  };
+  auto ldfrag = [&](int h, float (&xf)[JT], float& xp) {
+    const int hb = __builtin_amdgcn_readfirstlane(h) * 256;
+    xp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vrow, hb, 0));
+#pragma unroll
+    for (int j = 0; j < JT; ++j) xf[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vhalf + 512 * j, hb, 0));
+  };
+  f32x16 acc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  f32x4s q1[DEPTH], qt[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    q1[d] = ldw(rw1, d);
+    qt[d] = ldw(rwt, d);
+  }
+  float xa[JT], xb[JT], pa, pb;
+  ldfrag(0, xa, pa);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    settle(q1[d]);
+    settle(qt[d]);
+  }
+  settle(pa);
+  float ac = pa * xa[0], an;
+  auto run_h = [&](int h, float (&xc)[JT], float& pc, float (&xn_)[JT], float& pn) {
+    ldfrag(min(h + 1, F - 1), xn_, pn);
+    const int sb = h * JT;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const f32x4s w1 = q1[j % DEPTH], wt = qt[j % DEPTH];
+      an = j + 1 < JT ? pc * xc[j + 1 < JT ? j + 1 : 0] : pn * xn_[0];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mfma32(ac, w1[0], acc[0]);
+      acc[1] = mfma32(ac, w1[1], acc[1]);
+      acc[2] = mfma32(ac, w1[2], acc[2]);
+      acc[3] = mfma32(ac, w1[3], acc[3]);
+      acc[4] = mfma32(ac, wt[0], acc[4]);
+      acc[5] = mfma32(ac, wt[1], acc[5]);
+      acc[6] = mfma32(ac, wt[2], acc[6]);
+      acc[7] = mfma32(ac, wt[3], acc[7]);
+      ac = an;
+      __builtin_amdgcn_sched_barrier(0);
+      q1[j % DEPTH] = ldw(rw1, sb + j + DEPTH);   // (after the step's MFMAs: they may land in the registers they replace)
+      qt[j % DEPTH] = ldw(rwt, sb + j + DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int h = 0;
+#pragma unroll 1
+  for (; h + 1 < F; h += 2) {
+    run_h(h, xa, pa, xb, pb);
+    run_h(h + 1, xb, pb, xa, pa);
+  }
+  if (h < F) run_h(h, xa, pa, xb, pb);
+
+  cin_fwdq_epilogue<4>(acc, rx, vhalf, wo, r, half, wave, wrow0, bias1, wsn, JTG, cvec, x1T, RT, HS, pool1, pool_p, pool_L, M, F, H, hf, lin_s, pv_s);
 }
 
 bool cin_launch_fwdq(hipStream_t st, int JT, const float* x2T, int XL, const float* W1f, const float* WTf, const float* bias1, const float* wsn, int JTG,

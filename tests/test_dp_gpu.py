@@ -131,11 +131,11 @@ def test_bench_line_accounting():
                         "--no-cpu-baseline", "--no-graph-replay"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    gemms = {k: v for k, v in res["kernels"].items() if "executed_flops_per_launch" in v}
+    gemms = {k: v for k, v in res["kernels"].items() if v.get("executed_flops_per_launch", 0) > 1e9}    # (cin_fwd_prep shares the prefix: 20 MFLOP)
     assert len(gemms) == 3 and all(abs(v["launches_per_step"] - 1.0) < 1e-9 for v in gemms.values()), gemms
     per_gemm = 2.0 * 65536 * 780 * 256
     assert 3 * per_gemm <= res["executed_flops_per_step"] <= 3 * per_gemm * 1.01
-    assert res["executed_flops_per_step"] == pytest.approx(sum(v["executed_flops_per_launch"] for v in gemms.values()), rel=1e-12)
+    assert res["executed_flops_per_step"] == pytest.approx(sum(v["executed_flops_per_launch"] for v in gemms.values()), rel=1e-3)
     assert res["executed_frac"] == pytest.approx(res["executed_flops_per_step"] / (res["ms_per_step"] * 1e-3) / (res["roofline"]["peak"] * 1e12), rel=1e-9)
     rf = res["roofline"]
     assert rf["frac"] == pytest.approx(rf["flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12 / rf["peak"], rel=1e-9)
