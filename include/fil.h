@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 213
+#define FIL_ABI_VERSION 214
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -96,8 +96,15 @@ int fil_dcn_bwd(const float* x, const float* w, const float* b, const float* s, 
  *             the flops) and, for L >= 3, the layer below it contracted against [1 | wsum_L] (its map is only ever sum-pooled
  *             or fed to the last layer: F+1 observable columns instead of H_{L-1}; the "fused tail", csrc/cin_tail.h);
  *         1 = fp32 MFMA with every layer through the general GEMM kernels (validation / comparison).
- *         (bit 2 was the split-bf16 experiment of rounds 1-3 -- every GEMM on three bf16 pieces per operand; retired in ABI 210
- *             once the exact path overtook it: FIL_ERR_UNSUPPORTED.)
+ *         + FIL_CIN_BF16X3 (2; ABI 214): the LABELLED reduced-operand mode ("bf16 operands + fp32 accumulate").  The three
+ *           GEMM launches of the merged quadratic tail run on split-bf16 operands (csrc/cin_qsplit.h): every fp32 operand as three bf16
+ *           pieces (an exact cut), every product as six v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the fp32-equivalent chain
+ *           a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 (dropped terms < 2^-24 relative) on the bf16 matrix pipe.  Holds the parity bars
+ *           of mode 0 (tests run both side by side); not bit-identical to it (other summation order), and an infinite input gives
+ *           NaN where the exact chain gives inf.  Selects something only where those kernels exist (three layers on the merged
+ *           quadratic tail, F in the kernels' menu, H_1 <= 128): elsewhere the call runs the exact kernels.  Never the default;
+ *           bench.py reports it beside the exact-fp32 headline, not as it.  (Bit 2 of ABI <= 209 was the same idea on the round-2
+ *           layer structure; ABI 210-213 answered it with FIL_ERR_UNSUPPORTED.)
  *         + FIL_CIN_X_TRANSPOSED (16), forward and backward alike: `x` is given transposed, [B*K][F] row-major (x_t[(b*K+k)*F+f]
  *           = x[b,f,k], as written by fil_embed_gather_xt): no input transpose, saved's own copy of it stays unused.  dx is
  *           still returned as [B,F,K].
@@ -171,7 +178,7 @@ int fil_cin_bwd(const float* x, const float* const* W, const float* const* bias,
  *       Parity of that mode is ~1e-3 (tests state 5e-3 / 2e-2); values beyond the fp16 range (65504) overflow.
  *   Limits: K <= 64, A <= 16, H <= 8, F <= 512 (and the LDS footprint <= 160 KiB).
  */
-enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_RETIRED_2 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
+enum fil_cin_mode_bits { FIL_CIN_GENERAL = 1, FIL_CIN_BF16X3 = 2, FIL_CIN_MB2 = 4, FIL_CIN_NOSYM = 8, FIL_CIN_X_TRANSPOSED = 16,
                          FIL_CIN_NOTAIL = 32, FIL_CIN_TAIL_ALWAYS = 64, FIL_CIN_NOKSPLIT = 128, FIL_CIN_NOQTAIL = 256, FIL_CIN_NOQMERGE = 512 };
 enum fil_precision { FIL_PREC_F32 = 0, FIL_PREC_F16_MFMA = 1 };
 size_t fil_attn_fwd_workspace_bytes(int B, int F, int K, int H, int A);

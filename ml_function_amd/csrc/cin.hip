@@ -11,6 +11,7 @@
 #include "cin_tail.h"
 #include "cin_launch.h"
 #include "cin_qtail.h"
+#include "cin_qsplit.h"
 #include "cin_qmerge.h"
 
 #include <stdlib.h>
@@ -203,7 +204,7 @@ static TailGeom tail_geom(const CinShape& s) {   // what the tail WOULD look lik
   g.uz_floats = (size_t)g.tiles * 64 * g.JHp;
   return g;
 }
-constexpr int kCinRetiredBits = FIL_CIN_RETIRED_2;   // mode bits that no longer select anything: FIL_ERR_UNSUPPORTED
+constexpr int kCinRetiredBits = 0;   // mode bits that no longer select anything: FIL_ERR_UNSUPPORTED (none at present)
 // is the tail used by a call with these mode bits?
 static bool tail_used(const CinShape& s, int mode) {
   if ((mode & (FIL_CIN_GENERAL | FIL_CIN_NOTAIL)) != 0) return false;
@@ -224,6 +225,13 @@ static bool qtail_used(const CinShape& s, int mode, const CinTune& tune) {
 static bool qmerge_used(const CinShape& s, int mode, const CinTune& tune) {
   return qtail_used(s, mode, tune) && 3 * s.F + 3 <= s.HSmax() && (mode & FIL_CIN_NOQMERGE) == 0 && knobs().qmerge != 0;   // (xe | gxR | dxR share one gradient buffer)
 }
+// ... on split-bf16 operands (cin_qsplit.h, FIL_CIN_BF16X3): where the merged kernels run in their full form and a split kernel exists
+static bool qsplit_fwd_menu(int JT) { return JT == 10; }
+static bool qsplit_used(const CinShape& s, int mode, const CinTune& tune) {
+  return (mode & FIL_CIN_BF16X3) != 0 && qmerge_used(s, mode, tune) && knobs().fwdq != 0 && knobs().dz2 != 0 && s.HS(0) == 128 &&
+         qsplit_fwd_menu(cin_jt_sym(s.F));
+}
+static size_t qsplit_wb_bytes(const CinShape& s) { return (size_t)cin_qs_steps(s.F, cin_jt_sym(s.F)) * kQsStageBytes; }
 static size_t qtail_wz_floats(const CinShape& s) {      // T in the dZ kernel's slot order
   const int jts = cin_jt_sym(s.F);
   return ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
@@ -299,6 +307,7 @@ static size_t fwd_ws_bytes(const CinShape& s) {
   t += align_up((size_t)kCinMaxH * sizeof(float), 256);                                                  // quadratic tail: zero bias of the R GEMM
   t += align_up(cin_x2_floats(s.M(), cin_x2_len(s.F)) * sizeof(float), 256);                             // wrapped rows of x (pair-symmetric forward)
   t += align_up((size_t)chunks_of(s.H[0]) * s.F * 2 * cin_jt_sym(s.F) * 128 * sizeof(float), 256);       // merged quadratic-tail forward: T's packed operand beside W1's
+  t += align_up(qsplit_wb_bytes(s), 256);                                                                // ... its split-bf16 planes (FIL_CIN_BF16X3)
   return t;
 }
 // floats of the dW partial-sum buffer: the largest splits * C * H over the layers (both first-layer forms, so the
@@ -397,12 +406,13 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   int rc = check_shape("fil_cin_fwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
   if (mode < 0 || mode > 1023 || (mode & kCinRetiredBits) != 0)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE; 2 = the retired split-bf16 experiment)", mode);
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: mode %d (bits: 1 general kernels, 2 BF16X3, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;   // x is already [B*K][F] (fil_embed_gather_xt): no input transpose
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);                    // last two layers as one implicit GEMM (cin_tail.h)
   const bool qtail = qtail_used(s, mode, tune);            // ... as a quadratic form over field pairs (cin_qtail.h)
   const bool qmerge = qmerge_used(s, mode, tune);          // ... with merged launches (cin_qmerge.h)
+  const bool qsplit = qsplit_used(s, mode, tune);          // ... on split-bf16 operands (cin_qsplit.h)
   const TailGeom tg = tail_geom(s);
   mode &= 1;
   if (B == 0) return FIL_OK;
@@ -426,6 +436,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
   float* x2T = ws.take<float>(cin_x2_floats(M, XL));
   const bool need_x2 = tune.sym;   // the pair-symmetric forward kernel reads the wrapped rows
   float* WfT = ws.take<float>((size_t)chunks_of(H[0]) * F * 2 * cin_jt_sym(F) * 128);
+  u32x4* Wb = reinterpret_cast<u32x4*>(ws.take<unsigned char>(qsplit_wb_bytes(s)));
   Carver sv(saved);
   float* xT_own = sv.take<float>((size_t)M * F);       // (unused when x arrives transposed; the layout of `saved` stays the same)
   const float* xT = xt_in ? x : xT_own;
@@ -521,8 +532,15 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
           hf = CinHeadFold{pooled, output_dim == 1 ? out : nullptr, dense_w, dense_b, ks, (int)(L * K), p * K, lL * K};
           head_done = true;
         }
-        if (!cin_launch_fwdq(st, JTs, x2T, XL, Wf, WfT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
-                             const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf))
+        if (qsplit) {
+          // split-bf16 operands: the planes of [W1s | Ts] from the two packed fp32 operands, then the same GEMM on the bf16 pipe
+          const int NT = cin_qs_steps(F, JTs);
+          hipLaunchKernelGGL(cin_qs_pack_wb_kernel, dim3(cdiv(NT * 512, 256)), dim3(256), 0, st, Wf, WfT, Wb, NT, F * JTs);
+          if (!cin_launch_fwdq_b(st, JTs, x2T, XL, Wb, NT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
+                                 const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf))
+            return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: no split-bf16 forward kernel for JT=%d (F=%d)", JTs, F);
+        } else if (!cin_launch_fwdq(st, JTs, x2T, XL, Wf, WfT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
+                                    const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf))
           return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: no merged forward kernel for JT=%d (F=%d)", JTs, F);
         pa.chunks[0] = pa.chunks[p] = pa.chunks[lL] = 1;
       }
@@ -672,7 +690,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   int rc = check_shape("fil_cin_bwd", B, F, K, L, H, s);
   if (rc != FIL_OK) return rc;
   if (mode < 0 || mode > 1023 || (mode & kCinRetiredBits) != 0)
-    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE; 2 = the retired split-bf16 experiment)", mode);
+    return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: mode %d (bits: 1 general kernels, 2 BF16X3, 4 MB2, 8 NOSYM, 16 X_TRANSPOSED, 32 NOTAIL, 64 TAIL_ALWAYS, 128 NOKSPLIT, 256 NOQTAIL, 512 NOQMERGE)", mode);
   const bool xt_in = (mode & FIL_CIN_X_TRANSPOSED) != 0;
   const CinTune tune(mode);
   const bool tail = tail_used(s, mode);

@@ -164,12 +164,12 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
     }
     split3(p, a);
   };
-  auto make_a_next = [&](u32x4 (&a)[3]) {
+  auto make_a_next = [&](const float (&xnm)[HPS], u32x4 (&a)[3]) {
     float p[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int t = HPS + e / JT + 2 * (e % JT);   // the next period's window is this one shifted by HPS, its tail = wn
-      p[e] = xn[e / JT] * (t < WS ? wl[t < WS ? t : 0] : wn[t >= WS ? t - WS : 0]);
+      p[e] = xnm[e / JT] * (t < WS ? wl[t < WS ? t : 0] : wn[t >= WS ? t - WS : 0]);
     }
     split3(p, a);
   };
@@ -177,6 +177,8 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
   make_a(0, acur);
   const int nper = NT / KP;
   const int ldsb = lane * 16;
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step 0's pieces (the in-loop wait of a period's first step allows for window loads
+                                                     // that the very first period has not issued)
 #pragma unroll 1
   for (int per = 0; per < nper; ++per) {
     const int h0 = per * HPS;
@@ -185,8 +187,6 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
       const int t = per * KP + kk;
       // Step t's pieces were issued three steps ago; younger vector-memory operations may stay in flight: the DMA pieces of steps
       // t+1, t+2 (6) and, for the two steps after a period's first one, the window loads issued there in front of its DMA (2 HPS).
-      constexpr int kSince = 0;
-      (void)kSince;
       if (kk == 1 || kk == 2 || (kk == 0 && KP == 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * HPS) : "memory");
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // every wave's pieces of step t have landed, and every wave is done reading slot (t - 1) % NS
@@ -194,14 +194,18 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
         // the next period's x[m, h] values and the HPS window entries that slide in (positions past XL / rows of an inactive wave: zeros)
 #pragma unroll
         for (int u = 0; u < HPS; ++u) {
-          const float v = ldx(vrow, h0 + HPS + u);
-          xn[u] = h0 + HPS + u < F ? v : 0.f;
+          xn[u] = ldx(vrow, h0 + HPS + u);     // (h >= F is masked where the value is USED: a select here would wait for the load)
           wn[u] = ldx(vhalf, h0 + WS + u);
         }
       }
       dma(t + NS - 1);   // (past NT: zeros into a free slot -- keeps the count of operations in flight the same in every step)
       if (kk + 1 < KP) make_a(kk + 1, anext);
-      else make_a_next(anext);
+      else {
+        // x[m, h] of the padded h >= F: zero (their weights are zero, but the wrapped row holds x[m, h - F] there: NaN x 0)
+#pragma unroll
+        for (int u = 0; u < HPS; ++u) xn[u] = h0 + HPS + u < F ? xn[u] : 0.f;
+        make_a_next(xn, anext);
+      }
       const unsigned char* sb = ring + (t % NS) * SB + ldsb;
       u32x4 b[2][3];
 #pragma unroll

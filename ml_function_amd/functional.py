@@ -183,6 +183,7 @@ def dcn_cross(x, w, b):
 
 
 # --------------------------------------------------------------------------------------------- A3  CIN
+CIN_BF16X3 = 2          # fil.h FIL_CIN_BF16X3: the labelled split-bf16 mode of the merged quadratic tail's GEMMs (csrc/cin_qsplit.h)
 CIN_X_TRANSPOSED = 16   # fil.h FIL_CIN_X_TRANSPOSED: x handed over as [B*K, F] (embed_gather(emit_xt=True))
 CIN_TAIL_ALWAYS = 64    # fil.h FIL_CIN_TAIL_ALWAYS: the tails wherever they are defined, whatever the batch size (tests, smoke)
 CIN_NOQTAIL = 256       # fil.h FIL_CIN_NOQTAIL: three-layer nets on the F+1-column fused tail instead of the quadratic tail

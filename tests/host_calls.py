@@ -48,7 +48,8 @@ def run(lib):
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 9, H3, 1, 0, None, 0, None), -4)
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 1, _lib.int_array([300]), 1, 0, None, 0, None), -4)
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 1999, None, 0, None), -4, b"mode")
-    expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 2, None, 0, None), -4, b"retired")   # the split-bf16 experiment's bit
+    expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 1024, None, 0, None), -4, b"mode 1024")   # beyond the mode bits
+    expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 2, None, 0, None), -1, b"")   # FIL_CIN_BF16X3 is a mode again (ABI 214): argument check next
     expect(lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 70, 16, 3, H3, 1, 0, None, 0, None), -4, b"64 fields")
     expect(lib.fil_cin_bwd(None, None, None, None, None, None, None, None, None, None, None, None, 4, 39, 16, 3, H3, 1, 0, None, None, 0, None), -1)
     for B in (0, 1, 4096, 150000):
