@@ -232,6 +232,10 @@ static bool qsplit_used(const CinShape& s, int mode, const CinTune& tune) {
          qsplit_fwd_menu(cin_jt_sym(s.F));
 }
 static size_t qsplit_wb_bytes(const CinShape& s) { return (size_t)cin_qs_steps(s.F, cin_jt_sym(s.F)) * kQsStageBytes; }
+static size_t qsplit_wzb_bytes(const CinShape& s) {     // one layer's slot-ordered weights as split planes (tiles x 8 steps x 3 KiB)
+  const int jts = cin_jt_sym(s.F);
+  return ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 8 * 3072;
+}
 static size_t qtail_wz_floats(const CinShape& s) {      // T in the dZ kernel's slot order
   const int jts = cin_jt_sym(s.F);
   return ((size_t)cdiv(s.F, cin_dz_h_per_period(jts)) * cin_dz_tiles_per_period(jts) + 1) * 32 * s.HS(0);
@@ -344,6 +348,7 @@ static size_t bwd_ws_bytes(const CinShape& s) {
   t += align_up((size_t)s.F * s.F * kCinMaxH * sizeof(float), 256);      // quadratic tail: dT
   t += align_up(((M + 255) / 256 + 1) * kQtConst * sizeof(float), 256);  //                 column-sum partials of dP_L x, their sum
   t += align_up(((M + 255) / 256) * (LK + 1) * sizeof(float), 256);      //                 the dense head's block partials (merged launches)
+  t += 2 * align_up(qsplit_wzb_bytes(s), 256);                           // FIL_CIN_BF16X3: W1s and Ts in slot order as split planes
   return t;
 }
 
@@ -696,6 +701,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   const bool tail = tail_used(s, mode);
   const bool qtail = qtail_used(s, mode, tune);
   const bool qmerge = qmerge_used(s, mode, tune);
+  const bool qsplit = qsplit_used(s, mode, tune);
   const TailGeom tg = tail_geom(s);
   mode &= 1;
   FIL_CHECK_ARG(W && dW && dbias);
@@ -745,6 +751,8 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
   const int qt_ndc = (int)((M + 255) / 256);
   float* qt_dcpart = ws.take<float>((size_t)(qt_ndc + 1) * kQtConst);   // block partials | their sum
   float* qt_hpart = ws.take<float>((size_t)qt_ndc * (LK + 1));           // merged launches: the dense head's block partials
+  u32x4* Wzb1 = reinterpret_cast<u32x4*>(ws.take<unsigned char>(qsplit_wzb_bytes(s)));
+  u32x4* Wzb2 = reinterpret_cast<u32x4*>(ws.take<unsigned char>(qsplit_wzb_bytes(s)));
 
   // saved tensors
   Carver sv(const_cast<float*>(saved));
@@ -868,7 +876,13 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       // both data-gradient passes in one launch (cin_dz2_kernel): G1 with W1, then dP_L x1 with T, into one dX image
       ProfScope ps("cin_bwd_dz_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
       // (the kernel also finishes dx: + the shortcut's part in dxT, + dP_L c, transposed to [B,F,K] on the way out)
-      if (!cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec))
+      bool split_done = false;
+      if (qsplit) {   // split-bf16 operands: both layers' slot-ordered weights as planes, then the same two passes on the bf16 pipe
+        hipLaunchKernelGGL(cin_qs_pack_wz_kernel, dim3(cdiv(2 * tiles0 * 512, 256)), dim3(256), 0, st, Wz, qtWzT, Wzb1, Wzb2, tiles0);
+        split_done = cin_launch_dz2_b(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wzb1, Wzb2, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec);
+      }
+      if (!split_done &&
+          !cin_launch_dz2(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wz, qtWzT, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec))
         return fail(FIL_ERR_UNSUPPORTED, "fil_cin_bwd: no two-pass data-gradient kernel for JT=%d (F=%d)", JTs, F);
       qm_joined = true;
     } else {

@@ -361,6 +361,49 @@ inline int cin_dz2_rows(int F, int JT) {   // LDS field rows: the wrapped slot f
   return std::max(cin_dz_sym_rows(F, JT), (F + hpp - 1) / hpp * hpp);
 }
 
+// What cin_dz2_kernel (and its split-bf16 form, cin_qsplit.h) does with the finished dX image of a wave's 32 rows.
+__device__ __forceinline__ void cin_dz2_finish(const float* smem, int wave, int lane, int wrow0, int M, int F, int K, const float* __restrict__ dsc, int ldp,
+                                               float* __restrict__ dxT, int accumulate, float* __restrict__ dx, const float* __restrict__ cvec) {
+  constexpr int FS = kDz2FieldStride;
+  const float* img = smem + wave * 32 * 2 + 1;
+  const int nrow = min(32, M - wrow0);
+  if (dx != nullptr) {
+    // final form: dx [B,F,K] = (what dxT holds: the shortcut's part) + the image + dP_L[m] c[f], transposed on the way out -- no
+    // separate transpose launch.  Lanes walk the wave's rows fastest: consecutive k of a sample are consecutive floats of dx.
+    const int rr = lane & 31;
+    const int mm = wrow0 + rr;
+    const bool ok = rr < nrow;
+    const long mc = ok ? mm : M - 1;
+    const long bb = mc / K;
+    const int kk = (int)(mc - bb * K);
+    const float sc = dsc[bb * ldp + kk];
+    float* dxb = dx + (bb * F) * K + kk;
+    const float* add = dxT + mc * F;
+    // (eight loads in flight per batch: one at a time they were F/2 exposed memory latencies in a row at the very end of the wave)
+    for (int f0 = lane >> 5; f0 < F; f0 += 16) {
+      float a8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] = accumulate ? add[min(f0 + 2 * u, F - 1)] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + 2 * u;
+        if (f < F) {
+          const float v = a8[u] + img[f * FS + rr * 2] + sc * cvec[f];
+          if (ok) dxb[(long)f * K] = v;
+        }
+      }
+    }
+    return;
+  }
+  // dX rows of the wave are contiguous in dxT ([32 rows][F]): written cooperatively from the LDS image, whole lines per store
+  float* dst = dxT + (long)wrow0 * F;
+  for (int idx = lane; idx < nrow * F; idx += 64) {
+    const int rr = idx / F, f = idx - rr * F;
+    const float v = img[f * FS + rr * 2];
+    dst[idx] = accumulate ? dst[idx] + v : v;
+  }
+}
+
 template <int JT, int G>
 __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
                                                          const float* __restrict__ dsc, int ldp, int K, const float* __restrict__ Wz1,
@@ -558,43 +601,7 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
     }
   }
   __builtin_amdgcn_wave_barrier();
-  const float* img = smem + wave * 32 * 2 + 1;
-  const int nrow = min(32, M - wrow0);
-  if (dx != nullptr) {
-    // final form: dx [B,F,K] = (what dxT holds: the shortcut's part) + the image + dP_L[m] c[f], transposed on the way out -- no
-    // separate transpose launch.  Lanes walk the wave's rows fastest: consecutive k of a sample are consecutive floats of dx.
-    const int rr = lane & 31;
-    const int mm = wrow0 + rr;
-    const bool ok = rr < nrow;
-    const long mc = ok ? mm : M - 1;
-    const long bb = mc / K;
-    const int kk = (int)(mc - bb * K);
-    const float sc = dsc[bb * ldp + kk];
-    float* dxb = dx + (bb * F) * K + kk;
-    const float* add = dxT + mc * F;
-    // (eight loads in flight per batch: one at a time they were F/2 exposed memory latencies in a row at the very end of the wave)
-    for (int f0 = lane >> 5; f0 < F; f0 += 16) {
-      float a8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] = accumulate ? add[min(f0 + 2 * u, F - 1)] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = f0 + 2 * u;
-        if (f < F) {
-          const float v = a8[u] + img[f * FS + rr * 2] + sc * cvec[f];
-          if (ok) dxb[(long)f * K] = v;
-        }
-      }
-    }
-    return;
-  }
-  // dX rows of the wave are contiguous in dxT ([32 rows][F]): written cooperatively from the LDS image, whole lines per store
-  float* dst = dxT + (long)wrow0 * F;
-  for (int idx = lane; idx < nrow * F; idx += 64) {
-    const int rr = idx / F, f = idx - rr * F;
-    const float v = img[f * FS + rr * 2];
-    dst[idx] = accumulate ? dst[idx] + v : v;
-  }
+  cin_dz2_finish(smem, wave, lane, wrow0, M, F, K, dsc, ldp, dxT, accumulate, dx, cvec);
 }
 
 // dx != nullptr: the kernel finishes the job -- dx [B,F,K] = transpose(dxT (read only) + its image) + dP_L c -- instead of updating dxT

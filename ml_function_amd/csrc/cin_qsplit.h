@@ -235,6 +235,226 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
   cin_fwdq_epilogue<8>(acc, rx, vhalf, wo, r, half, wave, wrow0, bias1, wsn, JTG, cvec, x1T, RT, HS, pool1, pool_p, pool_L, M, F, H, hf, lin_s, pv_s);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Data gradients (cin_dz2_kernel on split operands): dZ^T tile = 32 slot rows (A: the slot-ordered pair weights, three planes) x 32 rows m
+// (B: the lane's half row of G1 / dP_L x1, cut ONCE per pass into 8 steps x 3 planes = 96 registers), 8 MFMA steps of 16 columns =
+// 48 bf16 MFMAs per tile instead of 64 f32 ones.  The accumulator layout, the slot order and the whole register / LDS contraction of
+// the tile into the dX image are cin_dz2_kernel's, unchanged: per tile the same ~140 vector / LDS instructions now stand beside
+// 1536 cycles of matrix time instead of 4096 -- they issue in the MFMAs' shadow.  The A planes stream through registers (a queue QD
+// steps deep, 16-byte scalar-offset buffer loads): 24 KB per tile and wave -- the LDS holds the two workgroups' dX images, there is no
+// room for a shared ring, so this kernel is bound by the L1 (64 B/clk/CU = its MFMA time at two waves per SIMD).
+//
+// Wzb [tile][step t][plane][lane][8 bf16]: element e of lane (r, half) = Wz[tile][slot row r][column half*64 + 8 t + e].
+static __global__ __launch_bounds__(256) void cin_qs_pack_wz_kernel(const float* __restrict__ Wz1, const float* __restrict__ Wz2, u32x4* __restrict__ Wzb1,
+                                                                    u32x4* __restrict__ Wzb2, int tiles) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int per = tiles * 512;
+  if (idx >= 2 * per) return;
+  const int which = idx >= per ? 1 : 0;
+  const int i = idx - which * per;
+  const int lane = i & 63, t = (i >> 6) & 7, tile = i >> 9;
+  const int r = lane & 31, half = lane >> 5;
+  const float* src = (which ? Wz2 : Wz1) + ((long)tile * 32 + r) * 128 + half * 64 + 8 * t;
+  const f32x4s lo = *reinterpret_cast<const f32x4s*>(src), hi = *reinterpret_cast<const f32x4s*>(src + 4);
+  const float p[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  u32x4 a[3];
+  split3(p, a);
+  u32x4* dst = (which ? Wzb2 : Wzb1) + ((long)(tile * 8 + t) * 3) * 64 + lane;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) dst[pl * 64] = a[pl];
+}
+
+template <int JT, int G>
+__global__ __launch_bounds__(256, 2) void cin_dz2_b_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
+                                                           const float* __restrict__ dsc, int ldp, int K, const u32x4* __restrict__ Wzb1,
+                                                           const u32x4* __restrict__ Wzb2, const float* __restrict__ xT, float* __restrict__ dxT,
+                                                           int accumulate, int M, int F, int H1, int H2, int periods, int FR,
+                                                           float* __restrict__ dx, const float* __restrict__ cvec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [FR][128 rows][2]
+  constexpr int P = JT / gcd_c(16, JT);
+  constexpr int HPP = 16 * P / JT;
+  constexpr int NT = 8;                                // MFMA steps per tile (16 columns each: 8 per wave half)
+  constexpr int FS = kDz2FieldStride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int wrow0 = (blockIdx.x * 4 + wave) * 32;
+  if (wrow0 >= M) return;   // (no workgroup barriers in this kernel)
+  float* lrow = smem + (wave * 32 + r) * 2;            // this lane's row: field f at lrow[f*FS + {0: x, 1: dX}]
+  const int m = wrow0 + r;
+  const bool vq = m < M;
+  const long mq = vq ? m : M - 1;
+  f32x4s gq[16];
+  {
+    const f32x4s* grow4 = reinterpret_cast<const f32x4s*>(g1T + mq * HS + half * 64);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) gq[s4] = grow4[s4];
+  }
+  for (int f0 = half; f0 < FR; f0 += 16) {
+    float xt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xt[u] = xT[mq * F + min(f0 + 2 * u, F - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + 2 * u;
+      if (f < FR) {
+        const int keep = (vq && f < F) ? -1 : 0;
+        *reinterpret_cast<float2*>(lrow + f * FS) = make_float2(__builtin_bit_cast(float, __builtin_bit_cast(int, xt[u]) & keep), 0.f);
+      }
+    }
+  }
+  float dpl;
+  {
+    const long bb = mq / K;
+    dpl = dsc[bb * ldp + (mq - bb * K)];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const long wbytes = ((long)periods * P + 1) * NT * 3 * 1024;
+  const int wo = lane * 16;
+  // B operand of the current pass: the lane's half row (columns past the layer's width and rows past M zeroed; pass 1: scaled by dP_L),
+  // cut into the planes of the tile's eight steps
+  u32x4 gpl[NT][3];
+  auto to_gpl = [&](const f32x4s (&gv4)[16], int Hk, float sc) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float p[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int keep = (vq && half * 64 + 8 * t + e < Hk) ? -1 : 0;
+        const float gv = gv4[2 * t + (e >> 2)][e & 3];   // (a copy: __builtin_bit_cast on the vector ELEMENT expression reads element 0 for every e)
+        p[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, gv) & keep) * sc;
+      }
+      split3(p, gpl[t]);
+    }
+  };
+  to_gpl(gq, H1, 1.f);
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* gT = pass == 0 ? g1T : g2T;
+    const int Hk = pass == 0 ? H1 : H2;
+    const float sc = pass == 0 ? 1.f : dpl;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(reinterpret_cast<const float*>(pass == 0 ? Wzb1 : Wzb2), wbytes);
+    auto ldw = [&](int t, int st, int pl) {   // step st of tile t
+      return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wo + pl * 1024, (t * NT + st) * 3072, 0));
+    };
+    constexpr int QD = 4;   // queue depth in steps (half a tile)
+    u32x4 q[QD][3];
+#pragma unroll
+    for (int st = 0; st < QD; ++st)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) q[st][pl] = ldw(0, st, pl);
+    if (pass == 1) {
+      const f32x4s* grow4 = reinterpret_cast<const f32x4s*>(gT + mq * HS + half * 64);
+      f32x4s g2[16];
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) g2[s4] = grow4[s4];
+      to_gpl(g2, Hk, sc);
+    }
+    float gx = 0.f;
+    f32x16 dprev;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dprev[i] = 0.f;
+    float xprev[HPP], xcur[HPP];
+#pragma unroll
+    for (int hl = 0; hl < HPP; ++hl) xprev[hl] = xcur[hl] = 0.f;
+    int hprev = 0;
+    float2 lv[G];
+    float* la[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      lv[k] = make_float2(0.f, 0.f);
+      la[k] = lrow;
+    }
+    float *abase = lrow, *awrap = lrow;
+    int symh = 0;
+    auto sym_period = [&](int hb) {
+      symh = hb + half;
+      abase = lrow + symh * FS;
+      awrap = abase - F * FS;
+    };
+    auto slot_fetch = [&](int tp, int rr, int k) {
+      const int sp = 16 * tp + rr;
+      const int off = sp / JT + 2 * (sp % JT);
+      la[k] = (symh >= F - off ? awrap : abase) + off * FS;
+      lv[k] = *reinterpret_cast<const float2*>(la[k]);
+    };
+    auto slot_apply = [&](const f32x16& d, const float (&xpv)[HPP], int hb, int tp, int rr, int k) {
+      const int sp = 16 * tp + rr;
+      const int hl = sp / JT, j = sp % JT;
+      const float dz = d[rr];
+      gx = fmaf(dz, lv[k].x, gx);
+      la[k][1] = fmaf(dz, xpv[hl], lv[k].y);
+      if (j == JT - 1) {
+        const float t = lane_halves_sum(gx);
+        gx = 0.f;
+        if (half == 0) __hip_atomic_fetch_add(lrow + (hb + hl) * FS + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    };
+    sym_period(hprev);
+#pragma unroll
+    for (int k = 0; k < G; ++k) slot_fetch(P - 1, k, k);
+    // slots per step: the previous tile's 16 slots are contracted over this tile's 8 steps, in blocks of G behind every G/2 steps
+    constexpr int SPB = G >= 2 ? G / 2 : 1;      // steps per block of G slots (G = 1: one slot per half step is not expressible: two per step)
+    static_assert(G == 4 || G == 2, "blocks of two or four slots");
+#pragma unroll 1
+    for (int per = 0; per < periods; ++per) {
+      const int hbase = per * HPP;
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xcur[hl] = lrow[(hbase + hl) * FS];
+#pragma unroll
+      for (int tp = 0; tp < P; ++tp) {
+        const int t = per * P + tp;
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int st = 0; st < NT; ++st) {
+          d = mfma_split(q[st % QD], gpl[st], d);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) q[st % QD][pl] = st + QD < NT ? ldw(t, st + QD, pl) : ldw(t + 1, st + QD - NT, pl);
+          if (st % SPB == SPB - 1) {
+            const int blk = st / SPB;   // block of G slots: blk*G .. blk*G + G-1
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+              const int rr = blk * G + k;
+              if (tp == 0) slot_apply(dprev, xprev, hprev, P - 1, rr, k);
+              else slot_apply(dprev, xcur, hbase, tp - 1, rr, k);
+            }
+            if (blk * G + G < 16) {
+#pragma unroll
+              for (int k = 0; k < G; ++k) slot_fetch(tp == 0 ? P - 1 : tp - 1, blk * G + G + k, k);
+            } else {
+              if (tp == 0) sym_period(hbase);
+#pragma unroll
+              for (int k = 0; k < G; ++k) slot_fetch(tp, k, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        dprev = d;
+      }
+#pragma unroll
+      for (int hl = 0; hl < HPP; ++hl) xprev[hl] = xcur[hl];
+      hprev = hbase;
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += G) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) slot_apply(dprev, xprev, hprev, P - 1, r0 + k, k);
+      if (r0 + G < 16) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) slot_fetch(P - 1, r0 + G + k, k);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  cin_dz2_finish(smem, wave, lane, wrow0, M, F, K, dsc, ldp, dxT, accumulate, dx, cvec);
+}
+
+bool cin_launch_dz2_b(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const u32x4* Wzb1,
+                      const u32x4* Wzb2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods, float* dx,
+                      const float* cvec);
+
 bool cin_launch_fwdq_b(hipStream_t st, int JT, const float* x2T, int XL, const u32x4* Wb, int NT, const float* bias1, const float* wsn, int JTG,
                        const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H, CinHeadFold hf);
 

@@ -17,4 +17,23 @@ bool cin_launch_fwdq_b(hipStream_t st, int JT, const float* x2T, int XL, const u
   return true;
 }
 
+bool cin_launch_dz2_b(hipStream_t st, int JT, const float* g1T, const float* g2T, int HS, const float* dsc, int ldp, int K, const u32x4* Wzb1,
+                      const u32x4* Wzb2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods, float* dx,
+                      const float* cvec) {
+  // (blocks of four slots only: F >= HPP + 2 JT, as cin_launch_dz2 picks them; other shapes keep the exact kernel)
+  if (!(JT >= 4 && F >= cin_dz_h_per_period(JT) + 2 * JT)) return false;
+  const int FR = cin_dz2_rows(F, JT);
+  const size_t sh = (size_t)FR * kDz2FieldStride * sizeof(float);
+#define FIL_Z2B(JTV)                                                                                                                           \
+  case JTV:                                                                                                                                    \
+    if (sh > 48 * 1024)                                                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_dz2_b_kernel<JTV, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    hipLaunchKernelGGL((cin_dz2_b_kernel<JTV, 4>), dim3(cdiv(M, 128)), dim3(kCinThreads), sh, st, g1T, g2T, HS, dsc, ldp, K, Wzb1, Wzb2, xT, dxT,  \
+                       accumulate, M, F, H1, H2, periods, FR, dx, cvec);                                                                       \
+    break;
+  switch (JT) { FIL_Z2B(10) default: return false; }
+#undef FIL_Z2B
+  return true;
+}
+
 }  // namespace fil
