@@ -323,6 +323,7 @@ static size_t dw_part_floats(const CinShape& s) {
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym, s.H[0]).splits * csym * s.H[0]);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), csym + s.F, s.H[0]).splits * (csym + s.F) * s.H[0]);   // quadratic tail: pairs + F single-field rows
   if (s.L == 3) pmax = std::max(pmax, (size_t)cin_dwq_plan(s.M(), csym + s.F, cu_count()).pairs * (csym + s.F) * 256);   // ... merged: 256 columns
+  if (s.L == 3) pmax = std::max(pmax, (size_t)cin_dwqb_plan(s.M(), csym + s.F, cu_count()).splits * (csym + s.F) * 256);  // ... split-bf16: a partial per row split
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.Hp(s.L - 1), s.F).splits * s.Hp(s.L - 1) * s.F);
   pmax = std::max(pmax, (size_t)dw_plan(s.M(), s.F, s.Hp(s.L - 1)).splits * s.Hp(s.L - 1) * s.F);   // (its swapped form)
   const TailGeom g = tail_geom(s);
@@ -838,20 +839,27 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       cin_launch_last_bwd2(st, JT, xT, xpT, xps, qtWsumP, qtWsnP, dPp, (int)LK, dPprev, Gbuf[cur], HS0, dxT, (int)M, F, K, Hpp, qtR, HS0, dPL, small);
     }
     FIL_CHECK_LAUNCH();
+    int dw_parts = 0;   // partials [C][256] the weight-gradient launch leaves
     {
       ProfScope ps("cin_bwd_dw_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
-      const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
-      hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth>), dim3((dp.wgs + 7) / 8 * 8), dim3(kDwqThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD,
-                         dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
+      if (qsplit) {   // split-bf16 operands (cin_qsplit.h): one partial per row split
+        const DwqbPlan bp = cin_dwqb_plan(M, Cl + F, cu_count());
+        cin_launch_dwq_b(st, bp, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD);
+        dw_parts = bp.splits;
+      } else {
+        const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
+        hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth>), dim3((dp.wgs + 7) / 8 * 8), dim3(kDwqThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD,
+                           dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
+        dw_parts = dp.pairs;
+      }
     }
     FIL_CHECK_LAUNCH();
     {
       // fixed-order sums of the partials -> dW1 (both rows of a pair), dT, v^T; + dbias1 from the column sums cin_last_bwd2_kernel left
       ProfScope ps("cin_reduce_dw", st);
-      const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
       const int nb1 = cdiv(H[0], 64);
       const int nh = output_dim == 1 ? cdiv((int)LK + 1, 64) : 0;   // + ddense_w | ddense_b from the head's block partials
-      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F + 3) / 4 + nb1 + nh), dim3(256), 0, st, part, dp.pairs, F, symD, H[0], Hpp, dW[0], qt_dT,
+      hipLaunchKernelGGL(cin_reduce_expand_q_kernel, dim3((Cl + F + 3) / 4 + nb1 + nh), dim3(256), 0, st, part, dw_parts, F, symD, H[0], Hpp, dW[0], qt_dT,
                          vlast, small, ncol, dbias[0], nb1, qt_hpart, qt_ndc, (int)LK, ddense_w, ddense_b);
     }
     FIL_CHECK_LAUNCH();

@@ -455,6 +455,166 @@ bool cin_launch_dz2_b(hipStream_t st, int JT, const float* g1T, const float* g2T
                       const u32x4* Wzb2, const float* xT, float* dxT, int accumulate, int M, int F, int H1, int H2, int periods, float* dx,
                       const float* cvec);
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradients (cin_dwq_kernel's GEMM on split operands): [dW1s | dTs | v^T] = P^T [G1 | x1], reduction over the rows m, 16 per MFMA
+// step.  Wave = 32 channel rows x 256 columns as before.  Operands:
+//   A (generated, channel rows on the lanes): A[c][m] = xe[m,h_c] xe[m,f_c] (columns 0..127), A' = A * xe[m, F+1+sel_c] (128..255) for the
+//     step's 16 rows -- the rows' xe entries come into LDS by LDS-DMA (2.7 KB per step), the lane gathers its three columns there;
+//   B ([G1 | x1], fp32 row-major in memory): a lane needs EIGHT ROWS of one column per plane vector, and cutting a 16 x 256 tile is
+//     ~350 vector instructions -- too many for one wave per step, so the four waves of a half workgroup, which take four channel tiles
+//     of ONE row split, cut each step's tile together (each thread: 2 x 8 values, a column of G1 and one of x1) one step ahead and
+//     hand the planes round through LDS (ring of two 24-KB slots; operands read by ds_read_b128 as in the forward).
+// Step index k = 8 half + e of the MFMA stands for row 16 t + rho(half, e), rho = (e & 3) + 8 (e >> 2) + 4 half (any bijection works
+// as long as A and B agree; this one is the accumulator row order, mfma32_row, of the kernels that produce G1 and x1).
+// Work: item = (row split, group of 4 channel tiles); a workgroup = 8 waves = two items (the halves never exchange data, they share
+// the step barrier); 26 tiles at F = 39 are 6 groups of four and one of two (2 of 28 wave slots idle).  No fold of split pairs (the
+// LDS is the rings'): one partial [C][256] per row split, summed by cin_reduce_expand_q_kernel as before.
+constexpr int kDwqbPlaneSlot = 24 * 1024, kDwqbXeSlot = 4096;
+constexpr int kDwqbHalfBytes = 2 * kDwqbPlaneSlot + 3 * kDwqbXeSlot;   // planes ring (2) + xe ring (3) of one half workgroup
+struct DwqbPlan {
+  int tiles, groups, splits, rows_per_split, items, wgs;
+};
+inline DwqbPlan cin_dwqb_plan(long M, int C, int cus) {
+  DwqbPlan p;
+  p.tiles = (C + 31) / 32;
+  p.groups = (p.tiles + 3) / 4;
+  long want = std::max<long>(1, 2L * cus / p.groups);           // two items per workgroup, one workgroup per CU, all resident at once
+  want = std::max<long>(want, (M + (1L << 20) - 1) >> 20);      // byte offsets inside a split (rows * 512) stay below 2^31
+  const long rows = std::max<long>(16, ((M + want - 1) / want + 15) / 16 * 16);
+  p.rows_per_split = (int)rows;
+  p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
+  p.items = p.groups * p.splits;
+  p.wgs = (p.items + 1) / 2;
+  return p;
+}
+
+template <int XS = 3>   // xe ring slots (a template so that only the translation unit that launches it compiles it)
+__global__ __launch_bounds__(512, 2) void cin_dwq_b_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
+                                                           int XE, float* __restrict__ part, int M, int F, int symD, int rows_per_split, int splits,
+                                                           int groups, int items) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 halves][planes 2 x 24 KB | xe 3 x 4 KB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, half = lane >> 5;
+  const int hg = wave >> 2, w4 = wave & 3;
+  const int Cp = F * symD, C = Cp + F, tiles = (C + 31) >> 5;
+  // XCD-aware work mapping (as cin_dwq_kernel): an XCD streams only its own row splits through its L2
+  const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int item = __builtin_amdgcn_readfirstlane(2 * wg + hg);
+  const bool live = item < items;                    // (a half without an item still walks the steps: the barrier is the workgroup's)
+  const int split = live ? item / groups : 0, grp = live ? item % groups : 0;
+  const int tile = grp * 4 + w4;
+  const bool work = live && tile < tiles;            // (a wave without a tile still cuts its share of the B tiles)
+  const int c0 = tile * 32;
+  const long m_lo = (long)split * rows_per_split;
+  const long mrem = live ? std::max<long>(0, std::min<long>(M, m_lo + rows_per_split) - m_lo) : 0;   // rows past it read as zeros
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(gT + (live ? m_lo * HS : 0), mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t r1 = make_rsrc_uniform(x1T + (live ? m_lo * HS : 0), mrem * HS * 4);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(xe + (live ? m_lo * XE : 0), mrem * XE * 4);
+  unsigned char* hbase = lds + hg * kDwqbHalfBytes;
+  unsigned char* xring = hbase + 2 * kDwqbPlaneSlot;
+  const int steps = rows_per_split >> 4;
+  const int c = c0 + r;
+  const int cc = c < C ? c : C - 1;
+  int hh, ff, sel;
+  if (cc < Cp) {
+    hh = cc / symD;
+    ff = (hh + (cc - hh * symD)) % F;
+    sel = 0;
+  } else {
+    hh = F;
+    ff = cc - Cp;
+    sel = 1;
+  }
+  const int so = F + 1 + sel;
+  auto dma_xe = [&](int t) {   // this wave's 1-KB piece of the step's 16 rows of xe (a slot is 4 KB: the rows and what follows them)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xring + (t % XS) * kDwqbXeSlot + w4 * 1024), 16, lane * 16,
+                                             __builtin_amdgcn_readfirstlane(t * 64 * XE + w4 * 1024), 0, 0);
+  };
+  // this thread's share of a step's B tile: column 4 r + w4 of G1 and of x1, rows rho(half, 0..7)
+  float raw[2][8];
+  const int bvo = (4 * half * HS + 4 * r + w4) * 4;
+  auto load_raw = [&](int t) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int sof = __builtin_amdgcn_readfirstlane((16 * t + (e & 3) + 8 * (e >> 2)) * HS * 4);
+      raw[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, bvo, sof, 0));
+      raw[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, bvo, sof, 0));
+    }
+  };
+  auto cut_raw = [&](int t) {   // -> the planes of step t, ring slot t % 2
+    unsigned char* dst = hbase + (t & 1) * kDwqbPlaneSlot + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 a[3];
+      split3(raw[j], a);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + (pl * 8 + j * 4 + w4) * 1024) = a[pl];
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  dma_xe(0);
+  load_raw(0);
+  dma_xe(1);
+  cut_raw(0);
+  load_raw(1);
+#pragma unroll 1
+  for (int t = 0; t < steps; ++t) {
+    // xe of step t was issued two steps ago; younger operations may stay in flight: the DMA piece and the 16 loads of step t+1
+    asm volatile("s_waitcnt vmcnt(17) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // xe(t) and every wave's planes(t) are in LDS; nobody reads xe slot (t+2)%3 or plane slot (t+1)%2 any more
+    dma_xe(t + 2);
+    cut_raw(t + 1);
+    load_raw(t + 2);
+    if (work) {
+      // A planes of this step from the xe rows in LDS
+      const float* xs = reinterpret_cast<const float*>(xring + (t % XS) * kDwqbXeSlot);
+      float pa[8], pb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* row = xs + ((e & 3) + 8 * (e >> 2) + 4 * half) * XE;
+        pa[e] = row[hh] * row[ff];
+        pb[e] = pa[e] * row[so];
+      }
+      u32x4 a0[3], a1[3];
+      split3(pa, a0);
+      split3(pb, a1);
+      const unsigned char* sb = hbase + (t & 1) * kDwqbPlaneSlot + lane * 16;
+      u32x4 b[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const u32x4*>(sb + (pl * 8) * 1024);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        if (nb + 1 < 8) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[(nb + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(sb + (pl * 8 + nb + 1) * 1024);
+        }
+        acc[nb] = nb < 4 ? mfma_split(a0, b[nb & 1], acc[nb]) : mfma_split(a1, b[nb & 1], acc[nb]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (trailing DMA pieces: nothing may land in LDS after the workgroup is gone)
+  if (!work) return;
+  float* pout = part + (long)split * C * 256;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int cr = c0 + mfma32_row(reg, half);
+    if (cr < C) {
+      float* dst = pout + (long)cr * 256 + 4 * r;
+      if (cr < Cp) *reinterpret_cast<float4*>(dst) = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+      *reinterpret_cast<float4*>(dst + 128) = make_float4(acc[4][reg], acc[5][reg], acc[6][reg], acc[7][reg]);
+    }
+  }
+}
+
+void cin_launch_dwq_b(hipStream_t st, const DwqbPlan& p, const float* gT, const float* x1T, int HS, const float* xe, int XE, float* part, int M, int F,
+                      int symD);
+
 bool cin_launch_fwdq_b(hipStream_t st, int JT, const float* x2T, int XL, const u32x4* Wb, int NT, const float* bias1, const float* wsn, int JTG,
                        const float* cvec, float* x1T, float* RT, int HS, float* pool1, float* pool_p, float* pool_L, int M, int F, int H, CinHeadFold hf);
 

@@ -36,4 +36,12 @@ bool cin_launch_dz2_b(hipStream_t st, int JT, const float* g1T, const float* g2T
   return true;
 }
 
+void cin_launch_dwq_b(hipStream_t st, const DwqbPlan& p, const float* gT, const float* x1T, int HS, const float* xe, int XE, float* part, int M, int F,
+                      int symD) {
+  const size_t sh = (size_t)2 * kDwqbHalfBytes;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cin_dwq_b_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(cin_dwq_b_kernel<3>, dim3((p.wgs + 7) / 8 * 8), dim3(512), sh, st, gT, x1T, HS, xe, XE, part, M, F, symD, p.rows_per_split, p.splits,
+                     p.groups, p.items);
+}
+
 }  // namespace fil
