@@ -422,6 +422,22 @@ def mfma_util(scope):
     return {"mfma_busy_frac": e.get("mfma_busy_frac"), "util_source": "committed profile " + os.path.basename(files[-1])}
 
 
+def split_mfma_util(scope):
+    """MFMA-pipe utilisation of the split-bf16 kernel behind `scope` from the newest committed SQ-counter summary of a --cin-mode 2
+    run (profiles/r*_cin_bf16x3_mfma_util.json, tools/pmc_split.sh); a lookup like mfma_util().  None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_cin_bf16x3_mfma_util.json")))
+    name = {"cin_fwd_q": "cin_fwdq_b_kernel", "cin_bwd_dw_q": "cin_dwq_b_kernel", "cin_bwd_dz_q": "cin_dz2_b_kernel"}.get(scope)
+    if not files or name is None:
+        return None
+    with open(files[-1]) as fh:
+        per = json.load(fh).get("per_launch", {})
+    for k, v in per.items():
+        if k.startswith(name):
+            return {"mfma_busy_frac": v.get("mfma_busy_frac"), "util_source": "committed profile " + os.path.basename(files[-1])}
+    return None
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh children through torch.distributed.run.
     The parent has not touched a GPU (no HIP call, no torch.cuda query) and never will; it relays rank 0's JSON line
@@ -502,6 +518,7 @@ def main():
                          "only feed ms_per_step_windows / _median / _min / _max, so that a 3 %% kernel change can be told from box noise")
     ap.add_argument("--no-graph-replay", action="store_true", help="skip the HIP-graph replay timing of the headline step (profiling runs: "
                     "keeps the number of step iterations the PMC summarisers expect)")
+    ap.add_argument("--no-candidate", action="store_true", help="skip the split-bf16 candidate (FIL_CIN_BF16X3) timed beside the headline")
     ap.add_argument("--stub", default="", help=argparse.SUPPRESS)   # tests: module with install(namespace) -> CPU/gloo stand-ins
     args = ap.parse_args()
     if args.workload in ("deepfm", "xdeepfm"):
@@ -647,6 +664,24 @@ def main():
         if prof_on:
             _lib.profile_end()
 
+    # The LABELLED reduced-operand mode of the same step (fil.h FIL_CIN_BF16X3: the three GEMM launches on split-bf16 operands, six
+    # bf16 MFMAs per product, fp32 accumulate), timed under the headline's protocol AFTER its windows and reported BESIDE it:
+    # `value` / `ms_per_step` above stay the exact-fp32 chain.
+    cand = None
+    if device.type == "cuda" and not use_dist and not args.stub and not args.no_candidate and (args.cin_mode & 2) == 0:
+        try:
+            m2 = args.cin_mode | Fn.CIN_BF16X3
+            for _ in range(args.warmup):
+                step(mode=m2)
+            dt2 = timed_steps(lambda: step(mode=m2), fence, args.steps)
+            _lib.profile_begin(GEMMS)
+            for _ in range(args.steps):
+                step(mode=m2)
+            fence()
+            cand = dict(dt=dt2, prof={k: v for k, v in _lib.profile_end().items() if v.get("executed", 0) > 1e9})
+        except Exception as e:   # (must not take the headline line down with it)
+            print("bench.py: the split-bf16 candidate failed: %r" % (e,), file=sys.stderr)
+
     # collective evidence: the same steps without the all-reduce (exposed = difference) and the collectives alone
     rccl = None
     if use_dist:
@@ -772,6 +807,27 @@ def main():
             res["executed_flops_per_step"] = exe_step
             res["algorithmic_flops_per_step"] = algo_step
             res["executed_frac"] = exe_step / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        if cand is not None:
+            c_ms = cand["dt"] / args.steps * 1e3
+            ck = {k: dict(avg_ms=round(v["avg_ms"], 4), executed_flops_per_launch=v["executed"], bf16_mfma_flops_per_launch=6.0 * v["executed"],
+                          bf16_tflops=round(6.0 * v["executed"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
+                          frac_of_bf16_peak=round(6.0 * v["executed"] / (v["avg_ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4))
+                  for k, v in sorted(cand["prof"].items())}
+            cd = max(ck, key=lambda k: ck[k]["avg_ms"]) if ck else None
+            res["candidate_bf16x3"] = {
+                "what": "the same step with fil.h FIL_CIN_BF16X3: the three GEMM launches on split-bf16 operands (each fp32 operand as three "
+                        "bf16 pieces, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate); holds the parity bars of the exact mode "
+                        "(tests/test_gpu_parity.py, same tests, same bars); reported beside the headline, never as `value`",
+                "ms_per_step": c_ms, "samples_per_s": shape["batch"] * args.steps / cand["dt"], "steps": args.steps, "warmup": args.warmup,
+                "dtype": "bf16x3 (three bf16 pieces per fp32 operand, fp32 accumulate)", "speedup_over_exact": ms_per_step / c_ms,
+                "kernels": ck}
+            if cd is not None:
+                util = split_mfma_util(cd)
+                res["candidate_bf16x3"]["roofline"] = {
+                    "bound": "mfma", "kernel": cd, "achieved": ck[cd]["bf16_tflops"], "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ck[cd]["frac_of_bf16_peak"], "avg_launch_ms": ck[cd]["avg_ms"],
+                    "flops_are": "6 x the executed fp32-equivalent flops (six bf16 MFMAs per product), padding not counted",
+                    **(util or {})}
         if graph_ms is not None:
             res["hipgraph_replay_ms_per_step"] = graph_ms
         if rccl is not None:

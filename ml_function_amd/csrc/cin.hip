@@ -226,7 +226,7 @@ static bool qmerge_used(const CinShape& s, int mode, const CinTune& tune) {
   return qtail_used(s, mode, tune) && 3 * s.F + 3 <= s.HSmax() && (mode & FIL_CIN_NOQMERGE) == 0 && knobs().qmerge != 0;   // (xe | gxR | dxR share one gradient buffer)
 }
 // ... on split-bf16 operands (cin_qsplit.h, FIL_CIN_BF16X3): where the merged kernels run in their full form and a split kernel exists
-static bool qsplit_fwd_menu(int JT) { return JT == 10; }
+static bool qsplit_fwd_menu(int JT) { return JT >= 2 && JT <= 12 && JT % 2 == 0; }   // (F <= 41 on the merged tail: JT <= 12)
 static bool qsplit_used(const CinShape& s, int mode, const CinTune& tune) {
   return (mode & FIL_CIN_BF16X3) != 0 && qmerge_used(s, mode, tune) && knobs().fwdq != 0 && knobs().dz2 != 0 && s.HS(0) == 128 &&
          qsplit_fwd_menu(cin_jt_sym(s.F));

@@ -105,20 +105,21 @@ static __global__ __launch_bounds__(256) void cin_qs_pack_wb_kernel(const float*
 //     registers instead is 24 KB per wave and step: 64 B/clk/CU at two waves per SIMD, the whole L1 bandwidth.
 //   A (generated): the lane keeps a sliding window of its row's wrapped positions (x2T, cin_transpose_in_body) over the period's HPS
 //     values of h -- product, cut, pack: ~60 vector instructions per step, issued in the shadow of the step's 48 MFMAs, one step ahead.
-template <int JT>
-__global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restrict__ x2T, int XL, const u32x4* __restrict__ Wb, int NT,
+template <int JT, int NW>   // NW waves per workgroup: 8 (one workgroup per CU, ring of 4) or 4 (two independent ones per CU, rings of 3)
+__global__ __launch_bounds__(64 * NW, 2) void cin_fwdq_b_kernel(const float* __restrict__ x2T, int XL, const u32x4* __restrict__ Wb, int NT,
                                                             const float* __restrict__ bias1, const float* __restrict__ wsn, int JTG,
                                                             const float* __restrict__ cvec, float* __restrict__ x1T, float* __restrict__ RT, int HS,
                                                             float* __restrict__ pool1, float* __restrict__ pool_p, float* __restrict__ pool_L, int M, int F,
                                                             int H, CinHeadFold hf) {
   using G = QsGeo<JT>;
-  constexpr int HPS = G::HPS, KP = G::KP, WS = G::WS, NS = kQsStages, SB = kQsStageBytes;
+  constexpr int HPS = G::HPS, KP = G::KP, WS = G::WS, NS = NW == 8 ? kQsStages : 3, SB = kQsStageBytes;
+  constexpr int PW = 24 / NW;                                            // 1-KB DMA pieces of a step per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];   // [NS][SB]
-  __shared__ float lin_s[8][32];
-  __shared__ float pv_s[8][3][32];
+  __shared__ float lin_s[NW][32];
+  __shared__ float pv_s[NW][3][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
-  const int wrow0 = (blockIdx.x * 8 + wave) * 32;
+  const int wrow0 = (blockIdx.x * NW + wave) * 32;
   const bool active = wrow0 < M;   // (a wave past the end still takes part in the ring: DMA pieces, barriers)
   const int wrow_u = __builtin_amdgcn_readfirstlane(wrow0);
   // this wave's half of its 64-row block of the wrapped rows ([p][64 rows]); an inactive wave reads zeros
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
   auto ldx = [&](int voff, int p) {   // wrapped position p (uniform) of the lane's row
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, __builtin_amdgcn_readfirstlane(p) * 256, 0));
   };
-  auto dma = [&](int t) {   // this wave's three pieces of step t -> ring slot t % NS
-    unsigned char* dst = ring + (t % NS) * SB + wave * 3072;
-    const int so = __builtin_amdgcn_readfirstlane(t * SB + wave * 3072);
+  auto dma = [&](int t) {   // this wave's PW pieces of step t -> ring slot t % NS
+    unsigned char* dst = ring + (t % NS) * SB + wave * (PW * 1024);
+    const int so = __builtin_amdgcn_readfirstlane(t * SB + wave * (PW * 1024));
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < PW; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, lane * 16, so + q * 1024, 0, 0);
   };
 
@@ -177,18 +178,19 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
   make_a(0, acur);
   const int nper = NT / KP;
   const int ldsb = lane * 16;
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step 0's pieces (the in-loop wait of a period's first step allows for window loads
-                                                     // that the very first period has not issued)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");   // step 0's pieces (the in-loop wait of a period's first step allows
+                                                                         // for window loads that the very first period has not issued)
 #pragma unroll 1
   for (int per = 0; per < nper; ++per) {
     const int h0 = per * HPS;
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) {
       const int t = per * KP + kk;
-      // Step t's pieces were issued three steps ago; younger vector-memory operations may stay in flight: the DMA pieces of steps
-      // t+1, t+2 (6) and, for the two steps after a period's first one, the window loads issued there in front of its DMA (2 HPS).
-      if (kk == 1 || kk == 2 || (kk == 0 && KP == 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * HPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // Step t's pieces were issued NS-1 steps ago; younger vector-memory operations may stay in flight: the DMA pieces of the NS-2
+      // steps behind it and, for the NS-2 steps after a period's first one, the window loads issued there in front of its DMA (2 HPS).
+      const int since = kk == 0 ? KP : kk;   // steps since the last window loads (compile-time once the step loop is unrolled)
+      if (since <= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW + 2 * HPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
       __builtin_amdgcn_s_barrier();   // every wave's pieces of step t have landed, and every wave is done reading slot (t - 1) % NS
       if (kk == 0) {
         // the next period's x[m, h] values and the HPS window entries that slide in (positions past XL / rows of an inactive wave: zeros)
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void cin_fwdq_b_kernel(const float* __restr
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the trailing DMA pieces: nothing may land in LDS after the workgroup is gone)
   if (!active) return;   // (no workgroup barriers below)
-  cin_fwdq_epilogue<8>(acc, rx, vhalf, wo, r, half, wave, wrow0, bias1, wsn, JTG, cvec, x1T, RT, HS, pool1, pool_p, pool_L, M, F, H, hf, lin_s, pv_s);
+  cin_fwdq_epilogue<NW>(acc, rx, vhalf, wo, r, half, wave, wrow0, bias1, wsn, JTG, cvec, x1T, RT, HS, pool1, pool_p, pool_L, M, F, H, hf, lin_s, pv_s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -466,9 +468,12 @@ bool cin_launch_dz2_b(hipStream_t st, int JT, const float* g1T, const float* g2T
 //     hand the planes round through LDS (ring of two 24-KB slots; operands read by ds_read_b128 as in the forward).
 // Step index k = 8 half + e of the MFMA stands for row 16 t + rho(half, e), rho = (e & 3) + 8 (e >> 2) + 4 half (any bijection works
 // as long as A and B agree; this one is the accumulator row order, mfma32_row, of the kernels that produce G1 and x1).
-// Work: item = (row split, group of 4 channel tiles); a workgroup = 8 waves = two items (the halves never exchange data, they share
-// the step barrier); 26 tiles at F = 39 are 6 groups of four and one of two (2 of 28 wave slots idle).  No fold of split pairs (the
-// LDS is the rings'): one partial [C][256] per row split, summed by cin_reduce_expand_q_kernel as before.
+// Work: item = (row split, group of 4 channel tiles) = one workgroup of 4 waves, TWO workgroups per CU (60 KB of LDS each).  They
+// are independent (a barrier per step inside each), so their steps drift apart and one's vector phase -- the cut of the next B tile,
+// the A planes: ~250 instructions between the barrier and the first MFMA -- runs under the other's MFMAs on the same SIMDs (as ONE
+// 8-wave workgroup sharing the barrier the two waves of a SIMD were in step and the matrix pipe idled through that phase: 178 us).
+// 26 tiles at F = 39 are 6 groups of four and one of two (2 of 28 wave slots idle).  No fold of split pairs (the LDS is the rings'):
+// one partial [C][256] per row split, summed by cin_reduce_expand_q_kernel as before.
 constexpr int kDwqbPlaneSlot = 24 * 1024, kDwqbXeSlot = 4096;
 constexpr int kDwqbHalfBytes = 2 * kDwqbPlaneSlot + 3 * kDwqbXeSlot;   // planes ring (2) + xe ring (3) of one half workgroup
 struct DwqbPlan {
@@ -478,29 +483,30 @@ inline DwqbPlan cin_dwqb_plan(long M, int C, int cus) {
   DwqbPlan p;
   p.tiles = (C + 31) / 32;
   p.groups = (p.tiles + 3) / 4;
-  long want = std::max<long>(1, 2L * cus / p.groups);           // two items per workgroup, one workgroup per CU, all resident at once
+  long want = std::max<long>(1, 2L * cus / p.groups);           // one item per workgroup, two workgroups per CU, all resident at once
   want = std::max<long>(want, (M + (1L << 20) - 1) >> 20);      // byte offsets inside a split (rows * 512) stay below 2^31
   const long rows = std::max<long>(16, ((M + want - 1) / want + 15) / 16 * 16);
   p.rows_per_split = (int)rows;
   p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
   p.items = p.groups * p.splits;
-  p.wgs = (p.items + 1) / 2;
+  p.wgs = p.items;
   return p;
 }
 
 template <int XS = 3>   // xe ring slots (a template so that only the translation unit that launches it compiles it)
-__global__ __launch_bounds__(512, 2) void cin_dwq_b_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
+__global__ __launch_bounds__(256, 2) void cin_dwq_b_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
                                                            int XE, float* __restrict__ part, int M, int F, int symD, int rows_per_split, int splits,
                                                            int groups, int items) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2 halves][planes 2 x 24 KB | xe 3 x 4 KB]
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // planes 2 x 24 KB | xe 3 x 4 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, half = lane >> 5;
-  const int hg = wave >> 2, w4 = wave & 3;
+  const int w4 = wave;
   const int Cp = F * symD, C = Cp + F, tiles = (C + 31) >> 5;
   // XCD-aware work mapping (as cin_dwq_kernel): an XCD streams only its own row splits through its L2
   const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int item = __builtin_amdgcn_readfirstlane(2 * wg + hg);
-  const bool live = item < items;                    // (a half without an item still walks the steps: the barrier is the workgroup's)
+  const int item = wg;
+  if (item >= items) return;                         // (whole workgroup)
+  const bool live = true;
   const int split = live ? item / groups : 0, grp = live ? item % groups : 0;
   const int tile = grp * 4 + w4;
   const bool work = live && tile < tiles;            // (a wave without a tile still cuts its share of the B tiles)
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void cin_dwq_b_kernel(const float* __restri
   const __amdgpu_buffer_rsrc_t rg = make_rsrc_uniform(gT + (live ? m_lo * HS : 0), mrem * HS * 4);
   const __amdgpu_buffer_rsrc_t r1 = make_rsrc_uniform(x1T + (live ? m_lo * HS : 0), mrem * HS * 4);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc_uniform(xe + (live ? m_lo * XE : 0), mrem * XE * 4);
-  unsigned char* hbase = lds + hg * kDwqbHalfBytes;
+  unsigned char* hbase = lds;
   unsigned char* xring = hbase + 2 * kDwqbPlaneSlot;
   const int steps = rows_per_split >> 4;
   const int c = c0 + r;

@@ -83,9 +83,19 @@ def _cin_run(c, mode, with_grad=True):
     return out.detach(), x.grad, [w.grad for w in Ws]
 
 
-# ---- dynamic range, subnormals, non-finite inputs (written in round 2 to decide whether the split-bf16 experiment could be promoted;
-# ---- the experiment is retired, the cases stay for the exact path: 0 = headline, 8 = FIL_CIN_NOSYM, the general first-layer kernels)
-@pytest.mark.parametrize("mode", [0, 8])
+# ---- dynamic range, subnormals, non-finite inputs: 0 = headline (exact), 8 = FIL_CIN_NOSYM, the general first-layer kernels,
+# ---- 66 = FIL_CIN_BF16X3 | TAIL_ALWAYS: the labelled split-bf16 mode of the merged quadratic tail (csrc/cin_qsplit.h) at the SAME bars
+SPLIT = 2 | 64     # (TAIL_ALWAYS: small batches reach the merged quadratic tail, whose GEMMs the bit re-routes; F = 39 is in its kernel menu)
+
+
+def _assert_split_kernels_ran(c, res_split):
+    """The bit selects something only inside the split kernels' menu: the same case on the exact merged tail must differ in its
+    last bits (other kernels, other summation order) -- a silent fall-back would be bit-identical."""
+    out, dx, dWs = _cin_run(c, 64)
+    assert not torch.equal(out, res_split[0]) or not torch.equal(dx, res_split[1])
+
+
+@pytest.mark.parametrize("mode", [0, 8, SPLIT])
 @pytest.mark.parametrize("exp10", [-9, -6, -3, 3, 5])
 def test_cin_extreme_magnitudes(mode, exp10):
     """Inputs scaled by 10^e (per-field spread of three more decades on top): the feature maps then sit at ~10^(2e), 10^(3e)
@@ -95,6 +105,8 @@ def test_cin_extreme_magnitudes(mode, exp10):
     rng = np.random.default_rng(5)
     c["x"] = (c["x"] * 10.0 ** exp10 * 10.0 ** rng.uniform(-1.5, 1.5, size=(1, F, 1))).astype(np.float32)
     out, dx, dWs = _cin_run(c, mode)
+    if mode == SPLIT and exp10 == -3:
+        _assert_split_kernels_ran(c, (out, dx, dWs))
     want = closed.cin_fwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["dense_b"], 1)
     gx, gWs, _, _, _ = closed.cin_bwd(c["x"], c["Ws"], c["bs"], c["dense_w"], c["g"], 1)
     check("magnitude 1e%d out" % exp10, out, want, tol=1e-5)
@@ -103,12 +115,12 @@ def test_cin_extreme_magnitudes(mode, exp10):
         check("magnitude 1e%d dW%d" % (exp10, l), dWs[l], gWs[l], tol=2e-5)
 
 
-@pytest.mark.parametrize("mode", [0, 8])
+@pytest.mark.parametrize("mode", [0, 8, SPLIT])
 def test_cin_subnormal_inputs(mode):
     """Every third field holds fp32 subnormals (1e-39..1e-44), the rest ordinary values: the subnormal fields' products are
     far below the others' rounding error, so the bar must still be met; and a batch of ONLY subnormals gives the
     bias-only answer (finite, equal to the oracle's at the bar)."""
-    B, F, K, conv = 24, 12, 8, [32, 48, 16]
+    B, F, K, conv = (24, 39, 8, [32, 48, 16]) if mode == SPLIT else (24, 12, 8, [32, 48, 16])
     c = synth.cin_case(B, F, K, conv, dist="normal")
     rng = np.random.default_rng(6)
     tiny = (10.0 ** rng.uniform(-44, -39, size=(B, F, K)) * np.sign(c["x"])).astype(np.float32)
@@ -128,11 +140,11 @@ def test_cin_subnormal_inputs(mode):
                 check("subnormal dW%d" % l, dWs[l], gWs[l], tol=2e-5)
 
 
-@pytest.mark.parametrize("mode", [0, 8])
+@pytest.mark.parametrize("mode", [0, 8, SPLIT])
 def test_cin_nonfinite_inputs_stay_in_their_samples(mode):
     """+-inf / NaN in single samples: a bad sample poisons its own output and dx rows (and the weight gradients), nothing else --
     the good samples return the same values as a run without the bad ones."""
-    B, F, K, conv = 16, 10, 8, [32, 32, 16]
+    B, F, K, conv = (16, 39, 8, [32, 32, 16]) if mode == SPLIT else (16, 10, 8, [32, 32, 16])
     c = synth.cin_case(B, F, K, conv, dist="normal")
     bad = c["x"].copy()
     bad[3, 2, 1] = np.inf
@@ -377,7 +389,8 @@ def _tail_case(B, F, K, conv, output_dim, mode):
 @pytest.mark.parametrize("B,F,K,conv", TAIL_SHAPES)
 # 64: three-layer nets take the quadratic tail with merged weight gradients (cin_qtail.h, cin_qmerge.h), the others the fused tail;
 # | 512: FIL_CIN_NOQMERGE -- the quadratic tail with two weight-gradient launches; | 256: FIL_CIN_NOQTAIL -- the F+1-column fused tail
-@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 512), (1, 64 | 256)])
+# | 2: FIL_CIN_BF16X3 -- the merged quadratic tail's GEMMs on split-bf16 operands where such kernels exist (else the exact ones)
+@pytest.mark.parametrize("output_dim,mode", [(1, 64), (2, 64), (1, 64 | 512), (1, 64 | 256), (1, 64 | 2), (2, 64 | 2)])
 def test_cin_fused_tail(B, F, K, conv, output_dim, mode):
     _tail_case(B, F, K, conv, output_dim, mode)
 
@@ -542,8 +555,9 @@ def _run_bench_shape(c, output_dim, mode, reps=1):
 
 
 # 0 = headline (quadratic tail, merged weight gradients), 512 = quadratic tail with two weight-gradient launches, 256 = F+1-column
-# fused tail, 32 = last-layer shortcut only (the round-2 headline), 1 = general kernels for every layer
-@pytest.mark.parametrize("mode", [0, 1, 32, 256, 512])
+# fused tail, 32 = last-layer shortcut only (the round-2 headline), 1 = general kernels for every layer, 2 = FIL_CIN_BF16X3: the
+# headline's three GEMM launches on split-bf16 operands (the labelled mode), held to the SAME bars
+@pytest.mark.parametrize("mode", [0, 1, 32, 256, 512, 2])
 def test_cin_at_the_benchmark_shape(mode):
     """The launch configuration bench.py times (M = B*K = 65,536 rows: 64-row waves, the weight-gradient split plans and XCD mapping
     of that size, the tails' kernels) against the fp64 oracle -- every output and every gradient, all 4096 samples."""
@@ -560,7 +574,7 @@ def test_cin_at_the_benchmark_shape(mode):
     report("c4 at B=4096, mode %d (bar 1e-5 on everything)" % mode)
 
 
-@pytest.mark.parametrize("mode", [0, 512, 256, 1])
+@pytest.mark.parametrize("mode", [0, 512, 256, 1, 2])
 def test_cin_at_the_benchmark_shape_deep_layers(mode):
     """B = 4096 with inputs x10, biases ~0.1 and output_dim = 2: each layer's pooled block [B, K] is compared with the fp64 oracle ON ITS
     OWN NORM (a 0.1 % error in the third layer's forward is 1e-3 here, not 5e-6 of the whole output), and so is every gradient."""
@@ -568,7 +582,7 @@ def test_cin_at_the_benchmark_shape_deep_layers(mode):
     del MEASURED[:]
     out, dx, dW, dbias, _, _ = _run_bench_shape(o["c"], 2, mode)
     K = 16
-    gt = 1e-5 if mode in (0, 512) else 2e-5      # north_star's bar on the paths the benchmark can take; the comparison paths (F+1-column
+    gt = 1e-5 if mode in (0, 512, 2) else 2e-5      # north_star's bar on the paths the benchmark can take; the comparison paths (F+1-column
     for l in range(3):                           # fused tail, general kernels) measure 1.4e-5 on one bias gradient of these x10 inputs
         check("deep pooled block %d" % l, out[:, l * K:(l + 1) * K], o["out"][:, l * K:(l + 1) * K])
     check("deep dx", dx, o["dx"], tol=gt)
@@ -578,7 +592,7 @@ def test_cin_at_the_benchmark_shape_deep_layers(mode):
     report("c4 deep layers at B=4096, mode %d (bar %.0e)" % (mode, gt))
 
 
-@pytest.mark.parametrize("mode", [0, 512])
+@pytest.mark.parametrize("mode", [0, 512, 2])
 def test_cin_at_twice_the_benchmark_batch(mode):
     """B = 8192 (131,072 rows: the next launch configuration up -- more row splits, two workgroup rounds) = the benchmark batch followed
     by the same samples in reverse order, against the SAME fp64 oracle: outputs and dx repeat, parameter gradients double."""
