@@ -265,6 +265,22 @@ int fil_score_add_sigmoid_fwd(const float* a, const float* b, const float* c, co
 int fil_score_add_sigmoid_bwd(const float* out, const float* dout, float* dsum, int n, void* stream);
 int fil_bce_mean_fwd(const float* p, const float* y, float eps, float* loss, float* dp, int n, void* stream);
 
+/* MergeScoreLayer.call (core_layer/core_layer.py:86-100): StackLayer concat of the n_parts (1..4) tensors parts[i] [B, widths[i]] ->
+ * Dense(O <= 8 units, softmax): out [B, O] = softmax(concat(parts) W + bias), W [D = sum widths, O] row-major (the Keras Dense kernel),
+ * bias [O].  DeepFM / DCN / Wide&Deep end in it (model/models.py:87,104).  ONE launch each way, the parts read where they lie (no
+ * concatenated copy).  dtype = storage type of the parts and of dparts (FIL_F32 or FIL_BF16: a model under bf16 autocast hands bf16
+ * activations); W, bias, out, dout, dW, db are fp32 and so is the arithmetic.
+ *   bwd: dz = out (dout - <dout, out>); dparts[i] [B, widths[i]] = dz W_i^T (entries / the array may be NULL: not wanted);
+ *        dW [D, O] = concat(parts)^T dz, db [O] = column sums of dz -- block partials summed in block order by the last workgroup to
+ *        finish (a ticket): deterministic.  workspace: fil_merge_softmax_bwd_workspace_bytes(B, D, O) bytes whose FIRST WORD IS ZERO
+ *        on entry (the ticket; the kernel leaves it at zero again, so a zero-initialised buffer can be reused call after call). */
+size_t fil_merge_softmax_bwd_workspace_bytes(int B, int D, int O);
+int fil_merge_softmax_fwd(const void* const* parts, const int* widths, int n_parts, const float* W, const float* bias, float* out, int B,
+                          int O, int dtype, void* stream);
+int fil_merge_softmax_bwd(const void* const* parts, const int* widths, int n_parts, const float* W, const float* out, const float* dout,
+                          void* const* dparts, float* dW, float* db, int B, int O, int dtype, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,140 @@ __global__ __launch_bounds__(1024) void bce_mean_fwd_kernel(const float* __restr
   if (threadIdx.x == 0) loss[0] = red[0] * inv_n;
 }
 
+
+// ---- MergeScoreLayer (core_layer/core_layer.py:86-100): StackLayer concat of the [B, w_i] parts -> Dense(O, softmax).  DeepFM / DCN end
+// in it (model/models.py:87,104).  torch: cat, GEMM [B,D]x[D,O] (O = 2), bias add, softmax and their backward: ~12 launches for 4 KB
+// of output.  Here ONE launch each way: the parts are read where they lie (no concatenated copy), fp32 or bf16 storage, fp32 math.
+constexpr int kMergeMaxO = 8;       // Dense units of the head
+constexpr int kMergeRows = 64;      // samples per workgroup of the backward
+struct MergeParts {
+  const void* p[4];
+  void* dp[4];
+  int w[4];        // widths; 0 = unused
+  int D;           // sum of the widths
+};
+template <typename T>
+__device__ __forceinline__ float merge_ld(const void* p, long i) { return (float)reinterpret_cast<const T*>(p)[i]; }
+template <typename T>
+__device__ __forceinline__ void merge_st(void* p, long i, float v) { reinterpret_cast<T*>(p)[i] = (T)v; }
+
+// out[b, :] = softmax(concat_i parts_i[b, :] W + bias): a wave per sample (lanes over the D columns, O dot products folded by the wave)
+template <typename T>
+__global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                float* __restrict__ out, int B, int O) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float z[kMergeMaxO];
+#pragma unroll
+  for (int o = 0; o < kMergeMaxO; ++o) z[o] = 0.f;
+  int d0 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = mp.w[i];
+    for (int d = lane; d < w; d += 64) {
+      const float x = merge_ld<T>(mp.p[i], (long)b * w + d);
+      const float* wr = W + (long)(d0 + d) * O;
+#pragma unroll
+      for (int o = 0; o < kMergeMaxO; ++o)
+        if (o < O) z[o] = fmaf(x, wr[o], z[o]);
+    }
+    d0 += w;
+  }
+#pragma unroll
+  for (int o = 0; o < kMergeMaxO; ++o) z[o] = wave_sum(z[o]);
+  if (lane == 0) {
+    float m = -INFINITY;
+    for (int o = 0; o < O; ++o) {
+      z[o] += bias[o];
+      m = fmaxf(m, z[o]);
+    }
+    float den = 0.f;
+    for (int o = 0; o < O; ++o) {
+      z[o] = expf(z[o] - m);
+      den += z[o];
+    }
+    for (int o = 0; o < O; ++o) out[(long)b * O + o] = z[o] / den;
+  }
+}
+
+// dz = out (dout - <dout, out>);  dparts_i[b, d] = sum_o dz[b, o] W[d, o];  block partials of dW[d, o] = sum_b x[b, d] dz[b, o] and
+// db[o] = sum_b dz[b, o] over the workgroup's kMergeRows samples (fixed order); the LAST workgroup to finish (a ticket) sums the
+// partials in block order -- a fixed order whoever that workgroup is -- into dW | db and re-arms the ticket.
+template <typename T>
+__global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, const float* __restrict__ W, const float* __restrict__ out,
+                                                                const float* __restrict__ dout, float* __restrict__ part, unsigned* __restrict__ ticket,
+                                                                float* __restrict__ dW, float* __restrict__ db, int B, int O) {
+  __shared__ float dz[kMergeRows][kMergeMaxO];
+  __shared__ unsigned last;
+  const int tid = threadIdx.x, b0 = blockIdx.x * kMergeRows, nrow = min(kMergeRows, B - b0), D = mp.D;
+  for (int s = tid; s < kMergeRows; s += 256) {
+    float dot = 0.f, p[kMergeMaxO], g[kMergeMaxO];
+#pragma unroll
+    for (int o = 0; o < kMergeMaxO; ++o) {
+      p[o] = (s < nrow && o < O) ? out[(long)(b0 + s) * O + o] : 0.f;
+      g[o] = (s < nrow && o < O) ? dout[(long)(b0 + s) * O + o] : 0.f;
+      dot = fmaf(p[o], g[o], dot);
+    }
+#pragma unroll
+    for (int o = 0; o < kMergeMaxO; ++o) dz[s][o] = p[o] * (g[o] - dot);
+  }
+  __syncthreads();
+  float* mypart = part + (long)blockIdx.x * (D + 1) * O;
+  int d0 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = mp.w[i];
+    for (int d = tid; d < w; d += 256) {
+      float wr[kMergeMaxO], acc[kMergeMaxO];
+#pragma unroll
+      for (int o = 0; o < kMergeMaxO; ++o) {
+        wr[o] = o < O ? W[(long)(d0 + d) * O + o] : 0.f;
+        acc[o] = 0.f;
+      }
+      for (int s = 0; s < nrow; ++s) {
+        const float x = merge_ld<T>(mp.p[i], (long)(b0 + s) * w + d);
+        float dx = 0.f;
+#pragma unroll
+        for (int o = 0; o < kMergeMaxO; ++o) {
+          acc[o] = fmaf(x, dz[s][o], acc[o]);
+          dx = fmaf(dz[s][o], wr[o], dx);
+        }
+        if (mp.dp[i] != nullptr) merge_st<T>(mp.dp[i], (long)(b0 + s) * w + d, dx);
+      }
+      for (int o = 0; o < O; ++o) mypart[(long)(d0 + d) * O + o] = acc[o];
+    }
+    d0 += w;
+  }
+  if (tid < O) {
+    float t = 0.f;
+    for (int s = 0; s < nrow; ++s) t += dz[s][tid];
+    mypart[(long)D * O + tid] = t;
+  }
+  // release this workgroup's partials, take a ticket; the last one acquires and reduces
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last == 0u) return;
+  __threadfence();
+  const int n = (D + 1) * O;
+  for (int i = tid; i < n; i += 256) {
+    float t0 = 0.f, t1 = 0.f;
+    unsigned blk = 0;
+    for (; blk + 1 < gridDim.x; blk += 2) {
+      t0 += __builtin_nontemporal_load(part + (long)blk * n + i);
+      t1 += __builtin_nontemporal_load(part + (long)(blk + 1) * n + i);
+    }
+    if (blk < gridDim.x) t0 += __builtin_nontemporal_load(part + (long)blk * n + i);
+    const float v = t0 + t1;
+    if (i < D * O) dW[i] = v;
+    else db[i - D * O] = v;
+  }
+  if (tid == 0) *ticket = 0u;   // (re-armed for the next call on this stream)
+}
+
 }  // namespace fil
 
 using namespace fil;
@@ -92,6 +226,70 @@ extern "C" int fil_bce_mean_fwd(const float* p, const float* y, float eps, float
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("bce_fwd", st, 4.0 * n * (dp != nullptr ? 3 : 2));
   hipLaunchKernelGGL(bce_mean_fwd_kernel, dim3(1), dim3(1024), 0, st, p, y, eps, loss, dp, n);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+static int merge_check(const char* fn, const void* const* parts, const int* widths, int n_parts, int B, int O, int dtype, MergeParts& mp) {
+  if (B < 0 || n_parts < 1 || n_parts > 4 || O < 1 || O > kMergeMaxO || parts == nullptr || widths == nullptr)
+    return fail(FIL_ERR_ARG, "%s: B=%d, %d parts (1..4), %d units (1..%d)", fn, B, n_parts, O, kMergeMaxO);
+  if (dtype != FIL_F32 && dtype != FIL_BF16) return fail(FIL_ERR_ARG, "%s: dtype %d (f32 or bf16 storage)", fn, dtype);
+  mp.D = 0;
+  for (int i = 0; i < 4; ++i) {
+    mp.p[i] = i < n_parts ? parts[i] : nullptr;
+    mp.dp[i] = nullptr;
+    mp.w[i] = i < n_parts ? widths[i] : 0;
+    if (i < n_parts && (widths[i] < 1 || (B > 0 && parts[i] == nullptr))) return fail(FIL_ERR_ARG, "%s: part %d: width %d", fn, i, widths[i]);
+    mp.D += mp.w[i];
+  }
+  if (mp.D > 8192) return fail(FIL_ERR_UNSUPPORTED, "%s: %d concatenated columns > 8192", fn, mp.D);
+  return FIL_OK;
+}
+
+extern "C" size_t fil_merge_softmax_bwd_workspace_bytes(int B, int D, int O) {
+  return 256 + (size_t)cdiv(std::max(B, 1), kMergeRows) * (size_t)(D + 1) * O * sizeof(float);
+}
+
+extern "C" int fil_merge_softmax_fwd(const void* const* parts, const int* widths, int n_parts, const float* W, const float* bias, float* out, int B,
+                                     int O, int dtype, void* stream) {
+  MergeParts mp;
+  const int rc = merge_check("fil_merge_softmax_fwd", parts, widths, n_parts, B, O, dtype, mp);
+  if (rc != FIL_OK) return rc;
+  if (B == 0) return FIL_OK;
+  FIL_CHECK_ARG(W != nullptr && bias != nullptr && out != nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps("merge_softmax_fwd", st, (double)B * (mp.D * (dtype == FIL_F32 ? 4.0 : 2.0) + O * 4.0));
+  if (dtype == FIL_F32) hipLaunchKernelGGL(merge_softmax_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
+  else hipLaunchKernelGGL(merge_softmax_fwd_kernel<__hip_bfloat16>, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" int fil_merge_softmax_bwd(const void* const* parts, const int* widths, int n_parts, const float* W, const float* out, const float* dout,
+                                     void* const* dparts, float* dW, float* db, int B, int O, int dtype, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  MergeParts mp;
+  const int rc = merge_check("fil_merge_softmax_bwd", parts, widths, n_parts, B, O, dtype, mp);
+  if (rc != FIL_OK) return rc;
+  FIL_CHECK_ARG(dW != nullptr && db != nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    (void)hipMemsetAsync(dW, 0, (size_t)mp.D * O * sizeof(float), st);
+    (void)hipMemsetAsync(db, 0, (size_t)O * sizeof(float), st);
+    return FIL_OK;
+  }
+  FIL_CHECK_ARG(W != nullptr && out != nullptr && dout != nullptr);
+  if (workspace == nullptr || workspace_bytes < fil_merge_softmax_bwd_workspace_bytes(B, mp.D, O))
+    return fail(FIL_ERR_WORKSPACE, "fil_merge_softmax_bwd: workspace %zu < %zu bytes", workspace_bytes, fil_merge_softmax_bwd_workspace_bytes(B, mp.D, O));
+  for (int i = 0; i < n_parts; ++i) mp.dp[i] = dparts != nullptr ? dparts[i] : nullptr;
+  // workspace: [ticket: one word the kernel leaves at zero | pad to 256 B | block partials].  The caller hands over ZEROED bytes the
+  // first time (the ticket); the kernel re-arms it, so a cached workspace needs no further clears.
+  unsigned* ticket = static_cast<unsigned*>(workspace);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+  ProfScope ps("merge_softmax_bwd", st, (double)B * (2.0 * mp.D * (dtype == FIL_F32 ? 4.0 : 2.0) + 2.0 * O * 4.0));
+  const int nblk = cdiv(B, kMergeRows);
+  if (dtype == FIL_F32) hipLaunchKernelGGL(merge_softmax_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, ticket, dW, db, B, O);
+  else hipLaunchKernelGGL(merge_softmax_bwd_kernel<__hip_bfloat16>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, ticket, dW, db, B, O);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

@@ -66,6 +66,21 @@ def _scratch(nbytes, device, tag):
     return ws
 
 
+def _scratch_zeroed(nbytes, device, tag):
+    """A cached workspace whose bytes were ZERO when it was created and that its users leave zero where they need it to be (a ticket
+    word the kernel re-arms): zero-filled once per (re)allocation, not per call.  Under capture: a fresh zeroed allocation (the graph's
+    own memset)."""
+    nbytes = max(int(nbytes), 256)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    key = (device, stream_ptr(), ("zeroed", tag))
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS_CACHE[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _WS_LAST_USE[(device, key[1])] = time.monotonic()
+    return ws
+
+
 def release_scratch():
     """Drop every cached scratch workspace (they are re-created on demand)."""
     _WS_CACHE.clear()
@@ -523,6 +538,57 @@ def score_add_sigmoid(parts):
     if any(t.shape != parts[0].shape for t in parts):
         raise FilError("score_add_sigmoid: the parts must have one shape, got %s" % [tuple(t.shape) for t in parts])
     return _ScoreAddSigmoidFn.apply(*parts)
+
+
+class _MergeSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kernel, bias, *parts):
+        _require_cuda(kernel, bias, *parts)
+        dt = parts[0].dtype
+        parts = [t.contiguous() for t in parts]
+        kernel, bias = _f32c(kernel), _f32c(bias)
+        B, O = parts[0].shape[0], kernel.shape[1]
+        widths = [int(t.shape[1]) for t in parts]
+        out = torch.empty((B, O), dtype=torch.float32, device=kernel.device)
+        check(_lib.load().fil_merge_softmax_fwd(ptr_array(parts), int_array(widths), len(parts), ptr(kernel), ptr(bias), ptr(out), B, O,
+                                                FIL_F32 if dt == torch.float32 else FIL_BF16, stream_ptr()), "fil_merge_softmax_fwd")
+        ctx.save_for_backward(kernel, out, *parts)
+        ctx.cfg = (widths, dt)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        kernel, out, *parts = ctx.saved_tensors
+        widths, dt = ctx.cfg
+        lib = _lib.load()
+        B, O, D = out.shape[0], out.shape[1], sum(widths)
+        g = _f32c(g)
+        need = ctx.needs_input_grad[2:]
+        dparts = [torch.empty_like(t) if n else None for t, n in zip(parts, need)]
+        dW = torch.empty_like(kernel)
+        db = torch.empty((O,), dtype=torch.float32, device=kernel.device)
+        ws = _scratch_zeroed(lib.fil_merge_softmax_bwd_workspace_bytes(B, D, O), kernel.device, "merge_softmax_bwd")
+        dp = (ctypes.c_void_p * len(parts))(*[None if t is None else t.data_ptr() for t in dparts])
+        check(lib.fil_merge_softmax_bwd(ptr_array(parts), int_array(widths), len(parts), ptr(kernel), ptr(out), ptr(g), dp, ptr(dW), ptr(db),
+                                        B, O, FIL_F32 if dt == torch.float32 else FIL_BF16, ptr(ws), ws.numel(), stream_ptr()),
+              "fil_merge_softmax_bwd")
+        return (dW, db) + tuple(dparts)
+
+
+def merge_softmax(parts, kernel, bias):
+    """softmax(concat(parts, -1) @ kernel + bias): MergeScoreLayer.call (core_layer.py:86-100) as one launch forward and one backward.
+    parts: 1..4 tensors [B, w_i] of ONE dtype (fp32, or bf16 under autocast); kernel [sum w_i, O <= 8], bias [O] fp32; returns fp32 [B, O]."""
+    parts = list(parts)
+    if not 1 <= len(parts) <= 4:
+        raise FilError("merge_softmax takes 1..4 parts, got %d" % len(parts))
+    dt = parts[0].dtype
+    if dt not in (torch.float32, torch.bfloat16) or any(t.dtype != dt or t.dim() != 2 or t.shape[0] != parts[0].shape[0] for t in parts):
+        raise FilError("merge_softmax: the parts must be [B, w] tensors of one dtype (float32 / bfloat16), got %s" %
+                       [(tuple(t.shape), t.dtype) for t in parts])
+    if kernel.dim() != 2 or kernel.shape[0] != sum(t.shape[1] for t in parts) or tuple(bias.shape) != (kernel.shape[1],):
+        raise FilError("merge_softmax: kernel %s / bias %s do not fit %d concatenated columns" %
+                       (tuple(kernel.shape), tuple(bias.shape), sum(t.shape[1] for t in parts)))
+    return _MergeSoftmaxFn.apply(kernel, bias, *parts)
 
 
 class _BceMeanFn(torch.autograd.Function):

@@ -115,9 +115,31 @@ class MergeScoreLayer(Layer):
         self.use_merge = use_merge
 
     def call(self, inputs, **kwargs):
+        fused = self._fused(inputs)
+        if fused is not None:
+            return fused
         if self.use_merge:
             inputs = self.concat(inputs)
         return self.dense(inputs)
+
+    def _fused(self, inputs):
+        """StackLayer concat -> Dense(softmax) as ONE launch each way (functional.merge_softmax, csrc/head.hip) when the inputs are what
+        the zoo hands over: 1..4 CUDA tensors of one floating dtype (fp32, or bf16 under autocast) that flatten to [B, w].  Anything
+        else -- and the first call, which builds the Dense -- takes the composed path."""
+        if not self.dense.built or self.dense.units > 8:
+            return None
+        parts = list(inputs) if self.use_merge else [inputs]
+        if not 1 <= len(parts) <= 4 or not all(torch.is_tensor(t) and t.is_cuda and t.dim() >= 2 for t in parts):
+            return None
+        if self.use_merge and self.concat.axis not in (-1, 1):
+            return None
+        parts = [t.reshape(t.shape[0], -1) for t in parts]
+        dt = parts[0].dtype
+        if dt not in (torch.float32, torch.bfloat16) or any(t.dtype != dt or t.shape[0] != parts[0].shape[0] for t in parts):
+            return None
+        if sum(t.shape[1] for t in parts) != self.dense.kernel.shape[0] or self.dense.kernel.shape[0] > 8192:
+            return None
+        return F.merge_softmax(parts, self.dense.kernel, self.dense.bias)
 
 
 class HiddenLayer(Layer):

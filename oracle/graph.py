@@ -233,6 +233,13 @@ def score_layer(inputs, use_add=True):
     return torch.sigmoid(x)
 
 
+def merge_score_layer(inputs, kernel, bias, use_merge=True):
+    """MergeScoreLayer.call, core_layer/core_layer.py:86-100: StackLayer() over the inputs when use_merge (flatten each, concatenate on
+    the last axis, :49-55), then tf.keras.layers.Dense(units=output_dim, activation='softmax'): softmax(x @ kernel + bias)."""
+    x = stack_layer(list(inputs)) if use_merge else inputs
+    return torch.softmax(torch.matmul(x, kernel) + bias, dim=-1)
+
+
 def binary_crossentropy(y_true, y_pred, eps=1e-7):
     """tf.losses.binary_crossentropy on probabilities, the loss the reference compiles its CTR models with
     (example/ctr_example/un_seq.py:61).  TensorFlow is a third-party dependency absent from /root/reference (README badge:

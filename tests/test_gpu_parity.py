@@ -1446,3 +1446,53 @@ def test_binary_crossentropy_matches_the_oracle(n, eps):
     assert np.abs(ga[inside] - gw[inside]).max() <= 1e-5 * scale
     again = losses.binary_crossentropy(dev(p), dev(y), eps=eps)
     assert torch.equal(again, got.detach())
+
+
+@pytest.mark.parametrize("B,widths,O,dtype", [(4096, (16, 128), 2, "f32"), (4096, (16, 128), 2, "bf16"), (333, (7, 1, 65, 300), 3, "f32"),
+                                              (1, (5,), 2, "f32"), (65, (1248, 64), 2, "f32"), (200, (40,), 8, "bf16")])
+def test_merge_softmax_head_matches_the_oracle(B, widths, O, dtype):
+    """MergeScoreLayer's concat -> Dense(softmax) (core_layer.py:86-100; the head of DeepFM / DCN, models.py:87,104) as one launch each
+    way (fil_merge_softmax_*) against oracle/graph.py:merge_score_layer in float64: probabilities 1e-6 absolute, every gradient 1e-5
+    norm-relative (bf16 storage: the oracle runs on the bf16-rounded parts; dparts come back rounded to bf16: 4e-3), repeat runs
+    bit-identical (the weight gradient's block partials are summed in block order by whichever workgroup finishes last)."""
+    from ml_function_amd import functional as Fn
+    from oracle import graph
+    rng = np.random.default_rng(31)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    parts_np = [rng.standard_normal((B, w)).astype(np.float32) for w in widths]
+    parts = [dev(p).to(tdt).requires_grad_() for p in parts_np]
+    D = sum(widths)
+    kernel = dev(rng.standard_normal((D, O)).astype(np.float32) / np.sqrt(D)).requires_grad_()
+    bias = dev(rng.standard_normal(O).astype(np.float32) * 0.1).requires_grad_()
+    g = rng.standard_normal((B, O)).astype(np.float32)
+    out = Fn.merge_softmax(parts, kernel, bias)
+    out.backward(dev(g))
+    T = lambda t: t.detach().double().cpu().requires_grad_()
+    parts64, k64, b64 = [T(p) for p in parts], T(kernel), T(bias)
+    want = graph.merge_score_layer(parts64, k64, b64)
+    want.backward(torch.tensor(g, dtype=torch.float64))
+    assert out.dtype == torch.float32 and tuple(out.shape) == (B, O)
+    assert float((out.detach().double().cpu() - want.detach()).abs().max()) < 1e-6
+    check("merge head dW", kernel.grad, k64.grad.numpy(), tol=1e-5)
+    check("merge head db", bias.grad, b64.grad.numpy(), tol=1e-5)
+    for i, (p, p64) in enumerate(zip(parts, parts64)):
+        assert p.grad.dtype == tdt
+        check("merge head dpart %d" % i, p.grad, p64.grad.numpy(), tol=1e-5 if dtype == "f32" else 4e-3)
+    first = (out.detach().clone(), kernel.grad.clone(), bias.grad.clone())
+    for t in parts + [kernel, bias]:
+        t.grad = None
+    out2 = Fn.merge_softmax(parts, kernel, bias)
+    out2.backward(dev(g))
+    assert torch.equal(out2, first[0]) and torch.equal(kernel.grad, first[1]) and torch.equal(bias.grad, first[2])
+
+
+def test_merge_score_layer_takes_the_fused_head_and_agrees_with_the_torch_path():
+    from ml_function_amd.layers import MergeScoreLayer
+    rng = np.random.default_rng(3)
+    a, b = dev(rng.standard_normal((50, 1, 16)).astype(np.float32)), dev(rng.standard_normal((50, 24)).astype(np.float32))
+    lay = MergeScoreLayer()
+    first = lay([a, b])                       # builds the Dense: the composed path
+    assert lay._fused([a, b]) is not None     # from now on: one launch
+    again = lay([a, b])
+    assert tuple(again.shape) == (50, 2) and float((again - first).abs().max()) < 1e-6
+    assert lay._fused([a.cpu(), b.cpu()]) is None and lay._fused([a.half(), b.half()]) is None
