@@ -68,15 +68,18 @@ struct MergeParts {
   const void* p[4];
   void* dp[4];
   int w[4];        // widths; 0 = unused
+  int bf[4];       // 1: the part (and its gradient) is stored as bf16, 0: fp32
   int D;           // sum of the widths
 };
-template <typename T>
-__device__ __forceinline__ float merge_ld(const void* p, long i) { return (float)reinterpret_cast<const T*>(p)[i]; }
-template <typename T>
-__device__ __forceinline__ void merge_st(void* p, long i, float v) { reinterpret_cast<T*>(p)[i] = (T)v; }
+__device__ __forceinline__ float merge_ld(const void* p, long i, int bf) {
+  return bf ? (float)reinterpret_cast<const __hip_bfloat16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void merge_st(void* p, long i, float v, int bf) {
+  if (bf) reinterpret_cast<__hip_bfloat16*>(p)[i] = (__hip_bfloat16)v;
+  else reinterpret_cast<float*>(p)[i] = v;
+}
 
 // out[b, :] = softmax(concat_i parts_i[b, :] W + bias): a wave per sample (lanes over the D columns, O dot products folded by the wave)
-template <typename T>
 __global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, const float* __restrict__ W, const float* __restrict__ bias,
                                                                 float* __restrict__ out, int B, int O) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, c
   for (int i = 0; i < 4; ++i) {
     const int w = mp.w[i];
     for (int d = lane; d < w; d += 64) {
-      const float x = merge_ld<T>(mp.p[i], (long)b * w + d);
+      const float x = merge_ld(mp.p[i], (long)b * w + d, mp.bf[i]);
       const float* wr = W + (long)(d0 + d) * O;
 #pragma unroll
       for (int o = 0; o < kMergeMaxO; ++o)
@@ -117,7 +120,6 @@ __global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, c
 // dz = out (dout - <dout, out>);  dparts_i[b, d] = sum_o dz[b, o] W[d, o];  block partials of dW[d, o] = sum_b x[b, d] dz[b, o] and
 // db[o] = sum_b dz[b, o] over the workgroup's kMergeRows samples (fixed order); the LAST workgroup to finish (a ticket) sums the
 // partials in block order -- a fixed order whoever that workgroup is -- into dW | db and re-arms the ticket.
-template <typename T>
 __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, const float* __restrict__ W, const float* __restrict__ out,
                                                                 const float* __restrict__ dout, float* __restrict__ part, unsigned* __restrict__ ticket,
                                                                 float* __restrict__ dW, float* __restrict__ db, int B, int O) {
@@ -149,14 +151,14 @@ __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, c
         acc[o] = 0.f;
       }
       for (int s = 0; s < nrow; ++s) {
-        const float x = merge_ld<T>(mp.p[i], (long)(b0 + s) * w + d);
+        const float x = merge_ld(mp.p[i], (long)(b0 + s) * w + d, mp.bf[i]);
         float dx = 0.f;
 #pragma unroll
         for (int o = 0; o < kMergeMaxO; ++o) {
           acc[o] = fmaf(x, dz[s][o], acc[o]);
           dx = fmaf(dz[s][o], wr[o], dx);
         }
-        if (mp.dp[i] != nullptr) merge_st<T>(mp.dp[i], (long)(b0 + s) * w + d, dx);
+        if (mp.dp[i] != nullptr) merge_st(mp.dp[i], (long)(b0 + s) * w + d, dx, mp.bf[i]);
       }
       for (int o = 0; o < O; ++o) mypart[(long)(d0 + d) * O + o] = acc[o];
     }
@@ -190,6 +192,48 @@ __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, c
     else db[i - D * O] = v;
   }
   if (tid == 0) *ticket = 0u;   // (re-armed for the next call on this stream)
+}
+
+
+// ---- Dense + bias + ReLU of the zoo's MLPs (DnnLayer: core_layer/core_layer.py:102-118,201-226), backward half.  The two GEMMs of a
+// layer's backward stay library GEMMs; what torch runs around them -- threshold_backward over [B, N], then a column
+// reduce of the same [B, N] for the bias gradient -- is ONE pass here: dz = dy where y > 0 (else 0), written in dy's storage type, and
+// dbias[n] = sum_b dz[b, n] through block partials summed in block order by the last workgroup to finish (a ticket: deterministic).
+constexpr int kReluRows = 64;   // rows per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bias_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dz, float* __restrict__ part,
+                                                            unsigned* __restrict__ ticket, float* __restrict__ dbias, int B, int N) {
+  __shared__ unsigned last;
+  const int tid = threadIdx.x, b0 = blockIdx.x * kReluRows, nrow = min(kReluRows, B - b0);
+  for (int n = tid; n < N; n += 256) {
+    float t = 0.f;
+    for (int s = 0; s < nrow; ++s) {
+      const long i = (long)(b0 + s) * N + n;
+      const float g = (float)y[i] > 0.f ? (float)dy[i] : 0.f;
+      dz[i] = (T)g;
+      t += g;
+    }
+    part[(long)blockIdx.x * N + n] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last == 0u) return;
+  __threadfence();
+  for (int n = tid; n < N; n += 256) {
+    float t0 = 0.f, t1 = 0.f;
+    unsigned blk = 0;
+    for (; blk + 1 < gridDim.x; blk += 2) {
+      t0 += __builtin_nontemporal_load(part + (long)blk * N + n);
+      t1 += __builtin_nontemporal_load(part + (long)(blk + 1) * N + n);
+    }
+    if (blk < gridDim.x) t0 += __builtin_nontemporal_load(part + (long)blk * N + n);
+    dbias[n] = t0 + t1;
+  }
+  if (tid == 0) *ticket = 0u;
 }
 
 }  // namespace fil
@@ -230,15 +274,19 @@ extern "C" int fil_bce_mean_fwd(const float* p, const float* y, float eps, float
   return FIL_OK;
 }
 
-static int merge_check(const char* fn, const void* const* parts, const int* widths, int n_parts, int B, int O, int dtype, MergeParts& mp) {
-  if (B < 0 || n_parts < 1 || n_parts > 4 || O < 1 || O > kMergeMaxO || parts == nullptr || widths == nullptr)
+static int merge_check(const char* fn, const void* const* parts, const int* widths, const int* dtypes, int n_parts, int B, int O, MergeParts& mp) {
+  if (B < 0 || n_parts < 1 || n_parts > 4 || O < 1 || O > kMergeMaxO || parts == nullptr || widths == nullptr || dtypes == nullptr)
     return fail(FIL_ERR_ARG, "%s: B=%d, %d parts (1..4), %d units (1..%d)", fn, B, n_parts, O, kMergeMaxO);
-  if (dtype != FIL_F32 && dtype != FIL_BF16) return fail(FIL_ERR_ARG, "%s: dtype %d (f32 or bf16 storage)", fn, dtype);
   mp.D = 0;
   for (int i = 0; i < 4; ++i) {
     mp.p[i] = i < n_parts ? parts[i] : nullptr;
     mp.dp[i] = nullptr;
     mp.w[i] = i < n_parts ? widths[i] : 0;
+    mp.bf[i] = 0;
+    if (i < n_parts) {
+      if (dtypes[i] != FIL_F32 && dtypes[i] != FIL_BF16) return fail(FIL_ERR_ARG, "%s: part %d: dtype %d (f32 or bf16 storage)", fn, i, dtypes[i]);
+      mp.bf[i] = dtypes[i] == FIL_BF16;
+    }
     if (i < n_parts && (widths[i] < 1 || (B > 0 && parts[i] == nullptr))) return fail(FIL_ERR_ARG, "%s: part %d: width %d", fn, i, widths[i]);
     mp.D += mp.w[i];
   }
@@ -250,26 +298,25 @@ extern "C" size_t fil_merge_softmax_bwd_workspace_bytes(int B, int D, int O) {
   return 256 + (size_t)cdiv(std::max(B, 1), kMergeRows) * (size_t)(D + 1) * O * sizeof(float);
 }
 
-extern "C" int fil_merge_softmax_fwd(const void* const* parts, const int* widths, int n_parts, const float* W, const float* bias, float* out, int B,
-                                     int O, int dtype, void* stream) {
+extern "C" int fil_merge_softmax_fwd(const void* const* parts, const int* widths, const int* dtypes, int n_parts, const float* W, const float* bias,
+                                     float* out, int B, int O, void* stream) {
   MergeParts mp;
-  const int rc = merge_check("fil_merge_softmax_fwd", parts, widths, n_parts, B, O, dtype, mp);
+  const int rc = merge_check("fil_merge_softmax_fwd", parts, widths, dtypes, n_parts, B, O, mp);
   if (rc != FIL_OK) return rc;
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(W != nullptr && bias != nullptr && out != nullptr);
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps("merge_softmax_fwd", st, (double)B * (mp.D * (dtype == FIL_F32 ? 4.0 : 2.0) + O * 4.0));
-  if (dtype == FIL_F32) hipLaunchKernelGGL(merge_softmax_fwd_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
-  else hipLaunchKernelGGL(merge_softmax_fwd_kernel<__hip_bfloat16>, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
+  ProfScope ps("merge_softmax_fwd", st, (double)B * (mp.D * 4.0 + O * 4.0));
+  hipLaunchKernelGGL(merge_softmax_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
 
-extern "C" int fil_merge_softmax_bwd(const void* const* parts, const int* widths, int n_parts, const float* W, const float* out, const float* dout,
-                                     void* const* dparts, float* dW, float* db, int B, int O, int dtype, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+extern "C" int fil_merge_softmax_bwd(const void* const* parts, const int* widths, const int* dtypes, int n_parts, const float* W, const float* out,
+                                     const float* dout, void* const* dparts, float* dW, float* db, int B, int O, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   MergeParts mp;
-  const int rc = merge_check("fil_merge_softmax_bwd", parts, widths, n_parts, B, O, dtype, mp);
+  const int rc = merge_check("fil_merge_softmax_bwd", parts, widths, dtypes, n_parts, B, O, mp);
   if (rc != FIL_OK) return rc;
   FIL_CHECK_ARG(dW != nullptr && db != nullptr);
   hipStream_t st = (hipStream_t)stream;
@@ -286,10 +333,36 @@ extern "C" int fil_merge_softmax_bwd(const void* const* parts, const int* widths
   // first time (the ticket); the kernel re-arms it, so a cached workspace needs no further clears.
   unsigned* ticket = static_cast<unsigned*>(workspace);
   float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
-  ProfScope ps("merge_softmax_bwd", st, (double)B * (2.0 * mp.D * (dtype == FIL_F32 ? 4.0 : 2.0) + 2.0 * O * 4.0));
+  ProfScope ps("merge_softmax_bwd", st, (double)B * (2.0 * mp.D * 4.0 + 2.0 * O * 4.0));
   const int nblk = cdiv(B, kMergeRows);
-  if (dtype == FIL_F32) hipLaunchKernelGGL(merge_softmax_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, ticket, dW, db, B, O);
-  else hipLaunchKernelGGL(merge_softmax_bwd_kernel<__hip_bfloat16>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, ticket, dW, db, B, O);
+  hipLaunchKernelGGL(merge_softmax_bwd_kernel, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, ticket, dW, db, B, O);
+  FIL_CHECK_LAUNCH();
+  return FIL_OK;
+}
+
+extern "C" size_t fil_relu_bias_bwd_workspace_bytes(int B, int N) { return 256 + (size_t)cdiv(std::max(B, 1), kReluRows) * (size_t)N * sizeof(float); }
+
+extern "C" int fil_relu_bias_bwd(const void* y, const void* dy, void* dz, float* dbias, int B, int N, int dtype, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  FIL_CHECK_ARG(B >= 0 && N >= 1 && dbias != nullptr);
+  if (dtype != FIL_F32 && dtype != FIL_BF16) return fail(FIL_ERR_ARG, "fil_relu_bias_bwd: dtype %d (f32 or bf16 storage)", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    (void)hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
+    return FIL_OK;
+  }
+  FIL_CHECK_ARG(y != nullptr && dy != nullptr && dz != nullptr);
+  if (workspace == nullptr || workspace_bytes < fil_relu_bias_bwd_workspace_bytes(B, N))
+    return fail(FIL_ERR_WORKSPACE, "fil_relu_bias_bwd: workspace %zu < %zu bytes", workspace_bytes, fil_relu_bias_bwd_workspace_bytes(B, N));
+  unsigned* ticket = static_cast<unsigned*>(workspace);   // (zero on entry, left at zero: as fil_merge_softmax_bwd)
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+  ProfScope ps("relu_bias_bwd", st, (double)B * N * 3.0 * (dtype == FIL_F32 ? 4.0 : 2.0));
+  const int nblk = cdiv(B, kReluRows);
+  if (dtype == FIL_F32)
+    hipLaunchKernelGGL(relu_bias_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dz, part, ticket, dbias, B, N);
+  else
+    hipLaunchKernelGGL(relu_bias_bwd_kernel<__hip_bfloat16>, dim3(nblk), dim3(256), 0, st, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy,
+                       (__hip_bfloat16*)dz, part, ticket, dbias, B, N);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

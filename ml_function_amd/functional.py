@@ -540,26 +540,70 @@ def score_add_sigmoid(parts):
     return _ScoreAddSigmoidFn.apply(*parts)
 
 
+class _DenseReluFn(torch.autograd.Function):
+    """y = relu(x @ kernel + bias) -- a hidden layer of the zoo's MLPs (DnnLayer, core_layer.py:102-118,201-226) -- as a library GEMM
+    with the bias + ReLU in its epilogue forward, and backward as ONE HIP pass (ReLU mask + bias gradient, fil_relu_bias_bwd) plus the
+    layer's two library GEMMs.  torch composes the same layer from 3 launches forward and 5 backward.  Under autocast the GEMMs run in
+    the autocast dtype (bf16), as torch.matmul would."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        _require_cuda(x, kernel, bias)
+        cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if cd not in (torch.float32, torch.bfloat16):
+            raise FilError("dense_relu: autocast dtype %s (float32 or bfloat16)" % cd)
+        with torch.autocast("cuda", enabled=False):
+            xc, wc = x.to(cd).contiguous(), kernel.to(cd)
+            y = torch._addmm_activation(bias.to(cd), xc, wc, use_gelu=False)
+        ctx.save_for_backward(xc, wc, y)
+        ctx.cfg = (x.dtype, kernel.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc, y = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.cfg
+        lib = _lib.load()
+        B, N = y.shape
+        dy = dy.to(y.dtype).contiguous()
+        dz = torch.empty_like(y)
+        db = torch.empty((N,), dtype=torch.float32, device=y.device)
+        ws = _scratch_zeroed(lib.fil_relu_bias_bwd_workspace_bytes(B, N), y.device, "relu_bias_bwd")
+        check(lib.fil_relu_bias_bwd(ptr(y), ptr(dy), ptr(dz), ptr(db), B, N, FIL_F32 if y.dtype == torch.float32 else FIL_BF16, ptr(ws),
+                                    ws.numel(), stream_ptr()), "fil_relu_bias_bwd")
+        with torch.autocast("cuda", enabled=False):
+            dx = torch.matmul(dz, wc.t()).to(xdt) if ctx.needs_input_grad[0] else None
+            dw = torch.matmul(xc.t(), dz).to(wdt) if ctx.needs_input_grad[1] else None
+        return dx, dw, db.to(bdt)
+
+
+def dense_relu(x, kernel, bias):
+    """relu(x @ kernel + bias), x [B, in] (fp32 or bf16), kernel [in, units], bias [units]."""
+    if x.dim() != 2 or kernel.dim() != 2 or x.shape[1] != kernel.shape[0] or tuple(bias.shape) != (kernel.shape[1],):
+        raise FilError("dense_relu: x %s, kernel %s, bias %s" % (tuple(x.shape), tuple(kernel.shape), tuple(bias.shape)))
+    return _DenseReluFn.apply(x, kernel, bias)
+
+
 class _MergeSoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kernel, bias, *parts):
         _require_cuda(kernel, bias, *parts)
-        dt = parts[0].dtype
+        dts = [FIL_F32 if t.dtype == torch.float32 else FIL_BF16 for t in parts]
         parts = [t.contiguous() for t in parts]
         kernel, bias = _f32c(kernel), _f32c(bias)
         B, O = parts[0].shape[0], kernel.shape[1]
         widths = [int(t.shape[1]) for t in parts]
         out = torch.empty((B, O), dtype=torch.float32, device=kernel.device)
-        check(_lib.load().fil_merge_softmax_fwd(ptr_array(parts), int_array(widths), len(parts), ptr(kernel), ptr(bias), ptr(out), B, O,
-                                                FIL_F32 if dt == torch.float32 else FIL_BF16, stream_ptr()), "fil_merge_softmax_fwd")
+        check(_lib.load().fil_merge_softmax_fwd(ptr_array(parts), int_array(widths), int_array(dts), len(parts), ptr(kernel), ptr(bias),
+                                                ptr(out), B, O, stream_ptr()), "fil_merge_softmax_fwd")
         ctx.save_for_backward(kernel, out, *parts)
-        ctx.cfg = (widths, dt)
+        ctx.cfg = (widths, dts)
         return out
 
     @staticmethod
     def backward(ctx, g):
         kernel, out, *parts = ctx.saved_tensors
-        widths, dt = ctx.cfg
+        widths, dts = ctx.cfg
         lib = _lib.load()
         B, O, D = out.shape[0], out.shape[1], sum(widths)
         g = _f32c(g)
@@ -569,21 +613,20 @@ class _MergeSoftmaxFn(torch.autograd.Function):
         db = torch.empty((O,), dtype=torch.float32, device=kernel.device)
         ws = _scratch_zeroed(lib.fil_merge_softmax_bwd_workspace_bytes(B, D, O), kernel.device, "merge_softmax_bwd")
         dp = (ctypes.c_void_p * len(parts))(*[None if t is None else t.data_ptr() for t in dparts])
-        check(lib.fil_merge_softmax_bwd(ptr_array(parts), int_array(widths), len(parts), ptr(kernel), ptr(out), ptr(g), dp, ptr(dW), ptr(db),
-                                        B, O, FIL_F32 if dt == torch.float32 else FIL_BF16, ptr(ws), ws.numel(), stream_ptr()),
-              "fil_merge_softmax_bwd")
+        check(lib.fil_merge_softmax_bwd(ptr_array(parts), int_array(widths), int_array(dts), len(parts), ptr(kernel), ptr(out), ptr(g), dp,
+                                        ptr(dW), ptr(db), B, O, ptr(ws), ws.numel(), stream_ptr()), "fil_merge_softmax_bwd")
         return (dW, db) + tuple(dparts)
 
 
 def merge_softmax(parts, kernel, bias):
     """softmax(concat(parts, -1) @ kernel + bias): MergeScoreLayer.call (core_layer.py:86-100) as one launch forward and one backward.
-    parts: 1..4 tensors [B, w_i] of ONE dtype (fp32, or bf16 under autocast); kernel [sum w_i, O <= 8], bias [O] fp32; returns fp32 [B, O]."""
+    parts: 1..4 tensors [B, w_i], each fp32 or bf16 (under bf16 autocast a model hands a bf16 FM output next to an fp32 MLP output);
+    kernel [sum w_i, O <= 8], bias [O] fp32; returns fp32 [B, O]."""
     parts = list(parts)
     if not 1 <= len(parts) <= 4:
         raise FilError("merge_softmax takes 1..4 parts, got %d" % len(parts))
-    dt = parts[0].dtype
-    if dt not in (torch.float32, torch.bfloat16) or any(t.dtype != dt or t.dim() != 2 or t.shape[0] != parts[0].shape[0] for t in parts):
-        raise FilError("merge_softmax: the parts must be [B, w] tensors of one dtype (float32 / bfloat16), got %s" %
+    if any(t.dtype not in (torch.float32, torch.bfloat16) or t.dim() != 2 or t.shape[0] != parts[0].shape[0] for t in parts):
+        raise FilError("merge_softmax: the parts must be [B, w] float32 / bfloat16 tensors, got %s" %
                        [(tuple(t.shape), t.dtype) for t in parts])
     if kernel.dim() != 2 or kernel.shape[0] != sum(t.shape[1] for t in parts) or tuple(bias.shape) != (kernel.shape[1],):
         raise FilError("merge_softmax: kernel %s / bias %s do not fit %d concatenated columns" %

@@ -124,7 +124,7 @@ class MergeScoreLayer(Layer):
 
     def _fused(self, inputs):
         """StackLayer concat -> Dense(softmax) as ONE launch each way (functional.merge_softmax, csrc/head.hip) when the inputs are what
-        the zoo hands over: 1..4 CUDA tensors of one floating dtype (fp32, or bf16 under autocast) that flatten to [B, w].  Anything
+        the zoo hands over: 1..4 CUDA tensors, each fp32 or bf16 (autocast), that flatten to [B, w].  Anything
         else -- and the first call, which builds the Dense -- takes the composed path."""
         if not self.dense.built or self.dense.units > 8:
             return None
@@ -134,8 +134,7 @@ class MergeScoreLayer(Layer):
         if self.use_merge and self.concat.axis not in (-1, 1):
             return None
         parts = [t.reshape(t.shape[0], -1) for t in parts]
-        dt = parts[0].dtype
-        if dt not in (torch.float32, torch.bfloat16) or any(t.dtype != dt or t.shape[0] != parts[0].shape[0] for t in parts):
+        if any(t.dtype not in (torch.float32, torch.bfloat16) or t.shape[0] != parts[0].shape[0] for t in parts):
             return None
         if sum(t.shape[1] for t in parts) != self.dense.kernel.shape[0] or self.dense.kernel.shape[0] > 8192:
             return None
@@ -244,6 +243,19 @@ class DnnLayer(Layer):
                 and isinstance(self.hidden_activate, torch.nn.ReLU) and not self.hidden_list[0].head_concat
                 and self.hidden_list[0].attention_head_dim > 1)
 
+    def _dense_relu(self, idx_, hidden_layer, x):
+        """A plain hidden layer whose residual Add is skipped (res_unit == 1 and in != units: keras Add raises on the shapes, :211-214)
+        is relu(x @ W + b): one library GEMM with the bias + ReLU in its epilogue, one HIP pass + two GEMMs backward
+        (functional.dense_relu).  None: anything else (first call: the Dense is not built yet; norms; a square layer, whose residual
+        IS added; another activation; a CPU tensor) takes the composed path below."""
+        d = hidden_layer.dense if isinstance(hidden_layer, HiddenLayer) else None
+        if (not isinstance(d, Dense) or not d.built or d.activation is not None or hidden_layer.use_bn or self.use_bn or self.use_ln
+                or self.res_unit != 1 or type(self.hidden_activate) is not torch.nn.ReLU or not torch.is_tensor(x) or not x.is_cuda
+                or x.dim() != 2 or x.shape[1] != d.kernel.shape[0] or d.kernel.shape[0] == d.kernel.shape[1]
+                or x.dtype not in (torch.float32, torch.bfloat16)):
+            return None
+        return F.dense_relu(x, d.kernel, d.bias)
+
     def call(self, inputs, **kwargs):
         x = inputs
         if self._fusable():
@@ -256,6 +268,11 @@ class DnnLayer(Layer):
         else:
             res = [[], []]
             for idx_, hidden_layer in enumerate(self.hidden_list):
+                fused = self._dense_relu(idx_, hidden_layer, x)
+                if fused is not None:
+                    x = fused
+                    res = [x, x]
+                    continue
                 x, ori = hidden_layer(x)
                 if idx_ == 0:
                     res = [ori, x]

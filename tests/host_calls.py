@@ -80,14 +80,18 @@ def run(lib):
     expect(lib.fil_score_add_sigmoid_bwd(None, None, None, 4, None), -1)
     expect(lib.fil_bce_mean_fwd(None, None, 1e-7, None, None, 0, None), -1)
     expect(lib.fil_bce_mean_fwd(None, None, 0.7, None, None, 8, None), -1, b"eps")
+    expect(lib.fil_relu_bias_bwd(None, None, None, None, 4, 8, 0, None, 0, None), -1)
+    expect(lib.fil_relu_bias_bwd(None, None, None, None, 4, 8, 5, None, 0, None), -1)
+    assert lib.fil_relu_bias_bwd_workspace_bytes(4096, 256) == 256 + 64 * 256 * 4
     w2 = _lib.int_array([16, 128])
     pp = (ctypes.c_void_p * 2)(None, None)
-    expect(lib.fil_merge_softmax_fwd(None, None, 2, None, None, None, 4, 2, 0, None), -1, b"parts")
-    expect(lib.fil_merge_softmax_fwd(pp, w2, 2, None, None, None, 4, 9, 0, None), -1, b"units")
-    expect(lib.fil_merge_softmax_fwd(pp, w2, 2, None, None, None, 4, 2, 2, None), -1, b"dtype")
-    expect(lib.fil_merge_softmax_fwd(pp, w2, 2, None, None, None, 0, 2, 0, None), 0)
-    expect(lib.fil_merge_softmax_fwd(pp, w2, 2, None, None, None, 4, 2, 1, None), -1)          # NULL parts with B > 0
-    expect(lib.fil_merge_softmax_bwd(pp, w2, 2, None, None, None, None, None, None, 4, 2, 0, None, 0, None), -1)
+    d2, dbad = _lib.int_array([0, 1]), _lib.int_array([0, 2])
+    expect(lib.fil_merge_softmax_fwd(None, None, None, 2, None, None, None, 4, 2, None), -1, b"parts")
+    expect(lib.fil_merge_softmax_fwd(pp, w2, d2, 2, None, None, None, 4, 9, None), -1, b"units")
+    expect(lib.fil_merge_softmax_fwd(pp, w2, dbad, 2, None, None, None, 0, 2, None), -1, b"dtype")
+    expect(lib.fil_merge_softmax_fwd(pp, w2, d2, 2, None, None, None, 0, 2, None), 0)
+    expect(lib.fil_merge_softmax_fwd(pp, w2, d2, 2, None, None, None, 4, 2, None), -1)          # NULL parts with B > 0
+    expect(lib.fil_merge_softmax_bwd(pp, w2, d2, 2, None, None, None, None, None, None, 4, 2, None, 0, None), -1)
     assert lib.fil_merge_softmax_bwd_workspace_bytes(4096, 144, 2) == 256 + 64 * 145 * 2 * 4
     assert lib.fil_merge_softmax_bwd_workspace_bytes(0, 144, 2) == 256 + 145 * 2 * 4
     small = lib.fil_attn_bwd_workspace_bytes(16, 200, 16, 4, 16, 1)

@@ -1449,7 +1449,8 @@ def test_binary_crossentropy_matches_the_oracle(n, eps):
 
 
 @pytest.mark.parametrize("B,widths,O,dtype", [(4096, (16, 128), 2, "f32"), (4096, (16, 128), 2, "bf16"), (333, (7, 1, 65, 300), 3, "f32"),
-                                              (1, (5,), 2, "f32"), (65, (1248, 64), 2, "f32"), (200, (40,), 8, "bf16")])
+                                              (1, (5,), 2, "f32"), (65, (1248, 64), 2, "f32"), (200, (40,), 8, "bf16"),
+                                              (4096, (16, 128), 2, "mixed")])
 def test_merge_softmax_head_matches_the_oracle(B, widths, O, dtype):
     """MergeScoreLayer's concat -> Dense(softmax) (core_layer.py:86-100; the head of DeepFM / DCN, models.py:87,104) as one launch each
     way (fil_merge_softmax_*) against oracle/graph.py:merge_score_layer in float64: probabilities 1e-6 absolute, every gradient 1e-5
@@ -1458,9 +1459,9 @@ def test_merge_softmax_head_matches_the_oracle(B, widths, O, dtype):
     from ml_function_amd import functional as Fn
     from oracle import graph
     rng = np.random.default_rng(31)
-    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
-    parts_np = [rng.standard_normal((B, w)).astype(np.float32) for w in widths]
-    parts = [dev(p).to(tdt).requires_grad_() for p in parts_np]
+    tdts = [torch.float32 if dtype == "f32" or (dtype == "mixed" and i > 0) else torch.bfloat16 for i in range(len(widths))]   # mixed: DeepFM
+    parts_np = [rng.standard_normal((B, w)).astype(np.float32) for w in widths]                                             # under autocast
+    parts = [dev(p).to(t).requires_grad_() for p, t in zip(parts_np, tdts)]
     D = sum(widths)
     kernel = dev(rng.standard_normal((D, O)).astype(np.float32) / np.sqrt(D)).requires_grad_()
     bias = dev(rng.standard_normal(O).astype(np.float32) * 0.1).requires_grad_()
@@ -1476,8 +1477,8 @@ def test_merge_softmax_head_matches_the_oracle(B, widths, O, dtype):
     check("merge head dW", kernel.grad, k64.grad.numpy(), tol=1e-5)
     check("merge head db", bias.grad, b64.grad.numpy(), tol=1e-5)
     for i, (p, p64) in enumerate(zip(parts, parts64)):
-        assert p.grad.dtype == tdt
-        check("merge head dpart %d" % i, p.grad, p64.grad.numpy(), tol=1e-5 if dtype == "f32" else 4e-3)
+        assert p.grad.dtype == tdts[i]
+        check("merge head dpart %d" % i, p.grad, p64.grad.numpy(), tol=1e-5 if tdts[i] == torch.float32 else 4e-3)
     first = (out.detach().clone(), kernel.grad.clone(), bias.grad.clone())
     for t in parts + [kernel, bias]:
         t.grad = None
@@ -1496,3 +1497,53 @@ def test_merge_score_layer_takes_the_fused_head_and_agrees_with_the_torch_path()
     again = lay([a, b])
     assert tuple(again.shape) == (50, 2) and float((again - first).abs().max()) < 1e-6
     assert lay._fused([a.cpu(), b.cpu()]) is None and lay._fused([a.half(), b.half()]) is None
+    mixed = lay([a.bfloat16(), b])            # a bf16 part next to an fp32 one (DeepFM under autocast)
+    assert mixed.dtype == torch.float32 and float((mixed - first).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("B,I,N,dtype", [(4096, 637, 256, "f32"), (4096, 256, 128, "bf16"), (1, 5, 3, "f32"), (333, 70, 9, "f32"), (130, 64, 200, "bf16")])
+def test_dense_relu_layer_matches_float64(B, I, N, dtype):
+    """A hidden layer of the zoo's MLPs (DnnLayer, core_layer.py:102-118,201-226: Dense -> skipped residual -> ReLU) as
+    functional.dense_relu: library GEMM with the bias + ReLU epilogue forward; ReLU mask + bias gradient as one HIP pass
+    (fil_relu_bias_bwd) and two library GEMMs backward.  Against relu(x W + b) in float64 (on the operands as stored): fp32 1e-5, the
+    bf16 storage mode 2e-2 (outputs and gradients are ROUNDED to bf16 there); the bias gradient's reduction repeats bit for bit."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(17)
+    x = dev(rng.standard_normal((B, I)).astype(np.float32)).requires_grad_()
+    W = dev(rng.standard_normal((I, N)).astype(np.float32) / np.sqrt(I)).requires_grad_()
+    b = dev(rng.standard_normal(N).astype(np.float32) * 0.3).requires_grad_()
+    g = dev(rng.standard_normal((B, N)).astype(np.float32))
+    def run():
+        for t in (x, W, b):
+            t.grad = None
+        if dtype == "bf16":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = Fn.dense_relu(x, W, b)
+        else:
+            y = Fn.dense_relu(x, W, b)
+        y.backward(g.to(y.dtype))
+        return y.detach(), x.grad.clone(), W.grad.clone(), b.grad.clone()
+    y, dx, dW, db = run()
+    assert y.dtype == (torch.float32 if dtype == "f32" else torch.bfloat16) and dx.dtype == W.grad.dtype == b.grad.dtype == torch.float32
+    cast = (lambda t: t.detach().double().cpu()) if dtype == "f32" else (lambda t: t.detach().bfloat16().double().cpu())
+    x64, W64, b64 = cast(x).requires_grad_(), cast(W).requires_grad_(), cast(b).requires_grad_()
+    want = torch.relu(x64 @ W64 + b64)
+    want.backward(g.double().cpu() if dtype == "f32" else g.bfloat16().double().cpu())
+    tol = 1e-5 if dtype == "f32" else 2e-2
+    check("dense_relu y", y, want.detach().numpy(), tol=tol)
+    check("dense_relu dx", dx, x64.grad.numpy(), tol=tol)
+    check("dense_relu dW", dW, W64.grad.numpy(), tol=tol)
+    check("dense_relu db", db, b64.grad.numpy(), tol=tol)
+    y2, dx2, dW2, db2 = run()
+    assert torch.equal(db, db2) and torch.equal(y, y2)
+
+
+def test_dnn_layer_takes_the_fused_hidden_layers_and_agrees_with_the_composed_path():
+    from ml_function_amd.layers import DnnLayer
+    rng = np.random.default_rng(4)
+    x = dev(rng.standard_normal((77, 40)).astype(np.float32))
+    lay = DnnLayer(hidden_units=[32, 32, 8])       # 40 -> 32 (fused), 32 -> 32 (square: the residual IS added: composed), 32 -> 8 (fused)
+    first = lay(x)                                 # builds the Dense layers: the composed path
+    assert lay._dense_relu(0, lay.hidden_list[0], x) is not None and lay._dense_relu(1, lay.hidden_list[1], first.new_zeros(77, 32)) is None
+    again = lay(x)
+    assert tuple(again.shape) == (77, 8) and float((again - first).abs().max()) < 1e-5
