@@ -333,6 +333,9 @@ def side_workloads(args):
                  "dtype": r["dtype"], "steps": a.steps}
             if r.get("hipgraph_replay_ms_per_step"):
                 e["hipgraph_replay_ms_per_step"] = round(r["hipgraph_replay_ms_per_step"], 4)
+                # host-side cost of launching the step op by op: a training user takes the replayed step (layers.capture_step, the
+                # default of examples/train_ctr.py)
+                e["eager_over_replay"] = round(r["ms_per_step"] / r["hipgraph_replay_ms_per_step"], 2)
             if "roofline" in r:
                 e["roofline"] = {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
             if "valu_roofline" in r:

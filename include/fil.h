@@ -267,17 +267,16 @@ int fil_bce_mean_fwd(const float* p, const float* y, float eps, float* loss, flo
 
 /* MergeScoreLayer.call (core_layer/core_layer.py:86-100): StackLayer concat of the n_parts (1..4) tensors parts[i] [B, widths[i]] ->
  * Dense(O <= 8 units, softmax): out [B, O] = softmax(concat(parts) W + bias), W [D = sum widths, O] row-major (the Keras Dense kernel),
- * bias [O].  DeepFM / DCN / Wide&Deep end in it (model/models.py:87,104).  ONE launch each way, the parts read where they lie (no
+ * bias [O].  DeepFM / DCN / Wide&Deep end in it (model/models.py:87,104).  One launch forward, two backward, the parts read where they lie (no
  * concatenated copy).  dtypes[i] = storage type of parts[i] and of dparts[i] (FIL_F32 or FIL_BF16: a model under bf16 autocast hands
  * a bf16 FM output next to an fp32 MLP output); W, bias, out, dout, dW, db are fp32 and so is the arithmetic.
  *   bwd: dz = out (dout - <dout, out>); dparts[i] [B, widths[i]] = dz W_i^T (entries / the array may be NULL: not wanted);
- *        dW [D, O] = concat(parts)^T dz, db [O] = column sums of dz -- block partials summed in block order by the last workgroup to
- *        finish (a ticket): deterministic.  workspace: fil_merge_softmax_bwd_workspace_bytes(B, D, O) bytes whose FIRST WORD IS ZERO
- *        on entry (the ticket; the kernel leaves it at zero again, so a zero-initialised buffer can be reused call after call). */
+ *        dW [D, O] = concat(parts)^T dz, db [O] = column sums of dz -- block partials summed in block order by a second, tiny launch:
+ *        deterministic.  workspace: fil_merge_softmax_bwd_workspace_bytes(B, D, O) bytes. */
 /* Backward half of Dense + bias + ReLU (the zoo's MLP layers, DnnLayer core_layer/core_layer.py:102-118,201-226; the layer's GEMMs stay
  * library GEMMs): dz[b,n] = y[b,n] > 0 ? dy[b,n] : 0 (y = the layer's OUTPUT) and dbias[n] = sum_b dz[b,n] in ONE pass over [B, N]
  * (torch: threshold_backward, then a column reduce).  y, dy, dz in `dtype` storage (FIL_F32 / FIL_BF16), dbias fp32; deterministic (block
- * partials in block order, ticket as in fil_merge_softmax_bwd: the workspace's first word is zero on entry and on exit). */
+ * partials summed in block order by a second, tiny launch). */
 size_t fil_relu_bias_bwd_workspace_bytes(int B, int N);
 int fil_relu_bias_bwd(const void* y, const void* dy, void* dz, float* dbias, int B, int N, int dtype, void* workspace, size_t workspace_bytes,
                       void* stream);

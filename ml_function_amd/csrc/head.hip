@@ -63,7 +63,7 @@ __global__ __launch_bounds__(1024) void bce_mean_fwd_kernel(const float* __restr
 // in it (model/models.py:87,104).  torch: cat, GEMM [B,D]x[D,O] (O = 2), bias add, softmax and their backward: ~12 launches for 4 KB
 // of output.  Here ONE launch each way: the parts are read where they lie (no concatenated copy), fp32 or bf16 storage, fp32 math.
 constexpr int kMergeMaxO = 8;       // Dense units of the head
-constexpr int kMergeRows = 64;      // samples per workgroup of the backward
+constexpr int kMergeRows = 64;      // samples per workgroup of the backward (four waves x 16 rows)
 struct MergeParts {
   const void* p[4];
   void* dp[4];
@@ -80,13 +80,14 @@ __device__ __forceinline__ void merge_st(void* p, long i, float v, int bf) {
 }
 
 // out[b, :] = softmax(concat_i parts_i[b, :] W + bias): a wave per sample (lanes over the D columns, O dot products folded by the wave)
+template <int MO>   // MO >= O: 2 (the reference's output_dim = 2) or kMergeMaxO
 __global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, const float* __restrict__ W, const float* __restrict__ bias,
                                                                 float* __restrict__ out, int B, int O) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  float z[kMergeMaxO];
+  float z[MO];
 #pragma unroll
-  for (int o = 0; o < kMergeMaxO; ++o) z[o] = 0.f;
+  for (int o = 0; o < MO; ++o) z[o] = 0.f;
   int d0 = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, c
       const float x = merge_ld(mp.p[i], (long)b * w + d, mp.bf[i]);
       const float* wr = W + (long)(d0 + d) * O;
 #pragma unroll
-      for (int o = 0; o < kMergeMaxO; ++o)
+      for (int o = 0; o < MO; ++o)
         if (o < O) z[o] = fmaf(x, wr[o], z[o]);
     }
     d0 += w;
   }
 #pragma unroll
-  for (int o = 0; o < kMergeMaxO; ++o) z[o] = wave_sum(z[o]);
+  for (int o = 0; o < MO; ++o) z[o] = wave_sum(z[o]);
   if (lane == 0) {
     float m = -INFINITY;
     for (int o = 0; o < O; ++o) {
@@ -118,49 +119,68 @@ __global__ __launch_bounds__(256) void merge_softmax_fwd_kernel(MergeParts mp, c
 }
 
 // dz = out (dout - <dout, out>);  dparts_i[b, d] = sum_o dz[b, o] W[d, o];  block partials of dW[d, o] = sum_b x[b, d] dz[b, o] and
-// db[o] = sum_b dz[b, o] over the workgroup's kMergeRows samples (fixed order); the LAST workgroup to finish (a ticket) sums the
-// partials in block order -- a fixed order whoever that workgroup is -- into dW | db and re-arms the ticket.
+// db[o] = sum_b dz[b, o] over the workgroup's kMergeRows samples, summed in block order by block_partials_sum_kernel.  Wave w takes rows 16 w .. 16 w + 15 of the
+// block, its lanes 64 columns at a time (16 loads in flight per lane); the four waves' sums of a column chunk meet in LDS in wave
+// order.  (First form: 64 workgroups of 64 rows, a thread per column walking the rows one by one: 45 us for 2.4 MB.)
+template <int MO>
 __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, const float* __restrict__ W, const float* __restrict__ out,
-                                                                const float* __restrict__ dout, float* __restrict__ part, unsigned* __restrict__ ticket,
-                                                                float* __restrict__ dW, float* __restrict__ db, int B, int O) {
-  __shared__ float dz[kMergeRows][kMergeMaxO];
-  __shared__ unsigned last;
-  const int tid = threadIdx.x, b0 = blockIdx.x * kMergeRows, nrow = min(kMergeRows, B - b0), D = mp.D;
+                                                                const float* __restrict__ dout, float* __restrict__ part, int B, int O) {
+  __shared__ float dz[kMergeRows][MO];
+  __shared__ float red[4][64][MO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * kMergeRows, nrow = min(kMergeRows, B - b0), D = mp.D;
   for (int s = tid; s < kMergeRows; s += 256) {
-    float dot = 0.f, p[kMergeMaxO], g[kMergeMaxO];
+    float dot = 0.f, p[MO], g[MO];
 #pragma unroll
-    for (int o = 0; o < kMergeMaxO; ++o) {
+    for (int o = 0; o < MO; ++o) {
       p[o] = (s < nrow && o < O) ? out[(long)(b0 + s) * O + o] : 0.f;
       g[o] = (s < nrow && o < O) ? dout[(long)(b0 + s) * O + o] : 0.f;
       dot = fmaf(p[o], g[o], dot);
     }
 #pragma unroll
-    for (int o = 0; o < kMergeMaxO; ++o) dz[s][o] = p[o] * (g[o] - dot);
+    for (int o = 0; o < MO; ++o) dz[s][o] = p[o] * (g[o] - dot);
   }
   __syncthreads();
   float* mypart = part + (long)blockIdx.x * (D + 1) * O;
+  const int r0 = wave * 16;     // this wave's rows of the block
   int d0 = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int w = mp.w[i];
-    for (int d = tid; d < w; d += 256) {
-      float wr[kMergeMaxO], acc[kMergeMaxO];
+    for (int dc = 0; dc < w; dc += 64) {   // (uniform over the workgroup: barriers inside)
+      const int d = dc + lane;
+      float wr[MO], acc[MO];
 #pragma unroll
-      for (int o = 0; o < kMergeMaxO; ++o) {
-        wr[o] = o < O ? W[(long)(d0 + d) * O + o] : 0.f;
+      for (int o = 0; o < MO; ++o) {
+        wr[o] = (d < w && o < O) ? W[(long)(d0 + d) * O + o] : 0.f;
         acc[o] = 0.f;
       }
-      for (int s = 0; s < nrow; ++s) {
-        const float x = merge_ld(mp.p[i], (long)(b0 + s) * w + d, mp.bf[i]);
-        float dx = 0.f;
+      if (d < w) {
 #pragma unroll
-        for (int o = 0; o < kMergeMaxO; ++o) {
-          acc[o] = fmaf(x, dz[s][o], acc[o]);
-          dx = fmaf(dz[s][o], wr[o], dx);
+        for (int h = 0; h < 1; ++h) {
+          float xs[16];     // sixteen rows of this column: all loads in flight before the first store
+#pragma unroll
+          for (int s = 0; s < 16; ++s) xs[s] = r0 + 16 * h + s < nrow ? merge_ld(mp.p[i], (long)(b0 + r0 + 16 * h + s) * w + d, mp.bf[i]) : 0.f;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            const int rr = r0 + 16 * h + s;
+            float dx = 0.f;
+#pragma unroll
+            for (int o = 0; o < MO; ++o) {
+              acc[o] = fmaf(xs[s], dz[rr][o], acc[o]);
+              dx = fmaf(dz[rr][o], wr[o], dx);
+            }
+            if (rr < nrow && mp.dp[i] != nullptr) merge_st(mp.dp[i], (long)(b0 + rr) * w + d, dx, mp.bf[i]);
+          }
         }
-        if (mp.dp[i] != nullptr) merge_st(mp.dp[i], (long)(b0 + s) * w + d, dx, mp.bf[i]);
       }
-      for (int o = 0; o < O; ++o) mypart[(long)(d0 + d) * O + o] = acc[o];
+#pragma unroll
+      for (int o = 0; o < MO; ++o) red[wave][lane][o] = acc[o];
+      __syncthreads();
+      if (wave == 0 && d < w) {
+        for (int o = 0; o < O; ++o) mypart[(long)(d0 + d) * O + o] = (red[0][lane][o] + red[1][lane][o]) + (red[2][lane][o] + red[3][lane][o]);
+      }
+      __syncthreads();
     }
     d0 += w;
   }
@@ -169,71 +189,103 @@ __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, c
     for (int s = 0; s < nrow; ++s) t += dz[s][tid];
     mypart[(long)D * O + tid] = t;
   }
-  // release this workgroup's partials, take a ticket; the last one acquires and reduces
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (last == 0u) return;
-  __threadfence();
-  const int n = (D + 1) * O;
-  for (int i = tid; i < n; i += 256) {
-    float t0 = 0.f, t1 = 0.f;
-    unsigned blk = 0;
-    for (; blk + 1 < gridDim.x; blk += 2) {
-      t0 += __builtin_nontemporal_load(part + (long)blk * n + i);
-      t1 += __builtin_nontemporal_load(part + (long)(blk + 1) * n + i);
-    }
-    if (blk < gridDim.x) t0 += __builtin_nontemporal_load(part + (long)blk * n + i);
-    const float v = t0 + t1;
-    if (i < D * O) dW[i] = v;
-    else db[i - D * O] = v;
-  }
-  if (tid == 0) *ticket = 0u;   // (re-armed for the next call on this stream)
 }
 
+// out[i] (i < n1) | out2[i - n1] = sum over the nblk block partials part[blk][n] in block order, eight in flight (a second, tiny launch:
+// a ticketed in-kernel reduction by the last workgroup needs an agent-scope release per workgroup, which on this chip writes the whole
+// L2 back -- 45-55 us behind kernels that left it dirty, measured -- where the launch boundary costs ~3 us)
+__global__ __launch_bounds__(256) void block_partials_sum_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out, int n1,
+                                                                 float* __restrict__ out2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int blk = 0;
+  for (; blk + 7 < nblk; blk += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] += part[(long)(blk + u) * n + i];
+  }
+  for (; blk < nblk; ++blk) t[0] += part[(long)blk * n + i];
+  const float v = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  if (i < n1) out[i] = v;
+  else out2[i - n1] = v;
+}
 
 // ---- Dense + bias + ReLU of the zoo's MLPs (DnnLayer: core_layer/core_layer.py:102-118,201-226), backward half.  The two GEMMs of a
 // layer's backward stay library GEMMs; what torch runs around them -- threshold_backward over [B, N], then a column
 // reduce of the same [B, N] for the bias gradient -- is ONE pass here: dz = dy where y > 0 (else 0), written in dy's storage type, and
-// dbias[n] = sum_b dz[b, n] through block partials summed in block order by the last workgroup to finish (a ticket: deterministic).
+// dbias[n] = sum_b dz[b, n] through block partials summed in block order by block_partials_sum_kernel (deterministic).
 constexpr int kReluRows = 64;   // rows per workgroup
-template <typename T>
+__device__ __forceinline__ void relu_ld4(const float* p, float (&v)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void relu_ld4(const __hip_bfloat16* p, float (&v)[4]) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void relu_st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void relu_st4(__hip_bfloat16* p, const float (&v)[4]) {   // (the values are dy's own bf16 values or zero: exact)
+  uint2 t;
+  t.x = (__builtin_bit_cast(unsigned, v[0]) >> 16) | (__builtin_bit_cast(unsigned, v[1]) & 0xffff0000u);
+  t.y = (__builtin_bit_cast(unsigned, v[2]) >> 16) | (__builtin_bit_cast(unsigned, v[3]) & 0xffff0000u);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+// VEC (N % 4 == 0, N <= 1024): a thread owns four consecutive columns and every RL-th row of the block's 32 (16- / 8-byte accesses,
+// four rows in flight); the row lanes' sums meet through LDS in lane order.  Otherwise: a thread per column, row by row.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void relu_bias_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dz, float* __restrict__ part,
-                                                            unsigned* __restrict__ ticket, float* __restrict__ dbias, int B, int N) {
-  __shared__ unsigned last;
+                                                            int B, int N) {
+  __shared__ float red[1024];
   const int tid = threadIdx.x, b0 = blockIdx.x * kReluRows, nrow = min(kReluRows, B - b0);
-  for (int n = tid; n < N; n += 256) {
-    float t = 0.f;
-    for (int s = 0; s < nrow; ++s) {
-      const long i = (long)(b0 + s) * N + n;
-      const float g = (float)y[i] > 0.f ? (float)dy[i] : 0.f;
-      dz[i] = (T)g;
-      t += g;
+  if constexpr (VEC) {
+    const int Q = N >> 2, RL = 256 / Q, q = tid % Q, rl = tid / Q;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < RL) {
+      for (int r0 = rl; r0 < nrow; r0 += 4 * RL) {
+        float yv[4][4], gv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * RL;
+          if (r < nrow) {
+            relu_ld4(y + (long)(b0 + r) * N + 4 * q, yv[u]);
+            relu_ld4(dy + (long)(b0 + r) * N + 4 * q, gv[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * RL;
+          if (r < nrow) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              gv[u][e] = yv[u][e] > 0.f ? gv[u][e] : 0.f;
+              acc[e] += gv[u][e];
+            }
+            relu_st4(dz + (long)(b0 + r) * N + 4 * q, gv[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[rl * N + 4 * q + e] = acc[e];
     }
-    part[(long)blockIdx.x * N + n] = t;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (last == 0u) return;
-  __threadfence();
-  for (int n = tid; n < N; n += 256) {
-    float t0 = 0.f, t1 = 0.f;
-    unsigned blk = 0;
-    for (; blk + 1 < gridDim.x; blk += 2) {
-      t0 += __builtin_nontemporal_load(part + (long)blk * N + n);
-      t1 += __builtin_nontemporal_load(part + (long)(blk + 1) * N + n);
+    __syncthreads();
+    for (int n = tid; n < N; n += 256) {
+      float t = 0.f;
+      for (int l = 0; l < RL; ++l) t += red[l * N + n];
+      part[(long)blockIdx.x * N + n] = t;
     }
-    if (blk < gridDim.x) t0 += __builtin_nontemporal_load(part + (long)blk * N + n);
-    dbias[n] = t0 + t1;
+  } else {
+    for (int n = tid; n < N; n += 256) {
+      float t = 0.f;
+      for (int s = 0; s < nrow; ++s) {
+        const long i = (long)(b0 + s) * N + n;
+        const float g = (float)y[i] > 0.f ? (float)dy[i] : 0.f;
+        dz[i] = (T)g;
+        t += g;
+      }
+      part[(long)blockIdx.x * N + n] = t;
+    }
   }
-  if (tid == 0) *ticket = 0u;
 }
 
 }  // namespace fil
@@ -307,7 +359,8 @@ extern "C" int fil_merge_softmax_fwd(const void* const* parts, const int* widths
   FIL_CHECK_ARG(W != nullptr && bias != nullptr && out != nullptr);
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("merge_softmax_fwd", st, (double)B * (mp.D * 4.0 + O * 4.0));
-  hipLaunchKernelGGL(merge_softmax_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
+  if (O <= 2) hipLaunchKernelGGL(merge_softmax_fwd_kernel<2>, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
+  else hipLaunchKernelGGL(merge_softmax_fwd_kernel<kMergeMaxO>, dim3(cdiv(B, 4)), dim3(256), 0, st, mp, W, bias, out, B, O);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
@@ -329,13 +382,12 @@ extern "C" int fil_merge_softmax_bwd(const void* const* parts, const int* widths
   if (workspace == nullptr || workspace_bytes < fil_merge_softmax_bwd_workspace_bytes(B, mp.D, O))
     return fail(FIL_ERR_WORKSPACE, "fil_merge_softmax_bwd: workspace %zu < %zu bytes", workspace_bytes, fil_merge_softmax_bwd_workspace_bytes(B, mp.D, O));
   for (int i = 0; i < n_parts; ++i) mp.dp[i] = dparts != nullptr ? dparts[i] : nullptr;
-  // workspace: [ticket: one word the kernel leaves at zero | pad to 256 B | block partials].  The caller hands over ZEROED bytes the
-  // first time (the ticket); the kernel re-arms it, so a cached workspace needs no further clears.
-  unsigned* ticket = static_cast<unsigned*>(workspace);
-  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);   // block partials [nblk][(D + 1) O]
   ProfScope ps("merge_softmax_bwd", st, (double)B * (2.0 * mp.D * 4.0 + 2.0 * O * 4.0));
-  const int nblk = cdiv(B, kMergeRows);
-  hipLaunchKernelGGL(merge_softmax_bwd_kernel, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, ticket, dW, db, B, O);
+  const int nblk = cdiv(B, kMergeRows), n = (mp.D + 1) * O;
+  if (O <= 2) hipLaunchKernelGGL(merge_softmax_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, B, O);
+  else hipLaunchKernelGGL(merge_softmax_bwd_kernel<kMergeMaxO>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, B, O);
+  hipLaunchKernelGGL(block_partials_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, nblk, n, dW, mp.D * O, db);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
@@ -354,15 +406,19 @@ extern "C" int fil_relu_bias_bwd(const void* y, const void* dy, void* dz, float*
   FIL_CHECK_ARG(y != nullptr && dy != nullptr && dz != nullptr);
   if (workspace == nullptr || workspace_bytes < fil_relu_bias_bwd_workspace_bytes(B, N))
     return fail(FIL_ERR_WORKSPACE, "fil_relu_bias_bwd: workspace %zu < %zu bytes", workspace_bytes, fil_relu_bias_bwd_workspace_bytes(B, N));
-  unsigned* ticket = static_cast<unsigned*>(workspace);   // (zero on entry, left at zero: as fil_merge_softmax_bwd)
-  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);   // block partials [nblk][N]
   ProfScope ps("relu_bias_bwd", st, (double)B * N * 3.0 * (dtype == FIL_F32 ? 4.0 : 2.0));
   const int nblk = cdiv(B, kReluRows);
-  if (dtype == FIL_F32)
-    hipLaunchKernelGGL(relu_bias_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dz, part, ticket, dbias, B, N);
-  else
-    hipLaunchKernelGGL(relu_bias_bwd_kernel<__hip_bfloat16>, dim3(nblk), dim3(256), 0, st, (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy,
-                       (__hip_bfloat16*)dz, part, ticket, dbias, B, N);
+  const bool vec = (N & 3) == 0 && N <= 1024;
+#define FIL_RELU(T, V) \
+  hipLaunchKernelGGL((relu_bias_bwd_kernel<T, V>), dim3(nblk), dim3(256), 0, st, (const T*)y, (const T*)dy, (T*)dz, part, B, N)
+  if (dtype == FIL_F32) {
+    if (vec) FIL_RELU(float, true); else FIL_RELU(float, false);
+  } else {
+    if (vec) FIL_RELU(__hip_bfloat16, true); else FIL_RELU(__hip_bfloat16, false);
+  }
+#undef FIL_RELU
+  hipLaunchKernelGGL(block_partials_sum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, nblk, N, dbias, N, (float*)nullptr);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }

@@ -66,21 +66,6 @@ def _scratch(nbytes, device, tag):
     return ws
 
 
-def _scratch_zeroed(nbytes, device, tag):
-    """A cached workspace whose bytes were ZERO when it was created and that its users leave zero where they need it to be (a ticket
-    word the kernel re-arms): zero-filled once per (re)allocation, not per call.  Under capture: a fresh zeroed allocation (the graph's
-    own memset)."""
-    nbytes = max(int(nbytes), 256)
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    key = (device, stream_ptr(), ("zeroed", tag))
-    ws = _WS_CACHE.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _WS_CACHE[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        _WS_LAST_USE[(device, key[1])] = time.monotonic()
-    return ws
-
-
 def release_scratch():
     """Drop every cached scratch workspace (they are re-created on demand)."""
     _WS_CACHE.clear()
@@ -568,7 +553,7 @@ class _DenseReluFn(torch.autograd.Function):
         dy = dy.to(y.dtype).contiguous()
         dz = torch.empty_like(y)
         db = torch.empty((N,), dtype=torch.float32, device=y.device)
-        ws = _scratch_zeroed(lib.fil_relu_bias_bwd_workspace_bytes(B, N), y.device, "relu_bias_bwd")
+        ws = _scratch(lib.fil_relu_bias_bwd_workspace_bytes(B, N), y.device, "relu_bias_bwd")
         check(lib.fil_relu_bias_bwd(ptr(y), ptr(dy), ptr(dz), ptr(db), B, N, FIL_F32 if y.dtype == torch.float32 else FIL_BF16, ptr(ws),
                                     ws.numel(), stream_ptr()), "fil_relu_bias_bwd")
         with torch.autocast("cuda", enabled=False):
@@ -611,7 +596,7 @@ class _MergeSoftmaxFn(torch.autograd.Function):
         dparts = [torch.empty_like(t) if n else None for t, n in zip(parts, need)]
         dW = torch.empty_like(kernel)
         db = torch.empty((O,), dtype=torch.float32, device=kernel.device)
-        ws = _scratch_zeroed(lib.fil_merge_softmax_bwd_workspace_bytes(B, D, O), kernel.device, "merge_softmax_bwd")
+        ws = _scratch(lib.fil_merge_softmax_bwd_workspace_bytes(B, D, O), kernel.device, "merge_softmax_bwd")
         dp = (ctypes.c_void_p * len(parts))(*[None if t is None else t.data_ptr() for t in dparts])
         check(lib.fil_merge_softmax_bwd(ptr_array(parts), int_array(widths), int_array(dts), len(parts), ptr(kernel), ptr(out), ptr(g), dp,
                                         ptr(dW), ptr(db), B, O, ptr(ws), ws.numel(), stream_ptr()), "fil_merge_softmax_bwd")
