@@ -141,3 +141,48 @@ def test_bench_line_accounting():
     assert rf["frac"] == pytest.approx(rf["flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12 / rf["peak"], rel=1e-9)
     assert rf["avg_launch_ms"] < res["ms_per_step"] and res["executed_frac"] < rf["frac"] + 0.1
     assert res["value"] == pytest.approx(4096 / (res["ms_per_step"] * 1e-3), rel=1e-9)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(script_args, n, timeout=900):
+    """n fresh ranks through torch.distributed.run (children of this process; nothing here hands them a GPU context)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+
+
+def test_rccl_worker_on_one_rank():
+    """The N-rank RCCL check of tests/dp_rccl_worker.py at world size 1 (what a one-GPU box can run): the worker itself, its launcher and
+    the overlapped reducer; the comparison is then the shard against itself."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run_ranks([os.path.join(root, "tests", "dp_rccl_worker.py")], 1)
+    assert r.returncode == 0 and "DP_RCCL_OK 1" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node; a gpurun box has one)")
+def test_two_ranks_over_rccl():
+    """World size 2 over RCCL / xGMI (skipped on a one-GPU box): (a) the sum of the two shards' gradients after the overlapped
+    layer-wise all-reduce == the full-batch gradient, identical on both ranks (tests/dp_rccl_worker.py); (b) bench.py --gpus 2 prints
+    its line with both ranks seen and the collectives' fields filled."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run_ranks([os.path.join(root, "tests", "dp_rccl_worker.py")], 2)
+    assert r.returncode == 0 and "DP_RCCL_OK 2" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "1", "--no-cpu-baseline"], 2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["rccl"]["world_size_seen"] == 2 and res["config"]["global_batch"] == 2 * 4096
+    assert res["value"] == pytest.approx(2 * 4096 / (res["ms_per_step"] * 1e-3), rel=1e-6)
+    assert len(res["rccl"]["ms_per_step_per_rank"]) == 2 and res["rccl"]["allreduce_alone_ms"] > 0
