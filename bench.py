@@ -760,6 +760,10 @@ def main():
             "ms_per_step_median": sorted(window_dts)[len(window_dts) // 2] / args.steps * 1e3,
             "ms_per_step_min": min(window_dts) / args.steps * 1e3, "ms_per_step_max": max(window_dts) / args.steps * 1e3,
             "dtype": "f32", "data": "synthetic",
+            "untimed_steps_before_the_timed_ones": {
+                "warmup_before_profiling_passes": args.warmup, "dominant_kernel_pick_pass": n_pre if prof_on else 0,
+                "per_kernel_table_pass": args.steps if prof_on else 0, "warmup_directly_in_front_of_the_timed_steps": args.warmup,
+                "note": "`warmup` above = the W steps directly in front of the K timed ones; the untimed per-kernel passes run before them"},
             "config": {"workload": "xDeepFM CIN 3x128 feature maps fwd+bwd, F=39 K=16, B=%d per GPU, fp32 "
                                    "(BASELINE.json configs[3])" % shape["batch"], "global_batch": global_batch,
                        "parallelism": "dp%d" % world, "grad_allreduce_bytes": int(flat.numel() * 4) if use_dist else 0},

@@ -1,6 +1,6 @@
 """Side-by-side experiment builds: python tools/abl_build.py <name> "<extra hipcc flags>" <file.hip> [...]
 Recompiles only the listed sources of ml_function_amd/csrc with the extra flags and links them with the default build's other
-objects into ml_function_amd/abl/libfil_<name>.so (git-ignored; travels with gpurun).  Run with FIL_LIB_PATH=<that file>."""
+objects into tools/abl/libfil_<name>.so (git-ignored, outside the product package; travels with gpurun).  Run with FIL_LIB_PATH=<that file>."""
 import os
 import subprocess
 import sys
@@ -12,7 +12,7 @@ from ml_function_amd import build as B
 def main():
     name, flags, files = sys.argv[1], sys.argv[2].split(), sys.argv[3:]
     B.build(verbose=False)
-    out_dir = os.path.join(B.HERE, "abl")
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abl")
     os.makedirs(out_dir, exist_ok=True)
     objs = []
     for src in B._sources():

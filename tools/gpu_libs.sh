@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 tag=$1; shift
 mkdir -p gpurun_out/$tag
 for name in "$@"; do
-  lib=""; [ "$name" != default ] && lib=$GRAFT_REPO_ROOT/ml_function_amd/abl/libfil_$name.so
+  lib=""; [ "$name" != default ] && lib=$GRAFT_REPO_ROOT/tools/abl/libfil_$name.so
   FIL_LIB_PATH=$lib timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side > gpurun_out/$tag/bench_$name.json 2> gpurun_out/$tag/bench_$name.err
   python - <<PY
 import json
