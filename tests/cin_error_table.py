@@ -1,22 +1,50 @@
-"""Test utility (lives under tests/ because it checks against oracle/): norm-relative / max-relative error of the CIN
-outputs and gradients against the fp64 oracle, for modes 0 (the default path) and 1 (general kernels).
-    python tests/cin_error_table.py   (needs a GPU)"""
-import os, sys
+"""Test utility (lives under tests/ because it checks against oracle/): norm-relative / max-relative error of every CIN output and
+gradient against the fp64 oracle graph (oracle/graph.py:cin, op for op, Z materialised; evaluated in float64 on the GPU in shards) at
+the BENCHMARK shape -- B=4096, F=39, K=16, 3x128 -- for mode 0 (the exact-fp32 headline path), mode 2 (FIL_CIN_BF16X3: the same three
+GEMM launches on split-bf16 operands) and mode 1 (general kernels), uniform (x10) and normal inputs.
+    python tests/cin_error_table.py [B]   (needs a GPU)"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+import torch
+
 from ml_function_amd import synth, functional as Fn
-from oracle import closed
-def rel(a,b):
-    a=a.detach().cpu().double().numpy().ravel(); b=np.asarray(b,dtype=np.float64).ravel()
-    return float(np.linalg.norm(a-b)/np.linalg.norm(b)), float(np.abs(a-b).max()/np.abs(b).max())
-for dist in ["uniform","normal"]:
-    c=synth.cin_case(256,39,16,[128,128,128],dist=dist)
-    if dist=="uniform": c["x"]=(c["x"]*10).astype(np.float32)
-    want=closed.cin_fwd(c["x"],c["Ws"],c["bs"],c["dense_w"],c["dense_b"],1)
-    dx,dWs,dbs,ddw,ddb=closed.cin_bwd(c["x"],c["Ws"],c["bs"],c["dense_w"],c["g"],1)
-    for mode in [0,1]:
-        dev=lambda a: torch.tensor(a,dtype=torch.float32,device="cuda")
-        x=dev(c["x"]).requires_grad_(); Ws=[dev(w).requires_grad_() for w in c["Ws"]]; bs=[dev(b).requires_grad_() for b in c["bs"]]
-        dw,db=dev(c["dense_w"]).requires_grad_(),dev(c["dense_b"]).requires_grad_()
-        out=Fn.cin(x,Ws,bs,dw,db,output_dim=1,mode=mode); out.backward(dev(c["g"]))
-        print(dist,"mode",mode,"out %.2e/%.2e"%rel(out,want),"dx %.2e/%.2e"%rel(x.grad,dx)," ".join("dW%d %.2e/%.2e"%((l,)+rel(Ws[l].grad,dWs[l])) for l in range(3)))
+from oracle import graph
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy().ravel()
+    b = b.detach().double().cpu().numpy().ravel()
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b)), float(np.abs(a - b).max() / np.abs(b).max())
+
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+print("CIN error table at B=%d, F=39, K=16, 3x128: norm-relative / max-relative error against the fp64 oracle graph" % B)
+for dist in ["uniform", "normal"]:
+    c = synth.cin_case(B, 39, 16, [128, 128, 128], dist=dist)
+    if dist == "uniform":
+        c["x"] = (c["x"] * 10).astype(np.float32)
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device="cuda")
+    Ws, bs, dw, db = [T(w).requires_grad_() for w in c["Ws"]], [T(b).requires_grad_() for b in c["bs"]], T(c["dense_w"]).requires_grad_(), T(c["dense_b"]).requires_grad_()
+    outs, dxs = [], []
+    for lo in range(0, B, 512):
+        x = T(c["x"][lo:lo + 512]).requires_grad_()
+        out = graph.cin(x, Ws, bs, dw, db, output_dim=1)
+        out.backward(T(c["g"][lo:lo + 512]))
+        outs.append(out.detach())
+        dxs.append(x.grad)
+    want, wdx = torch.cat(outs), torch.cat(dxs)
+    for mode, name in ((0, "exact fp32 (mode 0)"), (2, "split bf16x3 (mode 2)"), (1, "general kernels (mode 1)")):
+        dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+        x = dev(c["x"]).requires_grad_()
+        W2 = [dev(w).requires_grad_() for w in c["Ws"]]
+        b2 = [dev(b).requires_grad_() for b in c["bs"]]
+        dw2, db2 = dev(c["dense_w"]).requires_grad_(), dev(c["dense_b"]).requires_grad_()
+        out = Fn.cin(x, W2, b2, dw2, db2, output_dim=1, mode=mode)
+        out.backward(dev(c["g"]))
+        print("%-8s %-26s out %.2e/%.2e  dx %.2e/%.2e  " % ((dist, name) + rel(out, want) + rel(x.grad, wdx)) +
+              "  ".join("dW%d %.2e/%.2e" % ((l + 1,) + rel(W2[l].grad, Ws[l].grad)) for l in range(3)) +
+              "  " + "  ".join("db%d %.2e/%.2e" % ((l + 1,) + rel(b2[l].grad, bs[l].grad)) for l in range(3)))
+    torch.cuda.empty_cache()
