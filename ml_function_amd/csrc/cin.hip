@@ -524,7 +524,10 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         const long npack = (long)chunks * F * 2 * JTs * 128;
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
         const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);
-        hipLaunchKernelGGL(cin_qtail_pack_kernel, dim3(nbf + nbz), dim3(256), 0, st, qtT, WfT, qtWzT, F, Hpp, JTs, chunks, nbf, HS0, tiles);
+        // (split-bf16 mode: + the forward's planes of [W1s | Ts], from W1 and T themselves)
+        const int NTq = qsplit ? cin_qs_steps(F, JTs) : 0, nbq = qsplit ? std::min(cdiv(NTq * 512, 256), 512) : 0;
+        hipLaunchKernelGGL(cin_qtail_pack_kernel, dim3(nbf + nbz + nbq), dim3(256), 0, st, qtT, WfT, qtWzT, F, Hpp, JTs, chunks, nbf, HS0, tiles, nbz, W[0],
+                           H[0], Wb, NTq);
       }
       FIL_CHECK_LAUNCH();
       {
@@ -539,9 +542,8 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
           head_done = true;
         }
         if (qsplit) {
-          // split-bf16 operands: the planes of [W1s | Ts] from the two packed fp32 operands, then the same GEMM on the bf16 pipe
+          // split-bf16 operands (their planes came out of the pack launch above): the same GEMM on the bf16 pipe
           const int NT = cin_qs_steps(F, JTs);
-          hipLaunchKernelGGL(cin_qs_pack_wb_kernel, dim3(cdiv(NT * 512, 256)), dim3(256), 0, st, Wf, WfT, Wb, NT, F * JTs);
           if (!cin_launch_fwdq_b(st, JTs, x2T, XL, Wb, NT, bias[0], qtWsnP, JT, qtCvec, x1T, qtR, HS0, const_cast<float*>(pa.part[0]),
                                  const_cast<float*>(pa.part[p]), const_cast<float*>(pa.part[lL]), (int)M, F, H[0], hf))
             return fail(FIL_ERR_UNSUPPORTED, "fil_cin_fwd: no split-bf16 forward kernel for JT=%d (F=%d)", JTs, F);
@@ -829,9 +831,11 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const size_t sh = (size_t)256 * (F + 3 + (output_dim == 1 ? L : 0)) * sizeof(float);
       allow_lds(cin_qtail_xe_kernel, sh);
       const int np = (int)std::min<long>(((long)tiles0 * 32 * HS0 + 255) / 256, 1024);   // + W1 in the dZ kernel's slot order
+      const int nq2 = qsplit ? 2 * std::min(cdiv(tiles0 * 512, 256), 256) : 0;           // + (split-bf16 mode) W1s and Ts in slot order as planes
       // (output_dim == 1: + the dense head's backward -- dP and the block partials of ddense_w | ddense_b)
-      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + np), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc,
-                         output_dim == 1 ? g : nullptr, dense_w, pooled, dP, qt_hpart, (int)LK, lL, p, W[0], Wz, H[0], JTs, HS0, tiles0);
+      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + np + nq2), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc,
+                         output_dim == 1 ? g : nullptr, dense_w, pooled, dP, qt_hpart, (int)LK, lL, p, W[0], Wz, H[0], JTs, HS0, tiles0, np, qtT, Hpp,
+                         Wzb1, Wzb2);
     }
     FIL_CHECK_LAUNCH();
     {
@@ -885,8 +889,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       ProfScope ps("cin_bwd_dz_q", st, algo1 + algo_tail, gemm_flops(M, 1, Cl, H[0]) + gemm_flops(M, 1, Cl, Hpp));
       // (the kernel also finishes dx: + the shortcut's part in dxT, + dP_L c, transposed to [B,F,K] on the way out)
       bool split_done = false;
-      if (qsplit) {   // split-bf16 operands: both layers' slot-ordered weights as planes, then the same two passes on the bf16 pipe
-        hipLaunchKernelGGL(cin_qs_pack_wz_kernel, dim3(cdiv(2 * tiles0 * 512, 256)), dim3(256), 0, st, Wz, qtWzT, Wzb1, Wzb2, tiles0);
+      if (qsplit) {   // split-bf16 operands (the planes of both layers' slot-ordered weights came out of the operand-row launch)
         split_done = cin_launch_dz2_b(st, JTs, Gbuf[cur], xpT, HS0, dPL, (int)LK, K, Wzb1, Wzb2, xT, dxT, /*accumulate=*/1, (int)M, F, H[0], Hpp, periods, dx, qtCvec);
       }
       if (!split_done &&

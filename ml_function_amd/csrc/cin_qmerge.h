@@ -268,10 +268,19 @@ static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* _
                                                                   const float* __restrict__ g, const float* __restrict__ dense_w,
                                                                   const float* __restrict__ pooled, float* __restrict__ dP, float* __restrict__ hpart,
                                                                   int LK, int lL, int lp, const float* __restrict__ W0, float* __restrict__ Wz,
-                                                                  int H0, int JTs, int HS0, int tiles0) {
+                                                                  int H0, int JTs, int HS0, int tiles0, int npz = -1,
+                                                                  const float* __restrict__ Tq = nullptr, int HT = 0, u32x4* __restrict__ Wzb1 = nullptr,
+                                                                  u32x4* __restrict__ Wzb2 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x >= nscale) {   // the first layer's weights in the dZ kernel's slot order (nothing else uses that buffer here)
-    cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, blockIdx.x - nscale, gridDim.x - nscale);
+    if (npz < 0) npz = gridDim.x - nscale;
+    const int b = blockIdx.x - nscale;
+    if (b < npz) cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, b, npz);
+    else {   // split-bf16 mode: both layers' slot-ordered weights as planes (cin_qs_pack_wz_body), half of the extra workgroups each
+      const int nq = ((int)gridDim.x - nscale - npz) >> 1, q = b - npz;
+      if (q < nq) cin_qs_pack_wz_body(W0, H0, Wzb1, tiles0, F, JTs, q, nq);
+      else if (q < 2 * nq) cin_qs_pack_wz_body(Tq, HT, Wzb2, tiles0, F, JTs, q - nq, nq);
+    }
     return;
   }
   // row image: F products | dP_L | dP_p | (head) g * pooled of the row's column in each of the L = LK/K layers | g on the sample's first row

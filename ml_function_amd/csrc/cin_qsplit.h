@@ -13,88 +13,9 @@
 // MFMA 32x32x16 operand maps: lane (r = lane & 31, half = lane >> 5) supplies A[i = r][k = 8 half .. 8 half + 7] and
 // B[k = 8 half .. 8 half + 7][j = r], eight bf16 in four dwords; the accumulator layout is the 32x32x2 one (mfma32_row).
 #pragma once
-#include "cin_qmerge.h"
+#include "cin_qmerge.h"   // (-> cin_qtail.h -> cin_split.h: the cut, the MFMA helpers, the plane layouts and their pack bodies)
 
 namespace fil {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x16 mfma32b(const u32x4& a, const u32x4& b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// acc += A B to fp32 accuracy from the pieces, small terms first
-__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
-  c = mfma32b(a[2], b[0], c);
-  c = mfma32b(a[0], b[2], c);
-  c = mfma32b(a[1], b[1], c);
-  c = mfma32b(a[1], b[0], c);
-  c = mfma32b(a[0], b[1], c);
-  c = mfma32b(a[0], b[0], c);
-  return c;
-}
-
-// two fp32 values -> their top halves in one dword (element 0 in the low half): a bf16 pair by truncation
-__device__ __forceinline__ unsigned pack_hi(float lo, float hi) {
-  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
-}
-__device__ __forceinline__ float top8(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
-// eight fp32 values -> the three bf16 planes of one MFMA operand (6.5 vector instructions per value: and, sub, and, sub + 1.5 perm)
-__device__ __forceinline__ void split3(const float (&p)[8], u32x4 (&a)[3]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float p0 = p[2 * q], p1 = p[2 * q + 1];
-    const float r0 = p0 - top8(p0), r1 = p1 - top8(p1);
-    const float s0 = r0 - top8(r0), s1 = r1 - top8(r1);
-    a[0][q] = pack_hi(p0, p1);
-    a[1][q] = pack_hi(r0, r1);
-    a[2][q] = pack_hi(s0, s1);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Geometry of the pair slots.  A wave half walks the slots s = h JT + j (the exact kernels' steps: pair (h, (h + 2j + half) mod F)) eight
-// per MFMA; a PERIOD is HPS values of h = KP whole MFMA steps (HPS JT = 8 KP, KP >= 2), inside which slot -> (h - h0, j) is compile-time.
-template <int JT>
-struct QsGeo {
-  static constexpr int HPS0 = 8 / gcd_c(8, JT);
-  static constexpr int HPS = HPS0 * JT / 8 >= 2 ? HPS0 : 2 * HPS0;
-  static constexpr int KP = HPS * JT / 8;
-  static constexpr int WS = HPS + 2 * JT - 2;   // window of wrapped positions a period touches: t = (h - h0) + 2j
-  static_assert(HPS * JT == 8 * KP && KP >= 2, "a period is a whole number (>= 2) of 8-slot steps");
-};
-inline int cin_qs_hps(int JT) {
-  const int h0 = 8 / cin_gcd(8, JT);
-  return h0 * JT / 8 >= 2 ? h0 : 2 * h0;
-}
-inline int cin_qs_steps(int F, int JT) {   // MFMA steps of the forward's reduction (slots past F JT carry zero weights)
-  const int hps = cin_qs_hps(JT);
-  return (F + hps - 1) / hps * (hps * JT / 8);
-}
-constexpr int kQsStageBytes = 24 * 1024;   // one forward step of B planes: [plane 3][column block 8][lane 64][8 bf16]
-constexpr int kQsStages = 4;
-
-// [W1s | Ts] in the forward operand layout of the exact kernel ([slot s][half][r][4]: cin_pack_wf_sym_body) -> the split planes
-// Wb [step t][plane][nb 0..7][lane][8 bf16]: element e of lane (r, half) = the weight of slot 8 t + e, column 4 r + (nb & 3) of
-// W1s (nb < 4) or Ts (nb >= 4).  One thread per (t, nb, lane).
-static __global__ __launch_bounds__(256) void cin_qs_pack_wb_kernel(const float* __restrict__ W1f, const float* __restrict__ WTf, u32x4* __restrict__ Wb,
-                                                                    int NT, int nslots) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= NT * 512) return;
-  const int lane = idx & 63, nb = (idx >> 6) & 7, t = idx >> 9;
-  const int r = lane & 31, half = lane >> 5;
-  const float* src = (nb < 4 ? W1f : WTf) + half * 128 + 4 * r + (nb & 3);
-  float p[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int s = 8 * t + e;
-    p[e] = s < nslots ? src[(long)s * 256] : 0.f;
-  }
-  u32x4 a[3];
-  split3(p, a);
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) Wb[((long)(t * 3 + pl) * 8 + nb) * 64 + lane] = a[pl];
-}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Forward: [x1 | R] = pairs(x) [W1s | Ts] on split operands.  Workgroup = 8 waves = 256 rows (two waves per SIMD), wave = 32 rows x 256
@@ -246,26 +167,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cin_fwdq_b_kernel(const float* __r
 // steps deep, 16-byte scalar-offset buffer loads): 24 KB per tile and wave -- the LDS holds the two workgroups' dX images, there is no
 // room for a shared ring, so this kernel is bound by the L1 (64 B/clk/CU = its MFMA time at two waves per SIMD).
 //
-// Wzb [tile][step t][plane][lane][8 bf16]: element e of lane (r, half) = Wz[tile][slot row r][column half*64 + 8 t + e].
-static __global__ __launch_bounds__(256) void cin_qs_pack_wz_kernel(const float* __restrict__ Wz1, const float* __restrict__ Wz2, u32x4* __restrict__ Wzb1,
-                                                                    u32x4* __restrict__ Wzb2, int tiles) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int per = tiles * 512;
-  if (idx >= 2 * per) return;
-  const int which = idx >= per ? 1 : 0;
-  const int i = idx - which * per;
-  const int lane = i & 63, t = (i >> 6) & 7, tile = i >> 9;
-  const int r = lane & 31, half = lane >> 5;
-  const float* src = (which ? Wz2 : Wz1) + ((long)tile * 32 + r) * 128 + half * 64 + 8 * t;
-  const f32x4s lo = *reinterpret_cast<const f32x4s*>(src), hi = *reinterpret_cast<const f32x4s*>(src + 4);
-  const float p[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  u32x4 a[3];
-  split3(p, a);
-  u32x4* dst = (which ? Wzb2 : Wzb1) + ((long)(tile * 8 + t) * 3) * 64 + lane;
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) dst[pl * 64] = a[pl];
-}
-
+// Wzb [tile][step t][plane][lane][8 bf16]: cin_qs_pack_wz_body (cin_split.h).
 template <int JT, int G>
 __global__ __launch_bounds__(256, 2) void cin_dz2_b_kernel(const float* __restrict__ g1T, const float* __restrict__ g2T, int HS,
                                                            const float* __restrict__ dsc, int ldp, int K, const u32x4* __restrict__ Wzb1,

@@ -12,6 +12,7 @@
 // dW_p, dW_L and the biases.  Every sum runs in a fixed order.
 #pragma once
 #include "cin_kernels.h"
+#include "cin_split.h"
 
 namespace fil {
 
@@ -89,11 +90,16 @@ static __global__ __launch_bounds__(256) void cin_qtail_prep_kernel(const float*
   else qt_wsum_body(Wp, wsum_p, Hpp * F, Hq, wsn_p, Hpp, F, JT2, chunksp, b - nt - npk - nwl, gridDim.x - nt - npk - nwl);
 }
 
-// T in both operand layouts from one launch: [0, nbf) the forward kernel's (cin_pack_wf_sym_body), the rest the dZ kernel's slot order
+// T in both operand layouts from one launch: [0, nbf) the forward kernel's (cin_pack_wf_sym_body), [nbf, nbf + nbz) the dZ kernel's slot
+// order; split-bf16 mode (nbq > 0): the rest writes the forward's planes of [W1s | Ts] (cin_qs_pack_wb_body, straight from W1 and T)
 static __global__ __launch_bounds__(256) void cin_qtail_pack_kernel(const float* __restrict__ T, float* __restrict__ Wf, float* __restrict__ Wz, int F,
-                                                                    int H, int JTs, int chunks, int nbf, int HS, int tiles) {
+                                                                    int H, int JTs, int chunks, int nbf, int HS, int tiles, int nbz = -1,
+                                                                    const float* __restrict__ W1 = nullptr, int H1 = 0, u32x4* __restrict__ Wb = nullptr,
+                                                                    int NT = 0) {
+  if (nbz < 0) nbz = gridDim.x - nbf;
   if ((int)blockIdx.x < nbf) cin_pack_wf_sym_body(T, Wf, F, H, 2 * JTs, chunks, blockIdx.x, nbf);
-  else cin_pack_wz_sym_body(T, Wz, F, H, JTs, HS, tiles, blockIdx.x - nbf, gridDim.x - nbf);
+  else if ((int)blockIdx.x < nbf + nbz) cin_pack_wz_sym_body(T, Wz, F, H, JTs, HS, tiles, blockIdx.x - nbf, nbz);
+  else cin_qs_pack_wb_body(W1, H1, T, H, Wb, NT, F, JTs, blockIdx.x - nbf - nbz, gridDim.x - nbf - nbz);
 }
 
 constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
