@@ -71,7 +71,10 @@ int fil_fm_pairs_bwd(const float* emb, const float* gpairs, float* demb, int B, 
 /* ---------------------------------------------------------------------------------------------
  * A2  DCN cross network -- replaces CrossLayer.call, interactive_layer.py:275-282, all L layers fused.
  *   x [B,D], w [L,D], b [L,D] (the reference's L tensors [D,1] stacked), y [B,D], s [B,L] (saved dots).
- *   bwd: g [B,D] -> dx [B,D], dw [L,D], db [L,D].  Limits: D <= 4096, L <= 6.
+ *   bwd: g [B,D] -> dx [B,D], dw [L,D], db [L,D].
+ *   Limit: L <= 16.  D <= 4096 with L <= 6 and 2 L D 4 bytes <= 160 KiB run the register-resident kernels (a sample's row in one
+ *   wave's registers, every parameter in LDS, all layers fused); anything else takes the generic two-pass kernels (any D): the closed
+ *   form of the recurrence -- L dot products per sample in one pass over its row, then y = c_L x0 + sum_t b_t column by column.
  */
 int fil_dcn_fwd(const float* x, const float* w, const float* b, float* y, float* s, int B, int D, int L, void* stream);
 size_t fil_dcn_bwd_workspace_bytes(int B, int D, int L);

@@ -335,35 +335,37 @@ __global__ __launch_bounds__(256) void dcn_reduce_closed_kernel(const float* __r
 // pass 1 (wave per sample): a0 = g.x0, c_t = w_t.x0, then the scalar recurrence -> ds[n,l]
 // pass 2 (thread per column d, loop over a chunk of samples): everything is elementwise given s[n,:], ds[n,:];
 //         dw/db accumulate in 2*L registers per column; chunk partials are reduced by dcn_reduce_kernel.
-constexpr int kDcnMaxL = 6;
+constexpr int kDcnMaxL = 6;      // layers of the register-resident kernels
+constexpr int kDcnGenMaxL = 16;  // layers of the generic (two-pass) kernels: any D
 
+template <int LM>
 __global__ __launch_bounds__(256) void dcn_bwd_scalars_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ g, float* __restrict__ ds, int B, int D,
                                                               int L) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: descriptors built from it stay in SGPRs, no waterfall loops)
   for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
-    float acc[kDcnMaxL + 1];
+    float acc[LM + 1];
 #pragma unroll
-    for (int i = 0; i <= kDcnMaxL; ++i) acc[i] = 0.f;
+    for (int i = 0; i <= LM; ++i) acc[i] = 0.f;
     const float* xr = x + (long)n * D;
     const float* gr = g + (long)n * D;
     for (int d = lane; d < D; d += 64) {
       const float xv = xr[d];
       acc[0] = fmaf(gr[d], xv, acc[0]);
 #pragma unroll
-      for (int t = 0; t < kDcnMaxL; ++t)
+      for (int t = 0; t < LM; ++t)
         if (t < L) acc[t + 1] = fmaf(w[(long)t * D + d], xv, acc[t + 1]);
     }
 #pragma unroll
-    for (int i = 0; i <= kDcnMaxL; ++i) acc[i] = wave_sum(acc[i]);
+    for (int i = 0; i <= LM; ++i) acc[i] = wave_sum(acc[i]);
     if (lane == 0) {
-      float dsv[kDcnMaxL];
+      float dsv[LM];
 #pragma unroll
-      for (int l = kDcnMaxL - 1; l >= 0; --l) {
+      for (int l = LM - 1; l >= 0; --l) {
         if (l < L) {
           float t = acc[0];
 #pragma unroll
-          for (int u = l + 1; u < kDcnMaxL; ++u)
+          for (int u = l + 1; u < LM; ++u)
             if (u < L) t = fmaf(dsv[u], acc[u + 1], t);
           dsv[l] = t;
           ds[(long)n * L + l] = t;
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_scalars_kernel(const float* __res
   }
 }
 
+template <int LM>
 __global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, const float* __restrict__ s,
                                                            const float* __restrict__ ds, const float* __restrict__ g,
@@ -382,9 +385,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restri
                                                            int nchunk) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_lo = blockIdx.y * nchunk, n_hi = min(B, n_lo + nchunk);
-  float wl[kDcnMaxL], bl[kDcnMaxL], dwacc[kDcnMaxL], dbacc[kDcnMaxL];
+  float wl[LM], bl[LM], dwacc[LM], dbacc[LM];
 #pragma unroll
-  for (int l = 0; l < kDcnMaxL; ++l) {
+  for (int l = 0; l < LM; ++l) {
     wl[l] = (d < D && l < L) ? w[(long)l * D + d] : 0.f;
     bl[l] = (d < D && l < L) ? b[(long)l * D + d] : 0.f;
     dwacc[l] = dbacc[l] = 0.f;
@@ -393,16 +396,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restri
     for (int n = n_lo; n < n_hi; ++n) {
       const float x0 = x[(long)n * D + d];
       float gx = g[(long)n * D + d];
-      float xl[kDcnMaxL];
+      float xl[LM];
       float cur = x0;
 #pragma unroll
-      for (int l = 0; l < kDcnMaxL; ++l) {
+      for (int l = 0; l < LM; ++l) {
         xl[l] = cur;
         if (l < L) cur = fmaf(x0, s[(long)n * L + l], cur) + bl[l];
       }
       float dx0 = 0.f;
 #pragma unroll
-      for (int l = kDcnMaxL - 1; l >= 0; --l) {
+      for (int l = LM - 1; l >= 0; --l) {
         if (l < L) {
           const float dsl = ds[(long)n * L + l];
           dbacc[l] += gx;
@@ -415,12 +418,86 @@ __global__ __launch_bounds__(256) void dcn_bwd_cols_kernel(const float* __restri
     }
     float* pout = partial + (long)blockIdx.y * 2 * L * D;
 #pragma unroll
-    for (int l = 0; l < kDcnMaxL; ++l) {
+    for (int l = 0; l < LM; ++l) {
       if (l < L) {
         pout[(long)l * D + d] = dwacc[l];
         pout[(long)(L + l) * D + d] = dbacc[l];
       }
     }
+  }
+}
+
+
+// ---- generic forward (any D, L <= kDcnGenMaxL): the closed form of the recurrence (reference interactive_layer.py:275-282).  With
+// x_l = c_l x0 + sum_{t<l} b_t the layer's dot is s_l = c_l (x0 . w_l) + beta_l, beta_l = (sum_{t<l} b_t) . w_l (parameters only),
+// c_{l+1} = c_l + s_l: ONE pass over the sample's row gives the L dots p_l = x0 . w_l (a wave per sample, L accumulators), the
+// recurrence is L scalar steps, and the output is y = c_L x0 + sum_t b_t, column by column, in a second pass.  The register-resident
+// kernel keeps a whole row in one wave (D <= 4096) and all parameters in LDS (2 L D 4 B <= 160 KiB); this pair has neither limit.
+template <int LM>
+__global__ __launch_bounds__(256) void dcn_fwd_scalars_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                              float* __restrict__ s, int B, int D, int L) {
+  __shared__ float beta[LM];
+  __shared__ float red[4][LM];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  {   // beta_l, once per workgroup (the grid is small: a persistent loop over the samples below)
+    float acc[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) acc[l] = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+      float bs = 0.f;
+#pragma unroll
+      for (int l = 0; l < LM; ++l)
+        if (l < L) {
+          acc[l] = fmaf(bs, w[(long)l * D + d], acc[l]);
+          bs += b[(long)l * D + d];
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LM; ++l) {
+      const float t = wave_sum(acc[l]);
+      if (lane == 0) red[wave][l] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < LM) beta[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
+  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+    float p[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) p[l] = 0.f;
+    const float* xr = x + (long)n * D;
+    for (int d = lane; d < D; d += 64) {
+      const float xv = xr[d];
+#pragma unroll
+      for (int l = 0; l < LM; ++l)
+        if (l < L) p[l] = fmaf(w[(long)l * D + d], xv, p[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < LM; ++l) p[l] = wave_sum(p[l]);
+    if (lane == 0) {
+      float c = 1.f;
+#pragma unroll
+      for (int l = 0; l < LM; ++l)
+        if (l < L) {
+          const float sl = fmaf(c, p[l], beta[l]);
+          s[(long)n * L + l] = sl;
+          c += sl;
+        }
+    }
+  }
+}
+// y[n, d] = c_L[n] x0[n, d] + sum_t b_t[d],  c_L = 1 + sum_l s_l (in layer order, as the scalars kernel built it)
+__global__ __launch_bounds__(256) void dcn_fwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ s,
+                                                           float* __restrict__ y, int B, int D, int L, int nchunk) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_lo = blockIdx.y * nchunk, n_hi = min(B, n_lo + nchunk);
+  if (d >= D) return;
+  float bs = 0.f;
+  for (int l = 0; l < L; ++l) bs += b[(long)l * D + d];
+  for (int n = n_lo; n < n_hi; ++n) {
+    float c = 1.f;
+    for (int l = 0; l < L; ++l) c += s[(long)n * L + l];
+    y[(long)n * D + d] = fmaf(c, x[(long)n * D + d], bs);
   }
 }
 
@@ -519,16 +596,27 @@ using namespace fil;
 extern "C" int fil_dcn_fwd(const float* x, const float* w, const float* b, float* y, float* s, int B, int D, int L,
                            void* stream) {
   FIL_CHECK_ARG(B >= 0 && D >= 1 && L >= 1);
-  if (L > 6) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: L=%d > 6", L);
-  if (D > 4096) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: D=%d > 4096", D);
+  if (L > kDcnGenMaxL) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: L=%d > %d", L, kDcnGenMaxL);
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(x && w && b && y && s);
   const bool vec = (D % 4 == 0);
   const int npl = pick_npl(D, vec);
   const size_t psz = (size_t)2 * L * D * sizeof(float);
-  if (psz > kDcnLdsLimit) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_fwd: 2*L*D*4 = %zu bytes of w,b exceed the 160 KiB LDS", psz);
-  const int grid = dcn_grid_fwd(B);
   hipStream_t st = (hipStream_t)stream;
+  if (L > kDcnMaxL || D > 4096 || npl <= 0 || psz > kDcnLdsLimit) {
+    // outside the register-resident kernel's limits (a row in one wave, every parameter in LDS): the generic two-pass forward
+    ProfScope ps("dcn_fwd_generic", st, (double)B * 3.0 * D * sizeof(float));
+    const int grid = std::max(1, std::min(cdiv(B, 4), 2 * 256));
+    if (L <= kDcnMaxL) hipLaunchKernelGGL(dcn_fwd_scalars_kernel<kDcnMaxL>, dim3(grid), dim3(256), 0, st, x, w, b, s, B, D, L);
+    else hipLaunchKernelGGL(dcn_fwd_scalars_kernel<kDcnGenMaxL>, dim3(grid), dim3(256), 0, st, x, w, b, s, B, D, L);
+    FIL_CHECK_LAUNCH();
+    const int chunks = std::max(1, std::min(cdiv(B, 8), 256));
+    const int nchunk = cdiv(B, chunks);
+    hipLaunchKernelGGL(dcn_fwd_cols_kernel, dim3(cdiv(D, 256), cdiv(B, nchunk)), dim3(256), 0, st, x, b, s, y, B, D, L, nchunk);
+    FIL_CHECK_LAUNCH();
+    return FIL_OK;
+  }
+  const int grid = dcn_grid_fwd(B);
   ProfScope ps("dcn_fwd", st, (double)B * 2.0 * D * sizeof(float));
 #define FWD_VEC(N) launch_fwd<N, 4>(grid, psz, st, x, w, b, y, s, B, D, L)
 #define FWD_SCALAR(N) launch_fwd<N, 1>(grid, psz, st, x, w, b, y, s, B, D, L)
@@ -544,7 +632,7 @@ static bool dcn_register_path(int D, int L) {
   // per-lane accumulators are 2*L*NPL registers (+5*NPL of sample state): stay inside the 512-register file
   // closed-form backward: (L + 1) row accumulators + x0, g and their prefetched successors + a parameter row in flight,
   // two waves per SIMD (256 registers per lane)
-  return npl > 0 && (L + 7) * npl <= 230 && std::max((size_t)L * D, (size_t)kDcnBwdWaves * (D + 8)) * sizeof(float) <= kDcnLdsLimit;
+  return L <= kDcnMaxL && D <= 4096 && npl > 0 && (L + 7) * npl <= 230 && std::max((size_t)L * D, (size_t)kDcnBwdWaves * (D + 8)) * sizeof(float) <= kDcnLdsLimit;
 }
 static int dcn_generic_chunks(int B) { return std::max(1, std::min(cdiv(B, 32), 64)); }
 
@@ -558,8 +646,7 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
                            float* dw, float* db, int B, int D, int L, void* workspace, size_t workspace_bytes,
                            void* stream) {
   FIL_CHECK_ARG(B >= 0 && D >= 1 && L >= 1);
-  if (L > 6) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: L=%d > 6", L);
-  if (D > 4096) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: D=%d > 4096", D);
+  if (L > kDcnGenMaxL) return fail(FIL_ERR_UNSUPPORTED, "fil_dcn_bwd: L=%d > %d", L, kDcnGenMaxL);
   FIL_CHECK_ARG(dw && db);
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
@@ -572,17 +659,19 @@ extern "C" int fil_dcn_bwd(const float* x, const float* w, const float* b, const
     return fail(FIL_ERR_WORKSPACE, "fil_dcn_bwd: workspace %zu < %zu bytes", workspace_bytes,
                 fil_dcn_bwd_workspace_bytes(B, D, L));
   if (!dcn_register_path(D, L)) {
-    // generic two-pass backward (any D, L <= 6): scalars per sample, then column-wise accumulation
+    // generic two-pass backward (any D, L <= 16): scalars per sample, then column-wise accumulation
     Carver wsc(workspace);
     float* dsbuf = wsc.take<float>((size_t)B * L);
     float* partial = wsc.take<float>((size_t)dcn_generic_chunks(B) * 2 * L * D);
     ProfScope ps("dcn_bwd_generic", st, (double)B * 5.0 * D * sizeof(float));
-    hipLaunchKernelGGL(dcn_bwd_scalars_kernel, dim3(std::min(cdiv(B, 4), 2048)), dim3(256), 0, st, x, w, g, dsbuf, B, D, L);
+    if (L <= kDcnMaxL) hipLaunchKernelGGL(dcn_bwd_scalars_kernel<kDcnMaxL>, dim3(std::min(cdiv(B, 4), 2048)), dim3(256), 0, st, x, w, g, dsbuf, B, D, L);
+    else hipLaunchKernelGGL(dcn_bwd_scalars_kernel<kDcnGenMaxL>, dim3(std::min(cdiv(B, 4), 2048)), dim3(256), 0, st, x, w, g, dsbuf, B, D, L);
     FIL_CHECK_LAUNCH();
     const int chunks = dcn_generic_chunks(B);
     const int nchunk = cdiv(B, chunks);
     const dim3 grid(cdiv(D, 256), cdiv(B, nchunk));
-    hipLaunchKernelGGL(dcn_bwd_cols_kernel, grid, dim3(256), 0, st, x, w, b, s, dsbuf, g, dx, partial, B, D, L, nchunk);
+    if (L <= kDcnMaxL) hipLaunchKernelGGL(dcn_bwd_cols_kernel<kDcnMaxL>, grid, dim3(256), 0, st, x, w, b, s, dsbuf, g, dx, partial, B, D, L, nchunk);
+    else hipLaunchKernelGGL(dcn_bwd_cols_kernel<kDcnGenMaxL>, grid, dim3(256), 0, st, x, w, b, s, dsbuf, g, dx, partial, B, D, L, nchunk);
     FIL_CHECK_LAUNCH();
     hipLaunchKernelGGL(dcn_reduce_kernel, dim3(cdiv(2 * L * D, 64)), dim3(256), 0, st, partial, dw, db, (int)grid.y, L * D);
     FIL_CHECK_LAUNCH();

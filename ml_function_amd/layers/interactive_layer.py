@@ -221,12 +221,10 @@ class CrossLayer(Layer):
         return Fn.dcn_cross(inputs, w, b).unsqueeze(-1)
 
     def fits_kernel_menu(self, x):
-        """fil_dcn_*'s limits (include/fil.h, csrc/dcn.hip): D <= 4096 (a sample's row lives in one wave's registers),
-        cross_hidden <= 6, and the forward stages every layer's w and b in LDS: 2 * L * D * 4 bytes <= 160 KiB (L = 6: D <= 3413;
-        the backward's own LDS need, max(L * D, 8 * (D + 8)) * 4 bytes, is smaller).  The reference has none (:255-282): a layer
-        outside them takes the composed path below instead of raising."""
-        d, L = x.shape[-1], self.cross_hidden
-        return d <= 4096 and L <= 6 and 2 * L * d * 4 <= 160 * 1024
+        """fil_dcn_*'s limit (include/fil.h, csrc/dcn.hip): cross_hidden <= 16, any D (D <= 4096 with cross_hidden <= 6 and the
+        parameters within the LDS run the register-resident kernels, anything else the generic two-pass ones).  The reference has no
+        limit (:255-282): a deeper layer takes the composed path below instead of raising."""
+        return self.cross_hidden <= 16
 
     def _composed(self, x, w, b):
         """The reference's recurrence (:275-282) on the GPU with plain torch ops (autograd for the backward), layer by layer:

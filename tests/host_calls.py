@@ -39,8 +39,11 @@ def run(lib):
     expect(lib.fil_fm_bwd(None, None, None, None, 4, 3, 2, 0, None), -1)
     expect(lib.fil_fm_pairs_fwd(None, None, 4, 1, 2, None), -1)
     expect(lib.fil_fm_pairs_bwd(None, None, None, 0, 3, 2, None), 0)
-    expect(lib.fil_dcn_fwd(None, None, None, None, None, 4, 5000, 3, None), -4, b"4096")
-    expect(lib.fil_dcn_fwd(None, None, None, None, None, 4, 100, 7, None), -4)
+    expect(lib.fil_dcn_fwd(None, None, None, None, None, 4, 5000, 3, None), -1)        # D > 4096: the generic kernels take it (argument check next)
+    expect(lib.fil_dcn_fwd(None, None, None, None, None, 4, 100, 7, None), -1)
+    expect(lib.fil_dcn_fwd(None, None, None, None, None, 4, 100, 17, None), -4, b"16")
+    expect(lib.fil_dcn_bwd(None, None, None, None, None, None, None, None, 4, 100, 17, None, 0, None), -4, b"16")
+    assert lib.fil_dcn_bwd_workspace_bytes(8, 6400, 8) > 0
     expect(lib.fil_dcn_bwd(None, None, None, None, None, None, None, None, 4, 100, 3, None, 0, None), -1)
     assert lib.fil_dcn_bwd_workspace_bytes(8192, 1248, 3) > 0 and lib.fil_dcn_bwd_workspace_bytes(0, 1248, 3) == 0
     assert lib.fil_dcn_bwd_workspace_bytes(16, 3200, 2) > 0          # generic two-pass path

@@ -258,7 +258,9 @@ def test_fm_pairs(B, F, K):
 
 
 # ------------------------------------------------------------------ DCN
-@pytest.mark.parametrize("B,D,L", [(8192, 1248, 3), (64, 1248, 3), (33, 845, 3), (5, 7, 1), (257, 512, 6), (16, 3200, 2), (9, 130, 4)])
+# (8, 6400, 8) ... (300, 5000, 16): outside the register-resident kernels (D > 4096, L > 6, or w and b beyond the LDS): the generic two-pass pair
+@pytest.mark.parametrize("B,D,L", [(8192, 1248, 3), (64, 1248, 3), (33, 845, 3), (5, 7, 1), (257, 512, 6), (16, 3200, 2), (9, 130, 4),
+                                   (8, 6400, 8), (5, 130, 7), (4, 4100, 2), (6, 4096, 6), (6, 3416, 6), (300, 5000, 16), (1, 9000, 1)])
 @pytest.mark.parametrize("dist", ["uniform", "normal"])
 def test_dcn(B, D, L, dist):
     from ml_function_amd import functional as Fn
@@ -1210,10 +1212,11 @@ def test_cin_layer_outside_the_kernel_menu_takes_the_composed_path(B, F, K, conv
         lay(torch.tensor(c["x"]))     # a CPU tensor: no CPU path
 
 
-@pytest.mark.parametrize("B,D,L", [(8, 6400, 8), (5, 130, 7), (4, 4100, 2), (6, 4096, 6), (6, 3416, 6)])
+@pytest.mark.parametrize("B,D,L", [(5, 130, 17), (3, 4100, 20)])
 def test_cross_layer_outside_the_kernel_menu_takes_the_composed_path(B, D, L):
-    """D > 4096 or cross_hidden > 6: the reference has no such limits (interactive_layer.py:255-282).  The HIP entry point refuses the
-    shape (FIL_ERR_UNSUPPORTED), the CrossLayer does not: it runs the reference's recurrence with torch ops on the GPU."""
+    """cross_hidden > 16: the reference has no such limit (interactive_layer.py:255-282).  The HIP entry point refuses the shape
+    (FIL_ERR_UNSUPPORTED), the CrossLayer does not: it runs the reference's recurrence with torch ops on the GPU.  (Round 6: D > 4096,
+    6 < L <= 16 and parameter sets beyond the LDS are kernel shapes now -- test_dcn.)"""
     from ml_function_amd import functional as Fn
     from ml_function_amd._lib import FilError
     from ml_function_amd.layers import CrossLayer

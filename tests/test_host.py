@@ -37,8 +37,8 @@ def test_argument_validation_without_gpu(lib):
     assert b"bad argument" in lib.fil_last_error()
     assert lib.fil_fm_fwd(None, None, None, 0, 3, 2, 0, None) == 0  # empty batch is a no-op
     assert lib.fil_fm_fwd(None, None, None, 4, 3, 2, 7, None) == -1  # unknown dtype
-    assert lib.fil_dcn_fwd(None, None, None, None, None, 4, 5000, 3, None) == -4  # D limit
-    assert b"4096" in lib.fil_last_error()
+    assert lib.fil_dcn_fwd(None, None, None, None, None, 4, 5000, 17, None) == -4  # L limit (any D runs since round 6)
+    assert b"16" in lib.fil_last_error()
     H = _lib.int_array([128, 128, 128])
     assert lib.fil_cin_fwd(None, None, None, None, None, None, None, None, 4, 39, 16, 9, H, 1, 0, None, 0, None) == -4
     Hbig = _lib.int_array([300])
