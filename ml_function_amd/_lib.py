@@ -6,8 +6,23 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIL_LIB_PATH (development only): an alternative build of the SAME library -- kernel experiments built side by side by
-# tools/abl_build.py and timed against the default one in separate processes.  Unset = the in-tree default.
-LIB_PATH = os.environ.get("FIL_LIB_PATH") or os.path.join(_HERE, "libfil_hip.so")
+# tools/abl_build.py (-> tools/abl/libfil_<name>.so) and timed against the default one in separate processes.  Honoured only for a
+# file inside this repository's tools/abl/ directory: the variable cannot point the product at a library from anywhere else.
+# Unset (or anything else) = the in-tree default.
+def _lib_path():
+    default = os.path.join(_HERE, "libfil_hip.so")
+    alt = os.environ.get("FIL_LIB_PATH")
+    if not alt:
+        return default
+    abl = os.path.realpath(os.path.join(_HERE, "..", "tools", "abl")) + os.sep
+    if os.path.realpath(alt).startswith(abl):
+        return alt
+    import warnings
+    warnings.warn("FIL_LIB_PATH=%s is outside %s: ignored, loading the in-tree libfil_hip.so" % (alt, abl))
+    return default
+
+
+LIB_PATH = _lib_path()
 HEADER_PATH = os.path.join(_HERE, "..", "include", "fil.h")
 
 FIL_F32, FIL_BF16 = 0, 1
