@@ -276,6 +276,17 @@ int fil_bce_mean_fwd(const float* p, const float* y, float eps, float* loss, flo
  *   bwd: dz = out (dout - <dout, out>); dparts[i] [B, widths[i]] = dz W_i^T (entries / the array may be NULL: not wanted);
  *        dW [D, O] = concat(parts)^T dz, db [O] = column sums of dz -- block partials summed in block order by a second, tiny launch:
  *        deterministic.  workspace: fil_merge_softmax_bwd_workspace_bytes(B, D, O) bytes. */
+/* The dense layers of the zoo's MLPs (DnnLayer / HiddenLayer / Dense, core_layer/core_layer.py:102-118,201-226) at batch-sized M and a
+ * few hundred columns: C [M][N] = op(A) [M][K] . op(B) [K][N] (+ bias[n] (epilogue 1), then ReLU (2)), fp32, exact
+ * v_mfma_f32_32x32x2_f32 chains, deterministic (a small output with a long reduction -- dW = x^T dz -- is split over k and the slices
+ * are summed in order by a second launch: that is what the workspace is for; a call with an epilogue is never split).
+ *   trans_a = 0: A is [M][K] row-major, leading dimension lda >= K;  1: A is [K][M], lda >= M   (dW = x^T dz: A = x, trans_a = 1)
+ *   trans_b = 0: B is [K][N] row-major, ldb >= N;                    1: B is [N][K], ldb >= K   (dx = dz W^T: B = W [in][out], trans_b = 1)
+ * Any M, N, K; 16-byte operand loads where base and leading dimension allow, element-wise otherwise. */
+size_t fil_gemm_f32_workspace_bytes(int M, int N, int K);
+int fil_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                 int trans_b, int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward half of Dense + bias + ReLU (the zoo's MLP layers, DnnLayer core_layer/core_layer.py:102-118,201-226; the layer's GEMMs stay
  * library GEMMs): dz[b,n] = y[b,n] > 0 ? dy[b,n] : 0 (y = the layer's OUTPUT) and dbias[n] = sum_b dz[b,n] in ONE pass over [B, N]
  * (torch: threshold_backward, then a column reduce).  y, dy, dz in `dtype` storage (FIL_F32 / FIL_BF16), dbias fp32; deterministic (block

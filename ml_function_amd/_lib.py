@@ -68,6 +68,8 @@ SIGNATURES = {
     "fil_score_add_sigmoid_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "fil_score_add_sigmoid_bwd": (_I, [_P, _P, _P, _I, _P]),
     "fil_bce_mean_fwd": (_I, [_P, _P, _F, _P, _P, _I, _P]),
+    "fil_gemm_f32_workspace_bytes": (_Z, [_I, _I, _I]),
+    "fil_gemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "fil_relu_bias_bwd_workspace_bytes": (_Z, [_I, _I]),
     "fil_relu_bias_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "fil_merge_softmax_bwd_workspace_bytes": (_Z, [_I, _I, _I]),

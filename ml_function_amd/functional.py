@@ -525,6 +525,26 @@ def score_add_sigmoid(parts):
     return _ScoreAddSigmoidFn.apply(*parts)
 
 
+def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, relu=False):
+    """op(a) @ op(b) (+ bias, ReLU) in fp32 through the library's own MFMA GEMM (fil_gemm_f32, csrc/gemm.hip): a, b contiguous 2-D CUDA
+    fp32 tensors; trans_a: a is [K, M]; trans_b: b is [N, K].  No autograd (the dense layers' Functions call it in both directions)."""
+    _require_cuda(a, b)
+    a, b = _f32c(a), _f32c(b)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != K:
+        raise FilError("gemm_f32: %s x %s (trans_a=%s, trans_b=%s)" % (tuple(a.shape), tuple(b.shape), trans_a, trans_b))
+    lib = _lib.load()
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    nws = lib.fil_gemm_f32_workspace_bytes(M, N, K)
+    ws = _scratch(nws, a.device, "gemm_f32") if nws else None
+    epi = 0 if bias is None else (2 if relu else 1)
+    check(lib.fil_gemm_f32(ptr(a), ptr(b), ptr(c), ptr(_f32c(bias)) if bias is not None else None, M, N, K, a.shape[1], b.shape[1], N,
+                           int(bool(trans_a)), int(bool(trans_b)), epi, ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
+                           stream_ptr()), "fil_gemm_f32")
+    return c
+
+
 class _DenseReluFn(torch.autograd.Function):
     """y = relu(x @ kernel + bias) -- a hidden layer of the zoo's MLPs (DnnLayer, core_layer.py:102-118,201-226) -- as a library GEMM
     with the bias + ReLU in its epilogue forward, and backward as ONE HIP pass (ReLU mask + bias gradient, fil_relu_bias_bwd) plus the
@@ -539,7 +559,10 @@ class _DenseReluFn(torch.autograd.Function):
             raise FilError("dense_relu: autocast dtype %s (float32 or bfloat16)" % cd)
         with torch.autocast("cuda", enabled=False):
             xc, wc = x.to(cd).contiguous(), kernel.to(cd)
-            y = torch._addmm_activation(bias.to(cd), xc, wc, use_gelu=False)
+            if cd == torch.float32:      # the library's own fp32 MFMA GEMM, bias + ReLU in its epilogue (csrc/gemm.hip)
+                y = gemm_f32(xc, wc, bias=bias, relu=True)
+            else:                        # bf16 autocast: the framework's GEMM with the same epilogue
+                y = torch._addmm_activation(bias.to(cd), xc, wc, use_gelu=False)
         ctx.save_for_backward(xc, wc, y)
         ctx.cfg = (x.dtype, kernel.dtype, bias.dtype)
         return y
@@ -557,8 +580,12 @@ class _DenseReluFn(torch.autograd.Function):
         check(lib.fil_relu_bias_bwd(ptr(y), ptr(dy), ptr(dz), ptr(db), B, N, FIL_F32 if y.dtype == torch.float32 else FIL_BF16, ptr(ws),
                                     ws.numel(), stream_ptr()), "fil_relu_bias_bwd")
         with torch.autocast("cuda", enabled=False):
-            dx = torch.matmul(dz, wc.t()).to(xdt) if ctx.needs_input_grad[0] else None
-            dw = torch.matmul(xc.t(), dz).to(wdt) if ctx.needs_input_grad[1] else None
+            if y.dtype == torch.float32:
+                dx = gemm_f32(dz, wc, trans_b=True).to(xdt) if ctx.needs_input_grad[0] else None      # dz W^T
+                dw = gemm_f32(xc, dz, trans_a=True).to(wdt) if ctx.needs_input_grad[1] else None      # x^T dz (split over the batch)
+            else:
+                dx = torch.matmul(dz, wc.t()).to(xdt) if ctx.needs_input_grad[0] else None
+                dw = torch.matmul(xc.t(), dz).to(wdt) if ctx.needs_input_grad[1] else None
         return dx, dw, db.to(bdt)
 
 

@@ -83,6 +83,10 @@ def run(lib):
     expect(lib.fil_score_add_sigmoid_bwd(None, None, None, 4, None), -1)
     expect(lib.fil_bce_mean_fwd(None, None, 1e-7, None, None, 0, None), -1)
     expect(lib.fil_bce_mean_fwd(None, None, 0.7, None, None, 8, None), -1, b"eps")
+    expect(lib.fil_gemm_f32(None, None, None, None, 4, 8, 16, 16, 8, 8, 0, 0, 0, None, 0, None), -1)           # NULL operands
+    expect(lib.fil_gemm_f32(None, None, None, None, 0, 8, 16, 16, 8, 8, 0, 0, 0, None, 0, None), 0)            # empty
+    expect(lib.fil_gemm_f32(None, None, None, None, 4, 8, 16, 16, 8, 8, 0, 0, 3, None, 0, None), -1)           # unknown epilogue
+    assert lib.fil_gemm_f32_workspace_bytes(4096, 256, 637) == 0 and lib.fil_gemm_f32_workspace_bytes(4096, 128, 256) == 0 and lib.fil_gemm_f32_workspace_bytes(637, 256, 4096) > 0 and lib.fil_gemm_f32_workspace_bytes(637, 256, 4096) % (637 * 256 * 4) == 0
     expect(lib.fil_relu_bias_bwd(None, None, None, None, 4, 8, 0, None, 0, None), -1)
     expect(lib.fil_relu_bias_bwd(None, None, None, None, 4, 8, 5, None, 0, None), -1)
     assert lib.fil_relu_bias_bwd_workspace_bytes(4096, 256) == 256 + 64 * 256 * 4

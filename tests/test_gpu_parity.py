@@ -1550,3 +1550,28 @@ def test_dnn_layer_takes_the_fused_hidden_layers_and_agrees_with_the_composed_pa
     assert lay._dense_relu(0, lay.hidden_list[0], x) is not None and lay._dense_relu(1, lay.hidden_list[1], first.new_zeros(77, 32)) is None
     again = lay(x)
     assert tuple(again.shape) == (77, 8) and float((again - first).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi", [(4096, 256, 637, 0, 0, 2), (4096, 637, 256, 0, 1, 0), (637, 256, 4096, 1, 0, 0), (4096, 128, 256, 0, 0, 2),
+                                             (256, 128, 4096, 1, 0, 0), (4096, 64, 128, 0, 0, 1), (1, 1, 1, 0, 0, 0), (65, 33, 17, 1, 1, 1),
+                                             (130, 70, 1000, 0, 1, 0), (7, 300, 5, 1, 0, 2), (64, 64, 16, 0, 0, 0), (200, 9, 2048, 1, 0, 0),
+                                             (1024, 256, 637, 0, 0, 2)])
+def test_gemm_f32_matches_float64(M, N, K, ta, tb, epi):
+    """fil_gemm_f32 (csrc/gemm.hip: the dense layers' GEMMs -- y = x W + b with ReLU, dx = dz W^T, dW = x^T dz, at the xDeepFM MLP's shapes
+    and at ragged ones) against the same product in float64: 1e-5 norm-relative (exact fp32 MFMA chains; split-K shapes sum their slices in
+    order), bit-identical on a repeat."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(M + 7 * N + 13 * K)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if epi else None
+    c = Fn.gemm_f32(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb), bias=dev(bias) if epi else None, relu=epi == 2)
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    if epi:
+        want = want + bias
+    if epi == 2:
+        want = np.maximum(want, 0.0)
+    assert tuple(c.shape) == (M, N)
+    check("gemm_f32", c, want, tol=1e-5)
+    c2 = Fn.gemm_f32(dev(a), dev(b), trans_a=bool(ta), trans_b=bool(tb), bias=dev(bias) if epi else None, relu=epi == 2)
+    assert torch.equal(c, c2)
