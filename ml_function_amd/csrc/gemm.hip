@@ -81,7 +81,14 @@ __global__ __launch_bounds__(4 * BN) void gemm_f32_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * kGemmLd];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin, each XCD has its own L2 -- workgroup id of XCD id % 8 takes
+  // tile (id % 8) (ntiles / 8) + id / 8 of the row-block-major list, so the column tiles of one block of A's rows (and their
+  // neighbours) run on ONE XCD and that block comes out of HBM / the Infinity Cache once instead of once per column tile
+  const int ntx = (N + BN - 1) / BN, nty = (M + kGemmBM - 1) / kGemmBM, ntile = ntx * nty;
+  const int per = (ntile + 7) >> 3;
+  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile >= ntile) return;   // (whole workgroup, before any barrier)
+  const int m0 = (tile / ntx) * kGemmBM, n0 = (tile % ntx) * BN;
   const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
   const int wm = (BN == 64 ? (wave >> 1) : wave) * 32, wn = BN == 64 ? (wave & 1) * 32 : 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)std::min<long>((TA ? (long)K * lda : (long)M * lda) * 4, 0x7fffffffL), 0x00020000);
@@ -193,7 +200,7 @@ extern "C" int fil_gemm_f32(const float* A, const float* B, float* C, const floa
   }
   const int kchunk = ns > 1 ? cdiv(cdiv(K, ns), kGemmBK) * kGemmBK : std::max(K, 1);
   const int bn = gemm_bn(M, N);
-  const dim3 grid(cdiv(N, bn), cdiv(M, kGemmBM), ns);
+  const dim3 grid(cdiv(cdiv(N, bn) * cdiv(M, kGemmBM), 8) * 8, 1, ns);   // (tiles in XCD-aware order: a multiple of 8 workgroups)
   ProfScope ps("gemm_f32", st, 2.0 * M * N * K);
 #define FIL_GEMM(TAV, TBV)                                                                                                                        \
   do {                                                                                                                                            \
