@@ -871,13 +871,12 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     ready(0);
     {
       ProfScope ps("cin_tail_params", st);
-      const size_t ldf = (((size_t)F + 3) & ~(size_t)3) + 4;
-      const size_t sh = std::max((F * ldf + std::max((size_t)Hq * ldf, (size_t)F * (Hq + 1))) * sizeof(float), (size_t)256 * sizeof(float));
+      const size_t sh = cin_qtail_params_lds(F, Hq);
       allow_lds(cin_qtail_params_kernel, sh);
       float* dcfin = qt_dcpart + (size_t)qt_ndc * kQtConst;
       hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq, qt_dcpart, qt_ndc,
                          dcfin);
-      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, dcfin, bias[p], qtWsumL, dW[lL], dbias[p], dbias[lL], F, Hq,
+      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, kQtFillCols)), dim3(kQtFillThreads), 0, st, part, Hpp, dcfin, bias[p], qtWsumL, dW[lL], dbias[p], dbias[lL], F, Hq,
                          tg.HL);
     }
     FIL_CHECK_LAUNCH();
@@ -969,14 +968,12 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
     FIL_CHECK_LAUNCH();
     {
       ProfScope ps("cin_tail_params", st);
-      const size_t ldf = (((size_t)F + 3) & ~(size_t)3) + 4;
-      // (at least the 4 x 64 floats the extra workgroup folds the dc partials through: small F with a narrow layer needs less for the products)
-      const size_t sh = std::max((F * ldf + std::max((size_t)Hq * ldf, (size_t)F * (Hq + 1))) * sizeof(float), (size_t)256 * sizeof(float));
+      const size_t sh = cin_qtail_params_lds(F, Hq);   // (at least the 4 x 64 floats the extra workgroup folds the dc partials through)
       allow_lds(cin_qtail_params_kernel, sh);
       float* dcfin = qt_dcpart + (size_t)qt_ndc * kQtConst;
       hipLaunchKernelGGL(cin_qtail_params_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[p], qtWsumL, qt_dT, vlast, dW[p], part, Hpp, F, Hq, qt_dcpart, qt_ndc,
                          dcfin);
-      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, 64)), dim3(256), 0, st, part, Hpp, dcfin, bias[p], qtWsumL, dW[lL], dbias[p], dbias[lL], F, Hq,
+      hipLaunchKernelGGL(cin_qtail_fill_kernel, dim3(cdiv(Hq * F, kQtFillCols)), dim3(kQtFillThreads), 0, st, part, Hpp, dcfin, bias[p], qtWsumL, dW[lL], dbias[p], dbias[lL], F, Hq,
                          tg.HL);
     }
     FIL_CHECK_LAUNCH();

@@ -361,13 +361,15 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
     return;
   }
   const int h = blockIdx.x >> 1, phase = blockIdx.x & 1;
-  // LDS: dt [F][ldf] | phase 0: wl [Hq][ldf] -- phase 1: wp [F][Hq+1];  ldf = F rounded up to 4, + 4: 16-byte rows, zero padded
-  const int ldf = ((F + 3) & ~3) + 4, nq = (F + 3) >> 2;   // (+4: eight consecutive rows start in eight different bank quads)
+  // Both products run on the matrix pipe (v_mfma_f32_32x32x2_f32, one 32-row strip of outputs per wave and visit): as scalar dot
+  // products out of LDS they were 2 F floats read per F FMAs -- 12 us of LDS reads per workgroup.  LDS (zero padded to whole tiles):
+  //   dt [FT][ldd]: dT[(f',f), h] as [f'][f], FT = F rounded up to 32, ldd = FT + 1 (odd: conflict-free down a column)
+  //   phase 0: wl [HT][ldd]: wsum_L as [n][f], HT = Hq rounded up to 32      phase 1: wp [FK][HT]: W_p[(h,f'),n] as [f'][n], FK = F rounded up to 2
+  const int FT = (F + 31) & ~31, HT = (Hq + 31) & ~31, FK = (F + 1) & ~1, ldd = FT + 1;
   float* dt = smem;
-  float* op = dt + F * ldf;
-  for (int i = threadIdx.x; i < F * ldf; i += 256) dt[i] = 0.f;
-  if (phase == 0)
-    for (int i = threadIdx.x; i < Hq * ldf; i += 256) op[i] = 0.f;
+  float* op = dt + FT * ldd;
+  const int nop = phase == 0 ? HT * ldd : FK * HT;
+  for (int i = threadIdx.x; i < FT * ldd + nop; i += 256) smem[i] = 0.f;
   __syncthreads();
   for (int i0 = threadIdx.x; i0 < F * F; i0 += 8 * 256) {   // (a column of dT: one dword per 512-byte row, all in flight together)
     float v[8];
@@ -378,100 +380,118 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
       const int i = i0 + u * 256;
       if (i < F * F) {
         const int fp = i / F;
-        dt[fp * ldf + (i - fp * F)] = v[u];
+        dt[fp * ldd + (i - fp * F)] = v[u];
       }
     }
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
+  const bool two = F > 32;   // a second strip of 32 f' (phase 0) / f (phase 1)
   if (phase == 0) {
-    qt_stage_rows(wsumL, op, Hq, F, ldf);
+    qt_stage_rows(wsumL, op, Hq, F, ldd);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < F * Hq; idx += 256) {
-      const int fp = idx / Hq, n = idx - fp * Hq;
-      const float4* d = reinterpret_cast<const float4*>(dt + fp * ldf);
-      const float4* w = reinterpret_cast<const float4*>(op + n * ldf);
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-      for (int q = 0; q < nq; ++q) {
-        const float4 dv = d[q], wv = w[q];
-        t0 = fmaf(dv.x, wv.x, t0);
-        t1 = fmaf(dv.y, wv.y, t1);
-        t2 = fmaf(dv.z, wv.z, t2);
-        t3 = fmaf(dv.w, wv.w, t3);
+    // out[f'][n] = sum_f dt[f'][f] wl[n][f]: A = dt (row f' on the lane), B = wl (column n on the lane); a wave takes 32 columns n
+    for (int nt = wave; nt < (HT >> 5); nt += 4) {
+      f32x16 a0, a1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a0[i] = a1[i] = 0.f;
+      const float* ar = dt + r * ldd + half;
+      const float* br = op + (nt * 32 + r) * ldd + half;
+      for (int k = 0; k < FK; k += 2) {
+        const float b = br[k];
+        a0 = mfma32(ar[k], b, a0);
+        if (two) a1 = mfma32(ar[32 * ldd + k], b, a1);
       }
-      dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + ((t0 + t1) + (t2 + t3));
+      const int n = nt * 32 + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int fp = mfma32_row(reg, half);
+        if (n < Hq && fp < F) dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + a0[reg];
+        if (two && n < Hq && fp + 32 < F) dWp[((long)h * F + fp + 32) * Hq + n] = vT[(long)(fp + 32) * Hpp + h] + a1[reg];
+      }
     }
   } else {
-    qt_stage_rows(Wp + (long)h * F * Hq, op, F, Hq, Hq + 1);
+    qt_stage_rows(Wp + (long)h * F * Hq, op, F, Hq, HT);
     __syncthreads();
+    // out[n][f] = sum_f' wp[f'][n] dt[f'][f]: A = wp (row n on the lane), B = dt (column f on the lane); a wave takes 32 rows n
     float* pl = partL + (long)h * Hq * F;
-    // thread (n, quad of f): four outputs from one scalar of W_p and one 16-byte read of dT per f'
-    for (int idx = threadIdx.x; idx < Hq * nq; idx += 256) {
-      const int n = idx / nq, f0 = 4 * (idx - n * nq);
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-      for (int fp = 0; fp < F; ++fp) {
-        const float wv = op[fp * (Hq + 1) + n];
-        const float4 dv = *reinterpret_cast<const float4*>(dt + fp * ldf + f0);
-        t0 = fmaf(wv, dv.x, t0);
-        t1 = fmaf(wv, dv.y, t1);
-        t2 = fmaf(wv, dv.z, t2);
-        t3 = fmaf(wv, dv.w, t3);
+    for (int mt = wave; mt < (HT >> 5); mt += 4) {
+      f32x16 a0, a1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a0[i] = a1[i] = 0.f;
+      const float* ar = op + half * HT + mt * 32 + r;
+      const float* br = dt + half * ldd + r;
+      for (int k = 0; k < FK; k += 2) {
+        const float a = ar[k * HT];
+        a0 = mfma32(a, br[k * ldd], a0);
+        if (two) a1 = mfma32(a, br[k * ldd + 32], a1);
       }
-      float* o = pl + n * F + f0;
-      o[0] = t0;
-      if (f0 + 1 < F) o[1] = t1;
-      if (f0 + 2 < F) o[2] = t2;
-      if (f0 + 3 < F) o[3] = t3;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = mt * 32 + mfma32_row(reg, half);
+        if (n < Hq && r < F) pl[n * F + r] = a0[reg];
+        if (two && n < Hq && r + 32 < F) pl[n * F + r + 32] = a1[reg];
+      }
     }
   }
 }
 
-// dwsum_L[(n,f)] = sum_h partL[h][(n,f)] + bias_p[n] dc[f]  ->  dW_L[(n,f), n'] for every n' (64 rows (n,f) per workgroup);
+// LDS bytes of cin_qtail_params_kernel
+inline size_t cin_qtail_params_lds(int F, int Hq) {
+  const size_t FT = ((size_t)F + 31) & ~(size_t)31, HT = ((size_t)Hq + 31) & ~(size_t)31, FK = ((size_t)F + 1) & ~(size_t)1, ldd = FT + 1;
+  const size_t fl = FT * ldd + (HT * ldd > FK * HT ? HT * ldd : FK * HT);
+  return (fl > 256 ? fl : 256) * sizeof(float);
+}
+
+// dwsum_L[(n,f)] = sum_h partL[h][(n,f)] + bias_p[n] dc[f]  ->  dW_L[(n,f), n'] for every n' (32 rows (n,f) per workgroup of 512
+// threads: half a wave per group of every 16th h, all of a lane's loads in flight together, the 16 groups summed in order);
 // workgroup 0 also finishes dbias_p[n] = sum_m dP_p[m] + sum_f wsum_L[(n,f)] dc[f] and dbias_L[n'] = sum_m dP_L[m].
 // dcfin[f] = dc[f], dcfin[F] = sum_m dP_L[m], dcfin[F+1] = sum_m dP_p[m] (summed by the extra workgroup of cin_qtail_params_kernel).
-static __global__ __launch_bounds__(256) void cin_qtail_fill_kernel(const float* __restrict__ partL, int Hpp, const float* __restrict__ dcfin,
-                                                                    const float* __restrict__ bias_p, const float* __restrict__ wsumL,
-                                                                    float* __restrict__ dWL, float* __restrict__ dbias_p, float* __restrict__ dbias_L,
-                                                                    int F, int Hq, int HL) {
+constexpr int kQtFillCols = 32, kQtFillThreads = 512;
+static __global__ __launch_bounds__(kQtFillThreads) void cin_qtail_fill_kernel(const float* __restrict__ partL, int Hpp, const float* __restrict__ dcfin,
+                                                                               const float* __restrict__ bias_p, const float* __restrict__ wsumL,
+                                                                               float* __restrict__ dWL, float* __restrict__ dbias_p,
+                                                                               float* __restrict__ dbias_L, int F, int Hq, int HL) {
   __shared__ float dc[kQtConst];
-  __shared__ float red[4][64];
-  __shared__ float val[64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave == 0) dc[lane] = lane < F + 2 ? dcfin[lane] : 0.f;
-  __syncthreads();
+  __shared__ float red[16][kQtFillCols];
+  __shared__ float val[kQtFillCols];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 16 groups of h
+  if (threadIdx.x < kQtConst) dc[threadIdx.x] = (int)threadIdx.x < F + 2 ? dcfin[threadIdx.x] : 0.f;
   const int C = Hq * F;
-  const int c = blockIdx.x * 64 + lane;
+  const int c = blockIdx.x * kQtFillCols + col;
   float t = 0.f;
   if (c < C) {
-    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
-    int h = wave;
-    for (; h + 12 < Hpp; h += 16) {
-      u0 += partL[(long)h * C + c];
-      u1 += partL[(long)(h + 4) * C + c];
-      u2 += partL[(long)(h + 8) * C + c];
-      u3 += partL[(long)(h + 12) * C + c];
+    int h = grp;
+    for (; h + 112 < Hpp; h += 128) {
+      float u[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = partL[(long)(h + 16 * e) * C + c];
+      t += ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
     }
-    for (; h < Hpp; h += 4) u0 += partL[(long)h * C + c];
-    t = (u0 + u1) + (u2 + u3);
+    for (; h < Hpp; h += 16) t += partL[(long)h * C + c];
   }
-  red[wave][lane] = t;
+  red[grp][col] = t;
   __syncthreads();
-  if (wave == 0 && c < C) {
+  if (grp == 0 && c < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) a += red[g][col];
     const int n = c / F, f = c - n * F;
-    val[lane] = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + bias_p[n] * dc[f];
+    val[col] = a + bias_p[n] * dc[f];
   }
   __syncthreads();
-  // the 64 rows of this workgroup x HL columns, coalesced over the columns
-  for (int i = threadIdx.x; i < 64 * HL; i += 256) {
-    const int rr = i / HL, col = i - rr * HL;
-    const int cr = blockIdx.x * 64 + rr;
-    if (cr < C) dWL[(long)cr * HL + col] = val[rr];
+  // the 32 rows of this workgroup x HL columns, coalesced over the columns
+  for (int i = threadIdx.x; i < kQtFillCols * HL; i += kQtFillThreads) {
+    const int rr = i / HL, cc = i - rr * HL;
+    const int cr = blockIdx.x * kQtFillCols + rr;
+    if (cr < C) dWL[(long)cr * HL + cc] = val[rr];
   }
   if (blockIdx.x == 0) {
-    for (int n = threadIdx.x; n < Hq; n += 256) {
+    for (int n = threadIdx.x; n < Hq; n += kQtFillThreads) {
       float u = dc[F + 1];
       for (int f = 0; f < F; ++f) u = fmaf(wsumL[n * F + f], dc[f], u);
       dbias_p[n] = u;
     }
-    for (int n = threadIdx.x; n < HL; n += 256) dbias_L[n] = dc[F];
+    for (int n = threadIdx.x; n < HL; n += kQtFillThreads) dbias_L[n] = dc[F];
   }
 }
 
