@@ -517,10 +517,16 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       {
         ProfScope ps("cin_tail_prep", st);
         // T / cvec (weights only) and, beside them, the x -> xT / wrapped-row transposes (x only)
-        const size_t sh = std::max(std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq), (size_t)F * (K + 1)) * sizeof(float);
+        // (x as given and K a power of two <= 64: the transposes go by 64-row blocks of whole samples, cin_transpose_block_body)
+        int ks = -1;
+        if (!xt_in && K <= 64 && (K & (K - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+          for (ks = 0; (1 << ks) < K;) ++ks;
+        const size_t sh_x = ks >= 0 ? (size_t)(64 >> ks) * F * (K + 1) : (size_t)F * (K + 1);
+        const size_t sh = std::max(std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq), sh_x) * sizeof(float);
         allow_lds(cin_qtail_t_x_kernel, sh);
-        hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(2 * Hpp + 1 + B), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
-                           2 * Hpp + 1, x, xT_own, K, x2T, XL, xt_in ? 1 : 0);
+        const int nx = ks >= 0 ? (int)((M + 63) / 64) : B;
+        hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(2 * Hpp + 1 + nx), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
+                           2 * Hpp + 1, x, xT_own, K, x2T, XL, xt_in ? 1 : 0, ks, (long)M);
         const long npack = (long)chunks * F * 2 * JTs * 128;
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
         const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);
@@ -833,7 +839,7 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
       const int np = (int)std::min<long>(((long)tiles0 * 32 * HS0 + 255) / 256, 1024);   // + W1 in the dZ kernel's slot order
       const int nq2 = qsplit ? 2 * std::min(cdiv(tiles0 * 512, 256), 256) : 0;           // + (split-bf16 mode) W1s and Ts in slot order as planes
       // (output_dim == 1: + the dense head's backward -- dP and the block partials of ddense_w | ddense_b)
-      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + np + nq2), dim3(256), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc,
+      hipLaunchKernelGGL(cin_qtail_xe_kernel, dim3(qt_ndc + np + nq2), dim3(kXeThreads), sh, st, xT, dPL, dPp, (int)LK, K, xe, qt_dcpart, (int)M, F, qt_ndc,
                          output_dim == 1 ? g : nullptr, dense_w, pooled, dP, qt_hpart, (int)LK, lL, p, W[0], Wz, H[0], JTs, HS0, tiles0, np, qtT, Hpp,
                          Wzb1, Wzb2);
     }

@@ -85,6 +85,73 @@ __device__ __forceinline__ void cin_transpose_in_body(const float* __restrict__ 
     }
   }
 }
+// The same for one 64-row block of xT / x2T per workgroup when K divides 64 (a block is 64 / K whole samples): the block's 64 F inputs,
+// its 64 F floats of xT and its 64 XL floats of x2T are each ONE contiguous range -- 16-byte accesses, every line written whole by
+// one workgroup (per sample: 4-byte accesses, and a 256-byte line of x2T assembled from four workgroups' quarter writes).
+// ks = log2 K.  LDS: [64 / K][F][K + 1].  M = B K need not be a multiple of 64 (the last block's missing samples are skipped).
+__device__ __forceinline__ void cin_transpose_block_body(const float* __restrict__ x, float* __restrict__ xT, float* __restrict__ x2T, int F, int ks,
+                                                         long blk, long M, int XL, float* smem) {
+  const int K = 1 << ks, kp = K + 1;
+  const long m0 = blk * 64;
+  const int rows = (int)min((long)64, M - m0);   // a multiple of K
+  const int n = rows * F;                        // floats of the block in x and in xT (a multiple of 4 only if rows F is: scalar tail)
+  const float* src = x + m0 * F;                 // (m0 = b0 K: sample b0 starts at x + b0 F K)
+  const int n4 = n >> 2;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = i0 + u * 256 < n4 ? reinterpret_cast<const float4*>(src)[i0 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 4 * (i0 + u * 256);
+      if (i < 4 * n4) {
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) smem[((i + c) >> ks) * kp + ((i + c) & (K - 1))] = e[c];   // x index (s F + f) K + k -> (s F + f)(K + 1) + k
+      }
+    }
+  }
+  for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) smem[(i >> ks) * kp + (i & (K - 1))] = src[i];
+  __syncthreads();
+  // xT: floats m0 F + i, i = j F + f  <-  image[(s F + f)(K + 1) + k], j = s K + k
+  float* dst = xT + m0 * F;
+  for (int i4 = threadIdx.x; i4 < n4; i4 += 256) {
+    int j = (4 * i4) / F, f = 4 * i4 - j * F;
+    float e[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      e[c] = smem[((j >> ks) * F + f) * kp + (j & (K - 1))];
+      if (++f == F) {
+        f = 0;
+        ++j;
+      }
+    }
+    reinterpret_cast<float4*>(dst)[i4] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+    const int j = i / F, f = i - j * F;
+    dst[i] = smem[((j >> ks) * F + f) * kp + (j & (K - 1))];
+  }
+  if (x2T != nullptr) {
+    // x2T: floats (blk XL + p) 64 + j  <-  x[m0 + j][p mod F]; four consecutive rows j per thread (K >= 4: one sample, consecutive k)
+    float* d2 = x2T + blk * XL * 64;
+    for (int i4 = threadIdx.x; i4 < XL * 16; i4 += 256) {
+      const int p = i4 >> 4, j0 = (i4 & 15) * 4;
+      int f = p;
+      while (f >= F) f -= F;
+      float e[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = j0 + c;
+        e[c] = j < rows ? smem[((j >> ks) * F + f) * kp + (j & (K - 1))] : 0.f;
+      }
+      if (j0 + 3 < rows) reinterpret_cast<float4*>(d2)[i4] = make_float4(e[0], e[1], e[2], e[3]);
+      else
+        for (int c = 0; c < 4; ++c)
+          if (j0 + c < rows) d2[4 * i4 + c] = e[c];
+    }
+  }
+}
 // the same from an input that is already transposed (FIL_CIN_X_TRANSPOSED): the K rows of sample b
 __device__ __forceinline__ void cin_wrap_rows_body(const float* __restrict__ xT, float* __restrict__ x2T, int F, int K, long b, int XL) {
   const float* src = xT + b * K * F;
@@ -1101,6 +1168,18 @@ __device__ __forceinline__ void cin_reduce_body(const float* __restrict__ part, 
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   if (i < n) {
     int p = wave;
+    for (; p + 60 < parts; p += 64) {   // (sixteen loads in flight per lane, summed as the loop below does: with hundreds of partials
+      float u[16];                      // four at a time was the longest dependent chain of the launches this rides in)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) u[e] = part[(long)(p + 4 * e) * ps + i];
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        t0 += u[e];
+        t1 += u[e + 1];
+        t2 += u[e + 2];
+        t3 += u[e + 3];
+      }
+    }
     for (; p + 12 < parts; p += 16) {
       t0 += part[(long)p * ps + i];
       t1 += part[(long)(p + 4) * ps + i];
@@ -1146,6 +1225,18 @@ static __global__ __launch_bounds__(256) void cin_reduce_expand_sym_kernel(const
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   if (i < n) {
     int p = wave;
+    for (; p + 60 < parts; p += 64) {   // (sixteen loads in flight per lane, summed as the loop below does: with hundreds of partials
+      float u[16];                      // four at a time was the longest dependent chain of the launches this rides in)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) u[e] = part[(long)(p + 4 * e) * ps + i];
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        t0 += u[e];
+        t1 += u[e + 1];
+        t2 += u[e + 2];
+        t3 += u[e + 3];
+      }
+    }
     for (; p + 12 < parts; p += 16) {
       t0 += part[(long)p * ps + i];
       t1 += part[(long)(p + 4) * ps + i];

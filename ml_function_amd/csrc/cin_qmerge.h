@@ -261,8 +261,9 @@ static __global__ __launch_bounds__(256) void cin_reduce_expand_q_kernel(const f
 // xe[m][XE = F+3] = x[m,0..F-1] | 1 | dP_L[m] | dP_p[m]  (operand rows of cin_dwq_kernel), and per block of 256 rows the column sums
 // dcpart[blk][f] = sum_m dP_L[m] x[m,f] (-> dc[f] = d pool_L / d c[f]), dcpart[blk][F] = sum_m dP_L[m], dcpart[blk][F+1] = sum_m dP_p[m]
 // (cf. cin_qtail_scale_kernel).  Further workgroups: [nscale, +nhead) the dense head's partial sums -> ddense_w | ddense_b; the
-// rest: the first layer's pair weights in the dZ kernel's slot order.   LDS: [256][F+3]
-static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
+// rest: the first layer's pair weights in the dZ kernel's slot order.   LDS: [256][F + 3 + L].  kXeThreads threads.
+constexpr int kXeThreads = 1024;
+static __global__ __launch_bounds__(kXeThreads) void cin_qtail_xe_kernel(const float* __restrict__ xT, const float* __restrict__ dPL,
                                                                   const float* __restrict__ dPp, int ldp, int K, float* __restrict__ xe,
                                                                   float* __restrict__ dcpart, int M, int F, int nscale,
                                                                   const float* __restrict__ g, const float* __restrict__ dense_w,
@@ -273,6 +274,7 @@ static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* _
                                                                   u32x4* __restrict__ Wzb2 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x >= nscale) {   // the first layer's weights in the dZ kernel's slot order (nothing else uses that buffer here)
+    if (threadIdx.x >= 256) return;   // (the pack bodies are written for 256 threads)
     if (npz < 0) npz = gridDim.x - nscale;
     const int b = blockIdx.x - nscale;
     if (b < npz) cin_pack_wz_sym_body(W0, Wz, F, H0, JTs, HS0, tiles0, b, npz);
@@ -283,73 +285,128 @@ static __global__ __launch_bounds__(256) void cin_qtail_xe_kernel(const float* _
     }
     return;
   }
-  // row image: F products | dP_L | dP_p | (head) g * pooled of the row's column in each of the L = LK/K layers | g on the sample's first row
+  // LDS: xs [256 F] (the block's rows of xT as they lie in memory) | dls [256] | dps [256] | hd [256][nl + 1] (head: g * pooled of the
+  // row's column in each of the L = LK/K layers | g on the sample's first row).  The block's rows of xT and of xe are each one
+  // contiguous range: both move by coalesced (16-byte) accesses through the image (one row per thread straight from memory was
+  // F + XE wave instructions with 64 lanes in 64 different lines each).  1024 threads: all of them fetch, then twelve waves write
+  // the xe rows while the other four take the column sums and the head's partials.
   const int nl = g != nullptr ? LK / K : 0;
-  const int ld = F + 3 + nl, XE = F + 3;
+  const int hl = nl + 1, XE = F + 3;
+  const int tid = threadIdx.x;
   const long m0 = (long)blockIdx.x * 256;
-  const long m = m0 + threadIdx.x;
-  float* row = smem + threadIdx.x * ld;
-  if (m < M) {
-    const long b = m / K;
-    const int k = (int)(m - b * K);
-    float dl, dp;
-    if (g != nullptr) {   // the dense head's backward rides here: dP[b, j] = g[b] dense_w[j], and this row's terms of ddense_w | ddense_b
-      const float gb = g[b];
-      for (int l = 0; l < nl; ++l) {
-        const float d = gb * dense_w[l * K + k];
-        dP[b * LK + l * K + k] = d;
-        row[F + 2 + l] = gb * pooled[b * LK + l * K + k];
-      }
-      row[F + 2 + nl] = k == 0 ? gb : 0.f;
-      dl = gb * dense_w[lL * K + k];
-      dp = gb * dense_w[lp * K + k];
-    } else {
-      dl = dPL[b * ldp + k];
-      dp = dPp[b * ldp + k];
-    }
-    for (int f = 0; f < F; ++f) {
-      const float v = xT[m * F + f];
-      xe[m * XE + f] = v;
-      row[f] = v * dl;
-    }
-    xe[m * XE + F] = 1.f;
-    xe[m * XE + F + 1] = dl;
-    xe[m * XE + F + 2] = dp;
-    row[F] = dl;
-    row[F + 1] = dp;
-  } else {
-    for (int f = 0; f < ld; ++f) row[f] = 0.f;
-  }
-  __syncthreads();
-  // column sums: wave q takes rows 64q .. 64q+63 of column f = lane, the four partial sums meet in wave order
-  __shared__ float cs[4][64];
+  const int nrows = (int)min((long)256, (long)M - m0);
+  float* xs = smem;
+  float* dls = xs + 256 * F;
+  float* dps = dls + 256;
+  float* hd = dps + 256;
   {
-    const int f = threadIdx.x & 63, q = threadIdx.x >> 6;
-    float t0 = 0.f, t1 = 0.f;
-    if (f < F + 2) {
-      for (int rr = 64 * q; rr < 64 * q + 64; rr += 2) {
-        t0 += smem[rr * ld + f];
-        t1 += smem[(rr + 1) * ld + f];
+    const float* src = xT + m0 * F;
+    const int n = nrows * F;
+    if ((reinterpret_cast<uintptr_t>(xT) & 15) == 0) {
+      const int n4 = n >> 2;
+      for (int i0 = tid; i0 < n4; i0 += 4 * kXeThreads) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u * kXeThreads < n4 ? reinterpret_cast<const float4*>(src)[i0 + u * kXeThreads] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + u * kXeThreads < n4) reinterpret_cast<float4*>(xs)[i0 + u * kXeThreads] = v[u];
       }
+      for (int i = 4 * n4 + tid; i < n; i += kXeThreads) xs[i] = src[i];
+    } else {
+      for (int i = tid; i < n; i += kXeThreads) xs[i] = src[i];
     }
-    cs[q][f] = t0 + t1;
+    for (int i = n + tid; i < 256 * F; i += kXeThreads) xs[i] = 0.f;
   }
-  // the head's partials of this block: column j = l K + k collects the rows whose k matches, in row order (fixed order); column LK = sum of g
-  if (g != nullptr) {
-    const int k0 = (int)(m0 % K);
-    for (int j = threadIdx.x; j <= LK; j += 256) {
-      float t = 0.f;
-      if (j < LK) {
-        const int l = j / K, k = j - l * K;
-        for (int rr = (k - k0 + K) % K; rr < 256; rr += K) t += smem[rr * ld + F + 2 + l];
+  if (tid < 256) {   // one row per thread: its pooled gradients (and the head's terms)
+    const long m = m0 + tid;
+    float dl = 0.f, dp = 0.f;
+    if (m < M) {
+      const long b = m / K;
+      const int k = (int)(m - b * K);
+      if (g != nullptr) {   // the dense head's backward rides here: dP[b, j] = g[b] dense_w[j], and this row's terms of ddense_w | ddense_b
+        const float gb = g[b];
+        for (int l = 0; l < nl; ++l) {
+          const float d = gb * dense_w[l * K + k];
+          dP[b * LK + l * K + k] = d;
+          hd[tid * hl + l] = gb * pooled[b * LK + l * K + k];
+        }
+        hd[tid * hl + nl] = k == 0 ? gb : 0.f;
+        dl = gb * dense_w[lL * K + k];
+        dp = gb * dense_w[lp * K + k];
       } else {
-        for (int rr = (K - k0) % K; rr < 256; rr += K) t += smem[rr * ld + F + 2 + nl];
+        dl = dPL[b * ldp + k];
+        dp = dPp[b * ldp + k];
       }
-      hpart[(long)blockIdx.x * (LK + 1) + j] = t;
+    } else if (g != nullptr) {
+      for (int l = 0; l <= nl; ++l) hd[tid * hl + l] = 0.f;
+    }
+    dls[tid] = dl;
+    dps[tid] = dp;
+  }
+  __syncthreads();
+  __shared__ float cs[4][64];
+  if (tid < kXeThreads - 256) {
+    // xe rows of the block: x | 1 | dP_L | dP_p, written as the contiguous range they are
+    constexpr int NT = kXeThreads - 256;
+    float* dst = xe + m0 * XE;
+    const int n4 = nrows * XE >> 2;
+    const float rxe = 1.f / (float)XE;
+    for (int i4 = tid; i4 < n4; i4 += NT) {
+      int rr = (int)(((float)(4 * i4) + 0.5f) * rxe);   // (4 i4 < 2^16: the quotient is exact)
+      int c = 4 * i4 - rr * XE;
+      float e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        e[u] = c < F ? xs[rr * F + c] : c == F ? 1.f : c == F + 1 ? dls[rr] : dps[rr];
+        if (++c == XE) {
+          c = 0;
+          ++rr;
+        }
+      }
+      reinterpret_cast<float4*>(dst)[i4] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    for (int i = 4 * n4 + tid; i < nrows * XE; i += NT) {
+      const int rr = i / XE, c = i - rr * XE;
+      dst[i] = c < F ? xs[rr * F + c] : c == F ? 1.f : c == F + 1 ? dls[rr] : dps[rr];
+    }
+  } else {
+    const int t2 = tid - (kXeThreads - 256);
+    // column sums: wave q takes rows 64q .. 64q+63 of column f = lane, the four partial sums meet in wave order
+    {
+      const int f = t2 & 63, q = t2 >> 6;
+      float t0 = 0.f, t1 = 0.f;
+      if (f < F) {
+        for (int rr = 64 * q; rr < 64 * q + 64; rr += 2) {
+          t0 += xs[rr * F + f] * dls[rr];
+          t1 += xs[(rr + 1) * F + f] * dls[rr + 1];
+        }
+      } else if (f < F + 2) {
+        const float* dv = f == F ? dls : dps;
+        for (int rr = 64 * q; rr < 64 * q + 64; rr += 2) {
+          t0 += dv[rr];
+          t1 += dv[rr + 1];
+        }
+      }
+      cs[q][f] = t0 + t1;
+    }
+    // the head's partials of this block: column j = l K + k collects the rows whose k matches, in row order (fixed order); column LK = sum of g
+    if (g != nullptr) {
+      const int k0 = (int)(m0 % K);
+      for (int j = t2; j <= LK; j += 256) {
+        float t = 0.f;
+        if (j < LK) {
+          const int l = j / K, k = j - l * K;
+          for (int rr = (k - k0 + K) % K; rr < 256; rr += K) t += hd[rr * hl + l];
+        } else {
+          for (int rr = (K - k0) % K; rr < 256; rr += K) t += hd[rr * hl + nl];
+        }
+        hpart[(long)blockIdx.x * (LK + 1) + j] = t;
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x < F + 2) dcpart[(long)blockIdx.x * kQtConst + threadIdx.x] = (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]);
+  if (tid < F + 2) dcpart[(long)blockIdx.x * kQtConst + tid] = (cs[0][tid] + cs[1][tid]) + (cs[2][tid] + cs[3][tid]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

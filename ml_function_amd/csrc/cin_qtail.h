@@ -189,11 +189,13 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_x_kernel(const float* 
                                                                    const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
                                                                    float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
                                                                    int Hpp, int F, int Hq, int nT, const float* __restrict__ x, float* __restrict__ xT,
-                                                                   int K, float* __restrict__ x2T, int XL, int xt_in) {
+                                                                   int K, float* __restrict__ x2T, int XL, int xt_in, int ks = -1, long M = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < nT) {
     cin_qtail_t_body(Wp, wsumL, bias_p, bias_L, HL, T, cvec, zbias, Hpp, F, Hq, b, smem);
+  } else if (ks >= 0) {   // (K = 2^ks divides 64, x as given: a workgroup per 64-row block)
+    cin_transpose_block_body(x, xT, x2T, F, ks, b - nT, M, XL, smem);
   } else if (xt_in) {
     cin_wrap_rows_body(x, x2T, F, K, b - nT, XL);
   } else {
@@ -344,14 +346,22 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
     // the extra workgroup: dc[f] (and the two dP sums behind it) = fixed-order sum of the block partials, for cin_qtail_fill_kernel
     float* red = smem;   // [4][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (sixteen partials in flight per lane: four at a time this one workgroup was ndc / 16 L2 round trips in a row -- the longest
+    // chain of the launch)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (lane < F + 2) {
       int p = wave;
-      for (; p + 12 < ndc; p += 16) {
-        a0 += dcpart[(long)p * kQtConst + lane];
-        a1 += dcpart[(long)(p + 4) * kQtConst + lane];
-        a2 += dcpart[(long)(p + 8) * kQtConst + lane];
-        a3 += dcpart[(long)(p + 12) * kQtConst + lane];
+      for (; p + 60 < ndc; p += 64) {
+        float u[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[e] = dcpart[(long)(p + 4 * e) * kQtConst + lane];
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          a0 += u[e];
+          a1 += u[e + 1];
+          a2 += u[e + 2];
+          a3 += u[e + 3];
+        }
       }
       for (; p < ndc; p += 4) a0 += dcpart[(long)p * kQtConst + lane];
     }
@@ -364,11 +374,11 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
   // Both products run on the matrix pipe (v_mfma_f32_32x32x2_f32, one 32-row strip of outputs per wave and visit): as scalar dot
   // products out of LDS they were 2 F floats read per F FMAs -- 12 us of LDS reads per workgroup.  LDS (zero padded to whole tiles):
   //   dt [FT][ldd]: dT[(f',f), h] as [f'][f], FT = F rounded up to 32, ldd = FT + 1 (odd: conflict-free down a column)
-  //   phase 0: wl [HT][ldd]: wsum_L as [n][f], HT = Hq rounded up to 32      phase 1: wp [FK][HT]: W_p[(h,f'),n] as [f'][n], FK = F rounded up to 2
-  const int FT = (F + 31) & ~31, HT = (Hq + 31) & ~31, FK = (F + 1) & ~1, ldd = FT + 1;
+  //   phase 0: wl [HT][ldd]: wsum_L as [n][f], HT = Hq rounded up to 32      phase 1: wp [FK16][HT]: W_p[(h,f'),n] as [f'][n], FK16 = F rounded up to 16 (the k loops' step)
+  const int FT = (F + 31) & ~31, HT = (Hq + 31) & ~31, FK16 = (F + 15) & ~15, ldd = FT + 1;
   float* dt = smem;
   float* op = dt + FT * ldd;
-  const int nop = phase == 0 ? HT * ldd : FK * HT;
+  const int nop = phase == 0 ? HT * ldd : FK16 * HT;
   for (int i = threadIdx.x; i < FT * ldd + nop; i += 256) smem[i] = 0.f;
   __syncthreads();
   for (int i0 = threadIdx.x; i0 < F * F; i0 += 8 * 256) {   // (a column of dT: one dword per 512-byte row, all in flight together)
@@ -391,22 +401,39 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
     __syncthreads();
     // out[f'][n] = sum_f dt[f'][f] wl[n][f]: A = dt (row f' on the lane), B = wl (column n on the lane); a wave takes 32 columns n
     for (int nt = wave; nt < (HT >> 5); nt += 4) {
+      // the shortcut's rank-one part of the lane's 16 (32) rows: requested before the products, used after them
+      float v0[16], v1[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int fp = mfma32_row(reg, half);
+        v0[reg] = vT[(long)min(fp, F - 1) * Hpp + h];
+        v1[reg] = two ? vT[(long)min(fp + 32, F - 1) * Hpp + h] : 0.f;
+      }
       f32x16 a0, a1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) a0[i] = a1[i] = 0.f;
       const float* ar = dt + r * ldd + half;
       const float* br = op + (nt * 32 + r) * ldd + half;
-      for (int k = 0; k < FK; k += 2) {
-        const float b = br[k];
-        a0 = mfma32(ar[k], b, a0);
-        if (two) a1 = mfma32(ar[32 * ldd + k], b, a1);
+      for (int k0 = 0; k0 < FK16; k0 += 16) {   // eight steps' fragments read together, then their products (the padding is zero)
+        float fa[8], fb[8], fc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          fa[u] = ar[k0 + 2 * u];
+          fb[u] = br[k0 + 2 * u];
+          fc[u] = two ? ar[32 * ldd + k0 + 2 * u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a0 = mfma32(fa[u], fb[u], a0);
+          if (two) a1 = mfma32(fc[u], fb[u], a1);
+        }
       }
       const int n = nt * 32 + r;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int fp = mfma32_row(reg, half);
-        if (n < Hq && fp < F) dWp[((long)h * F + fp) * Hq + n] = vT[(long)fp * Hpp + h] + a0[reg];
-        if (two && n < Hq && fp + 32 < F) dWp[((long)h * F + fp + 32) * Hq + n] = vT[(long)(fp + 32) * Hpp + h] + a1[reg];
+        if (n < Hq && fp < F) dWp[((long)h * F + fp) * Hq + n] = v0[reg] + a0[reg];
+        if (two && n < Hq && fp + 32 < F) dWp[((long)h * F + fp + 32) * Hq + n] = v1[reg] + a1[reg];
       }
     }
   } else {
@@ -420,10 +447,19 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
       for (int i = 0; i < 16; ++i) a0[i] = a1[i] = 0.f;
       const float* ar = op + half * HT + mt * 32 + r;
       const float* br = dt + half * ldd + r;
-      for (int k = 0; k < FK; k += 2) {
-        const float a = ar[k * HT];
-        a0 = mfma32(a, br[k * ldd], a0);
-        if (two) a1 = mfma32(a, br[k * ldd + 32], a1);
+      for (int k0 = 0; k0 < FK16; k0 += 16) {
+        float fa[8], fb[8], fc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          fa[u] = ar[(k0 + 2 * u) * HT];
+          fb[u] = br[(k0 + 2 * u) * ldd];
+          fc[u] = two ? br[(k0 + 2 * u) * ldd + 32] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a0 = mfma32(fa[u], fb[u], a0);
+          if (two) a1 = mfma32(fa[u], fc[u], a1);
+        }
       }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
@@ -437,8 +473,8 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
 
 // LDS bytes of cin_qtail_params_kernel
 inline size_t cin_qtail_params_lds(int F, int Hq) {
-  const size_t FT = ((size_t)F + 31) & ~(size_t)31, HT = ((size_t)Hq + 31) & ~(size_t)31, FK = ((size_t)F + 1) & ~(size_t)1, ldd = FT + 1;
-  const size_t fl = FT * ldd + (HT * ldd > FK * HT ? HT * ldd : FK * HT);
+  const size_t FT = ((size_t)F + 31) & ~(size_t)31, HT = ((size_t)Hq + 31) & ~(size_t)31, FK16 = ((size_t)F + 15) & ~(size_t)15, ldd = FT + 1;
+  const size_t fl = FT * ldd + (HT * ldd > FK16 * HT ? HT * ldd : FK16 * HT);
   return (fl > 256 ? fl : 256) * sizeof(float);
 }
 
