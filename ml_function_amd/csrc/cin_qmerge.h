@@ -534,7 +534,9 @@ __global__ __launch_bounds__(256, 2) void cin_dz2_kernel(const float* __restrict
 
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {   // (running the passes in the other order in half of the workgroups, so that the two waves of a
-    // SIMD do not reload their operands at the same moment, changed nothing)
+    // SIMD do not reload their operands at the same moment, changed nothing; neither did a real stagger -- every other group of eight
+    // workgroups walking pass 0 [periods/2, end) | pass 1 | pass 0 [0, periods/2), their reloads in the middle of the others' passes:
+    // 225.6 -> 227-229 us, the third reload costs more than the spread returns)
     const float* gT = pass == 0 ? g1T : g2T;
     const int Hk = pass == 0 ? H1 : H2;
     const float sc = pass == 0 ? 1.f : dpl;
