@@ -63,14 +63,15 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_DZ2=0         ... its two data-gradient passes as two launches of the pair-symmetric dZ kernel instead of one two-pass launch
 //   FIL_CIN_FWDQ=0        ... its forward as two 128-column launches + the pool kernel instead of the 256-column launch with fused pools
 //   FIL_CIN_HEADFOLD=0    ... the pooled relayout + Dense(1) head as their own launch instead of the 256-column launch's epilogue
+//   FIL_CIN_PACKFOLD=0    ... T's two operand layouts by a pack launch instead of by the T workgroups themselves (exact mode)
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq, headfold;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq, headfold, packfold;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1), env_int("FIL_CIN_HEADFOLD", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1), env_int("FIL_CIN_HEADFOLD", 1), env_int("FIL_CIN_PACKFOLD", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -522,18 +523,24 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         if (!xt_in && K <= 64 && (K & (K - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
           for (ks = 0; (1 << ks) < K;) ++ks;
         const size_t sh_x = ks >= 0 ? (size_t)(64 >> ks) * F * (K + 1) : (size_t)F * (K + 1);
-        const size_t sh = std::max(std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq), sh_x) * sizeof(float);
-        allow_lds(cin_qtail_t_x_kernel, sh);
-        const int nx = ks >= 0 ? (int)((M + 63) / 64) : B;
-        hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(2 * Hpp + 1 + nx), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
-                           2 * Hpp + 1, x, xT_own, K, x2T, XL, xt_in ? 1 : 0, ks, (long)M);
-        const long npack = (long)chunks * F * 2 * JTs * 128;
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
-        const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);
-        // (split-bf16 mode: + the forward's planes of [W1s | Ts], from W1 and T themselves)
-        const int NTq = qsplit ? cin_qs_steps(F, JTs) : 0, nbq = qsplit ? std::min(cdiv(NTq * 512, 256), 512) : 0;
-        hipLaunchKernelGGL(cin_qtail_pack_kernel, dim3(nbf + nbz + nbq), dim3(256), 0, st, qtT, WfT, qtWzT, F, Hpp, JTs, chunks, nbf, HS0, tiles, nbz, W[0],
-                           H[0], Wb, NTq);
+        // exact mode: every T workgroup writes its column of both operand layouts itself (one workgroup per column) -- no pack launch;
+        // split-bf16 mode: the planes of [W1s | Ts] need whole rows of T, the pack launch stays
+        const bool fold = !qsplit && knobs().packfold != 0;
+        const QtPackFold pf = fold ? QtPackFold{WfT, qtWzT, JTs, chunks, HS0, tiles} : QtPackFold{nullptr, nullptr, 0, 0, 0, 0};
+        const size_t sh = std::max(cin_qtail_t_lds_floats(F, Hq, fold), sh_x) * sizeof(float);
+        allow_lds(cin_qtail_t_x_kernel, sh);
+        const int nx = ks >= 0 ? (int)((M + 63) / 64) : B, nT = Hpp + 1;
+        hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(nT + nx), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
+                           nT, x, xT_own, K, x2T, XL, xt_in ? 1 : 0, ks, (long)M, pf);
+        if (!fold) {
+          const long npack = (long)chunks * F * 2 * JTs * 128;
+          const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);
+          // (split-bf16 mode: + the forward's planes of [W1s | Ts], from W1 and T themselves)
+          const int NTq = qsplit ? cin_qs_steps(F, JTs) : 0, nbq = qsplit ? std::min(cdiv(NTq * 512, 256), 512) : 0;
+          hipLaunchKernelGGL(cin_qtail_pack_kernel, dim3(nbf + nbz + nbq), dim3(256), 0, st, qtT, WfT, qtWzT, F, Hpp, JTs, chunks, nbf, HS0, tiles, nbz, W[0],
+                             H[0], Wb, NTq);
+        }
       }
       FIL_CHECK_LAUNCH();
       {
@@ -570,9 +577,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
       {
         ProfScope ps("cin_tail_prep", st);
         // (wsum_L, wsum_p and its MFMA operand copy came out of the preparation launch)
-        const size_t sh = std::max((size_t)2 * F * ((((size_t)Hq + 3) & ~(size_t)3) + 4), (size_t)Hq * F + Hq) * sizeof(float);
+        const size_t sh = cin_qtail_t_lds_floats(F, Hq, false) * sizeof(float);
         allow_lds(cin_qtail_t_kernel, sh);
-        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(2 * Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
         // T in the forward kernel's operand layout (workspace) and in the dZ kernel's slot order (saved for the backward): one launch
         const long npack = (long)chunks * F * 2 * JTs * 128;
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;

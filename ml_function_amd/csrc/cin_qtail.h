@@ -102,15 +102,41 @@ static __global__ __launch_bounds__(256) void cin_qtail_pack_kernel(const float*
   else cin_qs_pack_wb_body(W1, H1, T, H, Wb, NT, F, JTs, blockIdx.x - nbf - nbz, gridDim.x - nbf - nbz);
 }
 
+// LDS floats of a T workgroup (cin_qtail_t_body; fold: + the column itself) -- and of the cvec workgroup beside them
+inline size_t cin_qtail_t_lds_floats(int F, int Hq, bool fold) {
+  const size_t FT = ((size_t)F + 31) & ~(size_t)31, ldn = (((size_t)Hq + 15) & ~(size_t)15) + 1;
+  return std::max(2 * FT * ldn + (fold ? (size_t)F * F : 0), (size_t)Hq * F + Hq);
+}
 constexpr int kQtConst = 64;   // cvec[f < F] = c[f], cvec[kQtConst] = sum_n bias_L[n], cvec[kQtConst + 1] = sum_n bias_p[n]
+
+// Where a T workgroup puts its column in the two operand layouts itself (Wf != nullptr: no pack launch behind it; the workgroup of column h
+// holds the whole column): Wf as cin_pack_wf_sym_body (JT2 = 2 JTs, chunks), Wz as cin_pack_wz_sym_body (JTs, NCOL, tiles).
+struct QtPackFold {
+  float* Wf;
+  float* Wz;
+  int JTs, chunks, NCOL, tiles;
+};
 
 // T[(f'*F + f)*Hpp + h] for block h < Hpp; block Hpp writes cvec and a zero bias vector for the R GEMM.
 __device__ __forceinline__ void cin_qtail_t_body(const float* __restrict__ Wp, const float* __restrict__ wsumL,
                                                  const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
                                                  float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
-                                                 int Hpp, int F, int Hq, int bid, float* smem) {
-  const int h = bid >> 1, part = bid & 1;   // two workgroups per h (each half of the (f', f) outputs); the last one: cvec
+                                                 int Hpp, int F, int Hq, int bid, float* smem, QtPackFold pf = QtPackFold{nullptr, nullptr, 0, 0, 0, 0}) {
+  const bool fold = pf.Wf != nullptr;
+  const int h = bid;   // one workgroup per column h of T; the last one: cvec
   if (h == Hpp) {
+    if (fold) {   // columns past the layer's width in both layouts are zero (none when Hpp fills its chunks)
+      const int JT2 = 2 * pf.JTs, padf = pf.chunks * 128 - Hpp, padz = pf.NCOL - Hpp;
+      for (int i = threadIdx.x; i < F * JT2 * padf; i += 256) {
+        const int row = i / padf, n = Hpp + (i - row * padf);
+        const int hh = row / JT2, d = row - hh * JT2;
+        pf.Wf[((long)((n >> 7) * F + hh) * JT2 + d) * 128 + (n & 127)] = 0.f;
+      }
+      for (int i = threadIdx.x; i < pf.tiles * 32 * padz; i += 256) {
+        const int row = i / padz;
+        pf.Wz[(long)row * pf.NCOL + Hpp + (i - row * padz)] = 0.f;
+      }
+    }
     float* wl = smem;            // wsum_L [Hq][F]
     float* bp = wl + Hq * F;     // bias_p [Hq]
     qt_stage(wsumL, wl, Hq * F);
@@ -134,43 +160,107 @@ __device__ __forceinline__ void cin_qtail_t_body(const float* __restrict__ Wp, c
     for (int i = threadIdx.x; i < Hpp; i += 256) zbias[i] = 0.f;
     return;
   }
-  // LDS: wp [F][ldn] (W_p rows of this h) | wlT [F][ldn] (wsum_L transposed: [f][n]); ldn = Hq rounded up to 4, + 4: rows are
-  // 16-byte aligned and 4 banks apart, the dot products over n run on 16-byte LDS reads
-  const int ldn = ((Hq + 3) & ~3) + 4;
+  // T_h[f'][f] = sum_n W_p[(h,f'),n] wsum_L[(n,f)] on the matrix pipe (v_mfma_f32_32x32x2_f32; as scalar dot products out of LDS the
+  // column was 2 Hq floats read per Hq FMAs and output).  LDS, zero padded to whole tiles: wp [FT][ldn] (W_p rows of this h) |
+  // wlT [FT][ldn] (wsum_L transposed: [f][n]) | tn [F F] (folded pack);  FT = F rounded up to 32, ldn = Hq rounded up to 16, + 1 (odd:
+  // conflict-free down a column).  Both inputs are requested before the images are cleared.
+  const int FT = (F + 31) & ~31, K16 = (Hq + 15) & ~15, ldn = K16 + 1, on = F * Hq;
   float* wp = smem;
-  float* wlT = smem + F * ldn;
-  for (int i = threadIdx.x; i < 2 * F * ldn; i += 256) smem[i] = 0.f;   // (padding columns must be zero)
+  float* wlT = smem + FT * ldn;
+  float* tn = wlT + FT * ldn;
+  const float* wsrc = Wp + (long)h * F * Hq;
+  const float rH = 1.f / (float)Hq, rF = 1.f / (float)F;
+  constexpr int NO = 20;   // loads per thread and input in the first batch (F = 39, Hq = 128: all of them)
+  float av[NO], bv[NO];
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    const int i = threadIdx.x + u * 256;
+    av[u] = i < on ? wsrc[i] : 0.f;
+    bv[u] = i < on ? wsumL[i] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * FT * ldn; i += 256) smem[i] = 0.f;
   __syncthreads();
-  qt_stage_rows(Wp + (long)h * F * Hq, wp, F, Hq, ldn);
-  for (int i0 = threadIdx.x; i0 < Hq * F; i0 += 8 * 256) {
-    float v[8];
+  auto put_a = [&](int i, float v) {   // W_p[(h,f'),n] at i = f' Hq + n
+    const int fp = (int)(((float)i + 0.5f) * rH);
+    wp[fp * ldn + (i - fp * Hq)] = v;
+  };
+  auto put_b = [&](int i, float v) {   // wsum_L[(n,f)] at i = n F + f
+    const int n = (int)(((float)i + 0.5f) * rF);
+    wlT[(i - n * F) * ldn + n] = v;
+  };
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < Hq * F ? wsumL[i0 + u * 256] : 0.f;
+  for (int u = 0; u < NO; ++u) {
+    const int i = threadIdx.x + u * 256;
+    if (i < on) {
+      put_a(i, av[u]);
+      put_b(i, bv[u]);
+    }
+  }
+  for (int i = threadIdx.x + NO * 256; i < on; i += 256) {   // (larger shapes: the rest, plainly)
+    put_a(i, wsrc[i]);
+    put_b(i, wsumL[i]);
+  }
+  __syncthreads();
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
+    const int ntile = FT >> 5;   // 1 or 2 strips each way: up to four 32 x 32 tiles, one per wave
+    if (wave < ntile * ntile) {
+      const int mt = wave / ntile, nt = wave - mt * ntile;
+      f32x16 acc;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * 256;
-      if (i < Hq * F) {
-        const int n = i / F;
-        wlT[(i - n * F) * ldn + n] = v[u];
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ar = wp + (mt * 32 + r) * ldn + half;
+      const float* br = wlT + (nt * 32 + r) * ldn + half;
+      for (int k0 = 0; k0 < K16; k0 += 16) {   // eight steps' fragments read together, then their products
+        float fa[8], fb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          fa[u] = ar[k0 + 2 * u];
+          fb[u] = br[k0 + 2 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma32(fa[u], fb[u], acc);
+      }
+      const int f = nt * 32 + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int fp = mt * 32 + mfma32_row(reg, half);
+        if (fp < F && f < F) {
+          T[(long)(fp * F + f) * Hpp + h] = acc[reg];
+          if (fold) tn[fp * F + f] = acc[reg];
+        }
       }
     }
   }
+  if (!fold) return;
   __syncthreads();
-  const int nhalf = (F * F + 1) / 2;
-  const int nq = (Hq + 3) >> 2;
-  for (int idx = part * nhalf + threadIdx.x; idx < min(F * F, (part + 1) * nhalf); idx += 256) {
-    const int fp = idx / F, f = idx - fp * F;
-    const float4* a = reinterpret_cast<const float4*>(wp + fp * ldn);
-    const float4* b = reinterpret_cast<const float4*>(wlT + f * ldn);
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    for (int q = 0; q < nq; ++q) {
-      const float4 av = a[q], bv = b[q];
-      t0 = fmaf(av.x, bv.x, t0);
-      t1 = fmaf(av.y, bv.y, t1);
-      t2 = fmaf(av.z, bv.z, t2);
-      t3 = fmaf(av.w, bv.w, t3);
+  // the pair weight of (hh, f = (hh + d) mod F) as the pack kernels form it
+  auto sym = [&](int hh, int d) -> float {
+    if (hh >= F || d > F / 2) return 0.f;
+    int f = hh + d;
+    if (f >= F) f -= F;
+    if (d == 0) return tn[hh * F + hh];
+    const float v = tn[hh * F + f] + tn[f * F + hh];
+    return 2 * d == F ? 0.5f * v : v;
+  };
+  {
+    const int JT2 = 2 * pf.JTs;
+    const float rj = 1.f / (float)JT2;
+    float* dst = pf.Wf + (long)(h >> 7) * F * JT2 * 128 + (h & 127);
+    for (int e = threadIdx.x; e < F * JT2; e += 256) {
+      const int hh = (int)(((float)e + 0.5f) * rj), d = e - hh * JT2;
+      dst[(long)e * 128] = sym(hh, d);
     }
-    T[(long)idx * Hpp + h] = (t0 + t1) + (t2 + t3);
+  }
+  {
+    const float rj = 1.f / (float)pf.JTs;
+    for (int row = threadIdx.x; row < pf.tiles * 32; row += 256) {
+      const int i = row & 31, t = row >> 5;
+      const int rr = (i & 3) + 4 * (i >> 3), hf = (i >> 2) & 1;
+      const int slot = 16 * t + rr;
+      const int hh = (int)(((float)slot + 0.5f) * rj), j = slot - hh * pf.JTs;
+      pf.Wz[(long)row * pf.NCOL + h] = sym(hh, 2 * j + hf);
+    }
   }
 }
 
@@ -189,11 +279,12 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_x_kernel(const float* 
                                                                    const float* __restrict__ bias_p, const float* __restrict__ bias_L, int HL,
                                                                    float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
                                                                    int Hpp, int F, int Hq, int nT, const float* __restrict__ x, float* __restrict__ xT,
-                                                                   int K, float* __restrict__ x2T, int XL, int xt_in, int ks = -1, long M = 0) {
+                                                                   int K, float* __restrict__ x2T, int XL, int xt_in, int ks = -1, long M = 0,
+                                                                   QtPackFold pf = QtPackFold{nullptr, nullptr, 0, 0, 0, 0}) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < nT) {
-    cin_qtail_t_body(Wp, wsumL, bias_p, bias_L, HL, T, cvec, zbias, Hpp, F, Hq, b, smem);
+    cin_qtail_t_body(Wp, wsumL, bias_p, bias_L, HL, T, cvec, zbias, Hpp, F, Hq, b, smem, pf);
   } else if (ks >= 0) {   // (K = 2^ks divides 64, x as given: a workgroup per 64-row block)
     cin_transpose_block_body(x, xT, x2T, F, ks, b - nT, M, XL, smem);
   } else if (xt_in) {
@@ -379,26 +470,39 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
   float* dt = smem;
   float* op = dt + FT * ldd;
   const int nop = phase == 0 ? HT * ldd : FK16 * HT;
+  // Both inputs are requested BEFORE the image is cleared (the clear and its barrier run under the loads): a column of dT -- one dword
+  // per 512-byte row -- and the operand's F Hq contiguous floats; quotients by multiplication (indices < 2^14: exact).
+  const float* osrc = phase == 0 ? wsumL : Wp + (long)h * F * Hq;
+  const int ocols = phase == 0 ? F : Hq, old = phase == 0 ? ldd : HT, on = F * Hq;
+  const float rF = 1.f / (float)F, rO = 1.f / (float)ocols;
+  constexpr int ND = 8, NO = 24;   // loads per thread in the first batch (F = 39, Hq = 128: all of them)
+  float dv[ND], ov[NO];
+#pragma unroll
+  for (int u = 0; u < ND; ++u) dv[u] = (int)threadIdx.x + u * 256 < F * F ? dT[(long)(threadIdx.x + u * 256) * Hpp + h] : 0.f;
+#pragma unroll
+  for (int u = 0; u < NO; ++u) ov[u] = (int)threadIdx.x + u * 256 < on ? osrc[threadIdx.x + u * 256] : 0.f;
   for (int i = threadIdx.x; i < FT * ldd + nop; i += 256) smem[i] = 0.f;
   __syncthreads();
-  for (int i0 = threadIdx.x; i0 < F * F; i0 += 8 * 256) {   // (a column of dT: one dword per 512-byte row, all in flight together)
-    float v[8];
+  auto put_dt = [&](int i, float v) {
+    const int fp = (int)(((float)i + 0.5f) * rF);
+    dt[fp * ldd + (i - fp * F)] = v;
+  };
+  auto put_op = [&](int i, float v) {
+    const int rr = (int)(((float)i + 0.5f) * rO);
+    op[rr * old + (i - rr * ocols)] = v;
+  };
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < F * F ? dT[(long)(i0 + u * 256) * Hpp + h] : 0.f;
+  for (int u = 0; u < ND; ++u)
+    if ((int)threadIdx.x + u * 256 < F * F) put_dt(threadIdx.x + u * 256, dv[u]);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * 256;
-      if (i < F * F) {
-        const int fp = i / F;
-        dt[fp * ldd + (i - fp * F)] = v[u];
-      }
-    }
-  }
+  for (int u = 0; u < NO; ++u)
+    if ((int)threadIdx.x + u * 256 < on) put_op(threadIdx.x + u * 256, ov[u]);
+  for (int i = threadIdx.x + ND * 256; i < F * F; i += 256) put_dt(i, dT[(long)i * Hpp + h]);   // (larger shapes: the rest, plainly)
+  for (int i = threadIdx.x + NO * 256; i < on; i += 256) put_op(i, osrc[i]);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
   const bool two = F > 32;   // a second strip of 32 f' (phase 0) / f (phase 1)
   if (phase == 0) {
-    qt_stage_rows(wsumL, op, Hq, F, ldd);
-    __syncthreads();
     // out[f'][n] = sum_f dt[f'][f] wl[n][f]: A = dt (row f' on the lane), B = wl (column n on the lane); a wave takes 32 columns n
     for (int nt = wave; nt < (HT >> 5); nt += 4) {
       // the shortcut's rank-one part of the lane's 16 (32) rows: requested before the products, used after them
@@ -437,8 +541,6 @@ static __global__ __launch_bounds__(256) void cin_qtail_params_kernel(const floa
       }
     }
   } else {
-    qt_stage_rows(Wp + (long)h * F * Hq, op, F, Hq, HT);
-    __syncthreads();
     // out[n][f] = sum_f' wp[f'][n] dt[f'][f]: A = wp (row n on the lane), B = dt (column f on the lane); a wave takes 32 rows n
     float* pl = partL + (long)h * Hq * F;
     for (int mt = wave; mt < (HT >> 5); mt += 4) {
