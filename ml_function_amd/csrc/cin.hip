@@ -479,7 +479,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
     ProfScope ps("cin_fwd_prep", st, 2.0 * M * F * sizeof(float));
     const int JTs = cin_jt_sym(F), chunks0 = chunks_of(H[0]);
     const long npack = (long)chunks0 * F * 2 * JTs * 128;
-    // (merged forward: the x transposes ride in the NEXT launch, beside the T workgroups -- this one is the weight work alone)
+    // (merged forward: the x transposes ride in the NEXT launch, behind the T workgroups, whose latency chain is the longer one -- this
+    // launch is the weight work alone.  Measured the other way round, transposes here and T alone there: 9.8 + 11.4 us against
+    // 4.2 + 12.5)
     const bool fq = qmerge && knobs().fwdq != 0 && s.HS(0) == 128;
     const int nt = fq ? 0 : B, npk = (int)std::min<long>((npack + 255) / 256, 1024), nwl = cdiv(tg.Hq * F, 8), nwp = cdiv(tg.Hpp * F, 8);
     const size_t sh = (xt_in || fq) ? 0 : (size_t)F * (K + 1) * sizeof(float);
@@ -530,7 +532,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         const QtPackFold pf = fold ? QtPackFold{WfT, qtWzT, JTs, chunks, HS0, tiles} : QtPackFold{nullptr, nullptr, 0, 0, 0, 0};
         const size_t sh = std::max(cin_qtail_t_lds_floats(F, Hq, fold), sh_x) * sizeof(float);
         allow_lds(cin_qtail_t_x_kernel, sh);
-        const int nx = ks >= 0 ? (int)((M + 63) / 64) : B, nT = Hpp + 1;
+        const int nx = ks >= 0 ? (int)((M + 63) / 64) : B, nT = cin_qtail_t_wgs(Hpp);
         hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(nT + nx), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
                            nT, x, xT_own, K, x2T, XL, xt_in ? 1 : 0, ks, (long)M, pf);
         if (!fold) {
@@ -579,7 +581,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         // (wsum_L, wsum_p and its MFMA operand copy came out of the preparation launch)
         const size_t sh = cin_qtail_t_lds_floats(F, Hq, false) * sizeof(float);
         allow_lds(cin_qtail_t_kernel, sh);
-        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(Hpp + 1), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
+        hipLaunchKernelGGL(cin_qtail_t_kernel, dim3(cin_qtail_t_wgs(Hpp)), dim3(256), sh, st, W[l], qtWsumL, bias[l], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq);
         // T in the forward kernel's operand layout (workspace) and in the dZ kernel's slot order (saved for the backward): one launch
         const long npack = (long)chunks * F * 2 * JTs * 128;
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;

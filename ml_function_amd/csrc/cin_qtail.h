@@ -71,18 +71,19 @@ __device__ __forceinline__ void qt_wsum_body(const float* __restrict__ W, float*
   }
 }
 
-// One launch for the forward's input-only preparation (cf. cin_fwd_prep_kernel): [0, nt) x -> xT transposes; [.., +npk) the first
+// One launch for the forward's input-only preparation (cf. cin_fwd_prep_kernel): [0, nt) x -> xT / wrapped-row transposes; [.., +npk) the first
 // layer's pair-symmetric weight pack; [.., +nwl) wsum_L; the rest (nwp workgroups): wsum_p and its MFMA operand copy.
 static __global__ __launch_bounds__(256) void cin_qtail_prep_kernel(const float* __restrict__ x, float* __restrict__ xT, int F, int K, int nt,
                                                                     const float* __restrict__ W0, float* __restrict__ Wf, int H0, int JT2s, int chunks0,
                                                                     int npk, const float* __restrict__ WL, float* __restrict__ wsumL, int Hq, int HL,
                                                                     int nwl, const float* __restrict__ Wp, float* __restrict__ wsum_p,
                                                                     float* __restrict__ wsn_p, int Hpp, int JT2, int chunksp,
-                                                                    float* __restrict__ x2T, int XL, int xt_in) {
+                                                                    float* __restrict__ x2T, int XL, int xt_in, int ks = -1, long M = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < nt) {
-    if (xt_in) cin_wrap_rows_body(x, x2T, F, K, b, XL);
+    if (ks >= 0) cin_transpose_block_body(x, xT, x2T, F, ks, b, M, XL, smem);   // (K = 2^ks divides 64, x as given: a workgroup per 64-row block)
+    else if (xt_in) cin_wrap_rows_body(x, x2T, F, K, b, XL);
     else cin_transpose_in_body(x, xT, F, K, b, smem, x2T, XL);
   }
   else if (b < nt + npk) cin_pack_wf_sym_body(W0, Wf, F, H0, JT2s, chunks0, b - nt, npk);
@@ -103,6 +104,7 @@ static __global__ __launch_bounds__(256) void cin_qtail_pack_kernel(const float*
 }
 
 // LDS floats of a T workgroup (cin_qtail_t_body; fold: + the column itself) -- and of the cvec workgroup beside them
+inline int cin_qtail_t_wgs(int Hpp) { return 8 * ((Hpp + 7) / 8) + 1; }   // workgroups of cin_qtail_t_body (the last one: cvec)
 inline size_t cin_qtail_t_lds_floats(int F, int Hq, bool fold) {
   const size_t FT = ((size_t)F + 31) & ~(size_t)31, ldn = (((size_t)Hq + 15) & ~(size_t)15) + 1;
   return std::max(2 * FT * ldn + (fold ? (size_t)F * F : 0), (size_t)Hq * F + Hq);
@@ -123,7 +125,12 @@ __device__ __forceinline__ void cin_qtail_t_body(const float* __restrict__ Wp, c
                                                  float* __restrict__ T, float* __restrict__ cvec, float* __restrict__ zbias,
                                                  int Hpp, int F, int Hq, int bid, float* smem, QtPackFold pf = QtPackFold{nullptr, nullptr, 0, 0, 0, 0}) {
   const bool fold = pf.Wf != nullptr;
-  const int h = bid;   // one workgroup per column h of T; the last one: cvec
+  // One workgroup per column h of T (+ the cvec workgroup, bid == 8 ceil(Hpp / 8)).  Every output of a column is a 4-byte store into a
+  // line that 31 other columns share: the columns are dealt so that workgroup i of XCD i % 8 (the dispatcher's round robin) takes
+  // column (i % 8) ceil(Hpp / 8) + i / 8 -- the columns of a 64-byte sector meet in ONE L2 instead of in eight.
+  const int per8 = (Hpp + 7) >> 3;
+  const int h = bid == 8 * per8 ? Hpp : (bid & 7) * per8 + (bid >> 3);
+  if (h > Hpp || (h == Hpp && bid != 8 * per8)) return;
   if (h == Hpp) {
     if (fold) {   // columns past the layer's width in both layouts are zero (none when Hpp fills its chunks)
       const int JT2 = 2 * pf.JTs, padf = pf.chunks * 128 - Hpp, padz = pf.NCOL - Hpp;
