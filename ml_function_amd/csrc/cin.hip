@@ -524,7 +524,7 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         int ks = -1;
         if (!xt_in && K <= 64 && (K & (K - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
           for (ks = 0; (1 << ks) < K;) ++ks;
-        const size_t sh_x = ks >= 0 ? (size_t)(64 >> ks) * F * (K + 1) : (size_t)F * (K + 1);
+        const size_t sh_x = ks >= 0 ? (size_t)(64 >> ks) * F * (K + 1) : (xt_in ? (size_t)64 * (F | 1) : (size_t)F * (K + 1));
         const int tiles = cdiv(F, cin_dz_h_per_period(JTs)) * cin_dz_tiles_per_period(JTs) + 1;
         // exact mode: every T workgroup writes its column of both operand layouts itself (one workgroup per column) -- no pack launch;
         // split-bf16 mode: the planes of [W1s | Ts] need whole rows of T, the pack launch stays
@@ -532,9 +532,9 @@ extern "C" int fil_cin_fwd(const float* x, const float* const* W, const float* c
         const QtPackFold pf = fold ? QtPackFold{WfT, qtWzT, JTs, chunks, HS0, tiles} : QtPackFold{nullptr, nullptr, 0, 0, 0, 0};
         const size_t sh = std::max(cin_qtail_t_lds_floats(F, Hq, fold), sh_x) * sizeof(float);
         allow_lds(cin_qtail_t_x_kernel, sh);
-        const int nx = ks >= 0 ? (int)((M + 63) / 64) : B, nT = cin_qtail_t_wgs(Hpp);
+        const int nx = (ks >= 0 || xt_in) ? (int)((M + 63) / 64) : B, nT = cin_qtail_t_wgs(Hpp);
         hipLaunchKernelGGL(cin_qtail_t_x_kernel, dim3(nT + nx), dim3(256), sh, st, W[p], qtWsumL, bias[p], bias[lL], tg.HL, qtT, qtCvec, qt_zbias, Hpp, F, Hq,
-                           nT, x, xT_own, K, x2T, XL, xt_in ? 1 : 0, ks, (long)M, pf);
+                           nT, x, xT_own, K, x2T, XL, xt_in ? 1 : 0, ks, (ks >= 0 || xt_in) ? (long)M : 0L, pf);
         if (!fold) {
           const long npack = (long)chunks * F * 2 * JTs * 128;
           const int nbf = (int)std::min<long>((npack + 255) / 256, 1024), nbz = (int)std::min<long>(((long)tiles * 32 * HS0 + 255) / 256, 1024);

@@ -152,6 +152,35 @@ __device__ __forceinline__ void cin_transpose_block_body(const float* __restrict
     }
   }
 }
+// The wrapped rows of one 64-row block from an input that is already transposed (FIL_CIN_X_TRANSPOSED; any K): the block's 64 F
+// floats of xT are one contiguous range, its 64 XL floats of x2T another -- through LDS [64][F | 1] (odd row pitch: the column reads
+// are conflict-free), 16-byte stores.
+__device__ __forceinline__ void cin_wrap_block_body(const float* __restrict__ xT, float* __restrict__ x2T, int F, long blk, long M, int XL,
+                                                    float* smem) {
+  const int ld = F | 1;
+  const long m0 = blk * 64;
+  const int rows = (int)min((long)64, M - m0);
+  const float* src = xT + m0 * F;
+  const float rF = 1.f / (float)F;
+  for (int i = threadIdx.x; i < rows * F; i += 256) {   // (coalesced dwords: xT as given need not be 16-byte aligned)
+    const int j = (int)(((float)i + 0.5f) * rF);
+    smem[j * ld + (i - j * F)] = src[i];
+  }
+  __syncthreads();
+  float* d2 = x2T + blk * XL * 64;
+  for (int i4 = threadIdx.x; i4 < XL * 16; i4 += 256) {
+    const int p = i4 >> 4, j0 = (i4 & 15) * 4;
+    int f = p;
+    while (f >= F) f -= F;
+    float e[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e[c] = j0 + c < rows ? smem[(j0 + c) * ld + f] : 0.f;
+    if (j0 + 3 < rows) reinterpret_cast<float4*>(d2)[i4] = make_float4(e[0], e[1], e[2], e[3]);
+    else
+      for (int c = 0; c < 4; ++c)
+        if (j0 + c < rows) d2[4 * i4 + c] = e[c];
+  }
+}
 // the same from an input that is already transposed (FIL_CIN_X_TRANSPOSED): the K rows of sample b
 __device__ __forceinline__ void cin_wrap_rows_body(const float* __restrict__ xT, float* __restrict__ x2T, int F, int K, long b, int XL) {
   const float* src = xT + b * K * F;

@@ -294,6 +294,8 @@ static __global__ __launch_bounds__(256) void cin_qtail_t_x_kernel(const float* 
     cin_qtail_t_body(Wp, wsumL, bias_p, bias_L, HL, T, cvec, zbias, Hpp, F, Hq, b, smem, pf);
   } else if (ks >= 0) {   // (K = 2^ks divides 64, x as given: a workgroup per 64-row block)
     cin_transpose_block_body(x, xT, x2T, F, ks, b - nT, M, XL, smem);
+  } else if (xt_in && M > 0) {   // (x arrives transposed: the wrapped rows by 64-row blocks)
+    cin_wrap_block_body(x, x2T, F, b - nT, M, XL, smem);
   } else if (xt_in) {
     cin_wrap_rows_body(x, x2T, F, K, b - nT, XL);
   } else {

@@ -585,8 +585,49 @@ class _DenseReluFn(torch.autograd.Function):
                 dw = gemm_f32(xc, dz, trans_a=True).to(wdt) if ctx.needs_input_grad[1] else None      # x^T dz (split over the batch)
             else:
                 dx = torch.matmul(dz, wc.t()).to(xdt) if ctx.needs_input_grad[0] else None
-                dw = torch.matmul(xc.t(), dz).to(wdt) if ctx.needs_input_grad[1] else None
+                dw = _batch_split_xt_dz(xc, dz).to(wdt) if ctx.needs_input_grad[1] else None
         return dx, dw, db.to(bdt)
+
+
+def _batch_split_xt_dz(x, dz, splits=16):
+    """x^T dz for bf16 x [B, I], dz [B, O] with the reduction over the batch cut into `splits` slices: one batched library GEMM + an
+    fp32 sum of the slices in slice order.  As ONE GEMM the library runs the (I x O)-tile grid of this shape -- 8...40 workgroups for a
+    4096-row batch -- at 27-31 us (MLP 637-256-128, B = 4096); cut in 16 it is 15-16 us including the sum (tools/mm_forms.py), and the
+    result is fp32 without a separate cast.  Small or ragged batches take the plain product."""
+    B = x.shape[0]
+    if B < 1024 or B % splits != 0:
+        return torch.matmul(x.t(), dz)
+    parts = torch.bmm(x.view(splits, B // splits, x.shape[1]).transpose(1, 2), dz.view(splits, B // splits, dz.shape[1]))
+    return parts.sum(0, dtype=torch.float32)
+
+
+class _DenseFn(torch.autograd.Function):
+    """y = x @ kernel + bias in fp32 through the library's own GEMM, forward and backward (dx = dy W^T, dW = x^T dy split over the batch and
+    summed in order, db = the column sums).  The logit heads of the zoo's MLPs are Dense(1) / Dense(2) on a [B, 64...144] input: as library
+    calls the framework runs dW = x^T dy of such a layer -- 64 x 1 outputs, reduction 4096 -- in 35 us (one 16 x 64 tile walking the batch)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        _require_cuda(x, kernel, bias)
+        xc, wc = _f32c(x), _f32c(kernel)
+        ctx.save_for_backward(xc, wc)
+        return gemm_f32(xc, wc, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = gemm_f32(dy, wc, trans_b=True) if ctx.needs_input_grad[0] else None
+        dw = gemm_f32(xc, dy, trans_a=True) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def dense(x, kernel, bias):
+    """x @ kernel + bias, x [B, in] fp32, kernel [in, units], bias [units] (csrc/gemm.hip both ways)."""
+    if x.dim() != 2 or kernel.dim() != 2 or x.shape[1] != kernel.shape[0] or tuple(bias.shape) != (kernel.shape[1],):
+        raise FilError("dense: x %s, kernel %s, bias %s" % (tuple(x.shape), tuple(kernel.shape), tuple(bias.shape)))
+    return _DenseFn.apply(x, kernel, bias)
 
 
 def dense_relu(x, kernel, bias):

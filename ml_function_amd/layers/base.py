@@ -37,6 +37,18 @@ def merge_packed_views(tensors):
     while i < n:
         t = tensors[i]
         base = getattr(t, "_base", None)
+        # the same for the [B,1] column views `dense[:, i:i+1]` of one contiguous [B,n] block (FeatureInput's dense inputs)
+        if (base is not None and base.dim() == 2 and t.dim() == 2 and t.shape[1] == 1 and t.shape[0] == base.shape[0]
+                and base.is_contiguous() and t.stride() == base.stride()):
+            first = t.storage_offset() - base.storage_offset()
+            j = i + 1
+            while (j < n and getattr(tensors[j], "_base", None) is base and tensors[j].shape == t.shape and tensors[j].stride() == t.stride()
+                   and tensors[j].storage_offset() == base.storage_offset() + first + (j - i)):
+                j += 1
+            if j - i > 1 and 0 <= first and first + (j - i) <= base.shape[1]:
+                out.append(base if (first == 0 and j - i == base.shape[1]) else base.narrow(1, first, j - i))
+                i = j
+                continue
         ok = (base is not None and base.dim() == 3 and t.dim() == 3 and t.shape[1] == 1 and t.shape[0] == base.shape[0]
               and t.shape[2] == base.shape[2] and base.is_contiguous() and t.stride() == base.stride())
         if not ok:

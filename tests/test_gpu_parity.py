@@ -1541,6 +1541,33 @@ def test_dense_relu_layer_matches_float64(B, I, N, dtype):
     assert torch.equal(db, db2) and torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("B,I,N", [(4096, 64, 1), (4096, 144, 2), (1, 3, 1), (333, 70, 9)])
+def test_dense_layer_matches_float64(B, I, N):
+    """The logit heads of the zoo's MLPs (Dense(1) / Dense(2), core_layer.py:201-226) as functional.dense: the library's own fp32 GEMM
+    forward and for both gradients, column sums for the bias.  Against x W + b in float64: 1e-5; and the Dense layer takes that path
+    on the GPU."""
+    from ml_function_amd import functional as Fn
+    from ml_function_amd.layers.core_layer import Dense
+    rng = np.random.default_rng(23 + N)
+    x = dev(rng.standard_normal((B, I)).astype(np.float32)).requires_grad_()
+    W = dev(rng.standard_normal((I, N)).astype(np.float32) / np.sqrt(I)).requires_grad_()
+    b = dev(rng.standard_normal(N).astype(np.float32) * 0.3).requires_grad_()
+    g = dev(rng.standard_normal((B, N)).astype(np.float32))
+    y = Fn.dense(x, W, b)
+    y.backward(g)
+    x64, W64, b64 = [t.detach().double().cpu().requires_grad_() for t in (x, W, b)]
+    want = x64 @ W64 + b64
+    want.backward(g.double().cpu())
+    check("dense y", y.detach(), want.detach().numpy(), tol=1e-5)
+    check("dense dx", x.grad, x64.grad.numpy(), tol=1e-5)
+    check("dense dW", W.grad, W64.grad.numpy(), tol=1e-5)
+    check("dense db", b.grad, b64.grad.numpy(), tol=1e-5)
+    lay = Dense(N)
+    out = lay(x.detach())
+    assert type(out.grad_fn).__name__ == "_DenseFnBackward"
+    check("Dense layer", out.detach(), (x.detach() @ lay.kernel + lay.bias).detach().double().cpu().numpy(), tol=1e-5)
+
+
 def test_dnn_layer_takes_the_fused_hidden_layers_and_agrees_with_the_composed_path():
     from ml_function_amd.layers import DnnLayer
     rng = np.random.default_rng(4)
@@ -1555,7 +1582,8 @@ def test_dnn_layer_takes_the_fused_hidden_layers_and_agrees_with_the_composed_pa
 @pytest.mark.parametrize("M,N,K,ta,tb,epi", [(4096, 256, 637, 0, 0, 2), (4096, 637, 256, 0, 1, 0), (637, 256, 4096, 1, 0, 0), (4096, 128, 256, 0, 0, 2),
                                              (256, 128, 4096, 1, 0, 0), (4096, 64, 128, 0, 0, 1), (1, 1, 1, 0, 0, 0), (65, 33, 17, 1, 1, 1),
                                              (130, 70, 1000, 0, 1, 0), (7, 300, 5, 1, 0, 2), (64, 64, 16, 0, 0, 0), (200, 9, 2048, 1, 0, 0),
-                                             (1024, 256, 637, 0, 0, 2)])
+                                             (1024, 256, 637, 0, 0, 2), (4096, 1, 64, 0, 0, 1), (4096, 64, 1, 0, 1, 0), (64, 1, 4096, 1, 0, 0),
+                                             (4096, 2, 144, 0, 0, 1), (144, 2, 4096, 1, 0, 0)])
 def test_gemm_f32_matches_float64(M, N, K, ta, tb, epi):
     """fil_gemm_f32 (csrc/gemm.hip: the dense layers' GEMMs -- y = x W + b with ReLU, dx = dz W^T, dW = x^T dz, at the xDeepFM MLP's shapes
     and at ragged ones) against the same product in float64: 1e-5 norm-relative (exact fp32 MFMA chains; split-K shapes sum their slices in
