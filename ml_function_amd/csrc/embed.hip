@@ -15,6 +15,7 @@
 // the dense table or hands them out as (rows, values) -- no atomics, no dense zero table needed.  The fp32-atomic
 // scatter-add (order of additions not fixed) stays available as fil_embed_scatter_add.
 #include "common.h"
+#include <cstdlib>
 
 namespace fil {
 
@@ -144,6 +145,95 @@ __global__ __launch_bounds__(1024) void embed_sort_fields_kernel(const int64_t* 
     const unsigned key = (unsigned)(c >> pos_bits);
     sorted_ids[(long)f * B + i] = key != 0u ? off + (int64_t)(key - 1u) : -1;
     perm[(long)f * B + i] = (int64_t)(unsigned)(c & pos_mask) * F + f;
+  }
+}
+
+// The same sort with the keys in REGISTERS: thread t of 1024 owns the E = N / 1024 consecutive elements t E .. t E + E - 1.  A
+// compare-exchange step at distance j < E is register-to-register, at E <= j < 64 E a lane exchange inside the wave (the partner of
+// element i is element i ^ j: the same slot of thread t ^ (j / E)), and only the steps at distance >= 64 E cross waves through LDS --
+// 10 of the 78 steps of N = 4096 (E = 4) need a barrier, against all 78 of the kernel above.  The composites are unique, so "the
+// lower index keeps the smaller one" is the same network as the swap form.
+template <typename KeyT>
+__device__ __forceinline__ KeyT lane_xor(KeyT v, int m) {
+  if constexpr (sizeof(KeyT) == 4) {
+    return (KeyT)__shfl_xor((int)v, m, 64);
+  } else {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m, 64);
+    return ((KeyT)hi << 32) | lo;
+  }
+}
+template <typename KeyT, int E>
+__global__ __launch_bounds__(1024) void embed_sort_fields_reg_kernel(const int64_t* __restrict__ offsets, const int64_t* __restrict__ sizes,
+                                                                     const unsigned char* __restrict__ frozen, const int64_t* __restrict__ idx,
+                                                                     int64_t* __restrict__ sorted_ids, int64_t* __restrict__ perm, int B, int F,
+                                                                     int pos_bits) {
+  constexpr int N = 1024 * E;
+  __shared__ KeyT xch[N];
+  const int f = blockIdx.x, t = threadIdx.x;
+  const bool live = frozen == nullptr || !frozen[f];
+  const int64_t vf = sizes != nullptr ? sizes[f] : (int64_t)0x7fffffff;
+  KeyT v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    KeyT c = ~(KeyT)0;            // padding sorts last
+    if (i < B) {
+      const int64_t id = idx[(long)i * F + f];
+      const bool ok = live && id >= 0 && id < vf;
+      c = ((KeyT)(ok ? (unsigned)id + 1u : 0u) << pos_bits) | (KeyT)(unsigned)i;
+    }
+    v[e] = c;
+  }
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if ((e & j) == 0) {
+            const bool up = k < E ? (e & k) == 0 : ((t * E) & k) == 0;
+            const KeyT a = v[e], b = v[e | j];
+            const bool sw = (a > b) == up;
+            v[e] = sw ? b : a;
+            v[e | j] = sw ? a : b;
+          }
+        }
+      } else {
+        const int m = j / E;                       // partner thread t ^ m
+        const bool up = ((t * E) & k) == 0;        // (k > j >= E: the same for the thread's E elements)
+        const bool lower = (t & m) == 0;
+        KeyT o[E];
+        if (m < 64) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] = lane_xor<KeyT>(v[e], m);
+        } else {
+          __syncthreads();                         // (the previous exchange's reads are done)
+#pragma unroll
+          for (int e = 0; e < E; ++e) xch[t * E + e] = v[e];
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] = xch[(t ^ m) * E + e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const KeyT lo = v[e] < o[e] ? v[e] : o[e], hi = v[e] < o[e] ? o[e] : v[e];
+          v[e] = (lower == up) ? lo : hi;
+        }
+      }
+    }
+  }
+  const int64_t off = offsets[f];
+  const KeyT pos_mask = ((KeyT)1 << pos_bits) - 1;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    if (i < B) {
+      const KeyT c = v[e];
+      const unsigned key = (unsigned)(c >> pos_bits);
+      sorted_ids[(long)f * B + i] = key != 0u ? off + (int64_t)(key - 1u) : -1;
+      perm[(long)f * B + i] = (int64_t)(unsigned)(c & pos_mask) * F + f;
+    }
   }
 }
 
@@ -406,7 +496,29 @@ extern "C" int fil_embed_sort_fields(const int64_t* offsets, const int64_t* size
     return fail(FIL_ERR_HIP, "fil_embed_sort_fields: cannot reserve %zu bytes of LDS", sh);
   }
   const dim3 block(N >= 2048 ? 1024 : std::max(64, N / 2));
-  if (narrow)
+  // (N = 1024 ... 8192: the keys in registers, embed_sort_fields_reg_kernel; FIL_EMBED_SORT_LDS=1 keeps the all-LDS network)
+  static const bool lds_only = [] {
+    const char* e = getenv("FIL_EMBED_SORT_LDS");
+    return e != nullptr && e[0] == '1';
+  }();
+  const int E = N / 1024;
+  if (!lds_only && N >= 1024 && N <= 8192) {
+#define FIL_SORT_REG(KT, EV, PB)                                                                                                                     \
+  hipLaunchKernelGGL((embed_sort_fields_reg_kernel<KT, EV>), dim3(F), dim3(1024), 0, (hipStream_t)stream, offsets, sizes, frozen, idx, sorted_ids, perm, \
+                     B, F, PB)
+    if (narrow) {
+      if (E == 1) FIL_SORT_REG(unsigned, 1, bits);
+      else if (E == 2) FIL_SORT_REG(unsigned, 2, bits);
+      else if (E == 4) FIL_SORT_REG(unsigned, 4, bits);
+      else FIL_SORT_REG(unsigned, 8, bits);
+    } else {
+      if (E == 1) FIL_SORT_REG(unsigned long long, 1, 32);
+      else if (E == 2) FIL_SORT_REG(unsigned long long, 2, 32);
+      else if (E == 4) FIL_SORT_REG(unsigned long long, 4, 32);
+      else FIL_SORT_REG(unsigned long long, 8, 32);
+    }
+#undef FIL_SORT_REG
+  } else if (narrow)
     hipLaunchKernelGGL(embed_sort_fields_kernel<unsigned>, dim3(F), block, sh, (hipStream_t)stream, offsets, sizes, frozen, idx, sorted_ids, perm, B, F, N, bits);
   else
     hipLaunchKernelGGL(embed_sort_fields_kernel<unsigned long long>, dim3(F), block, sh, (hipStream_t)stream, offsets, sizes, frozen, idx, sorted_ids, perm, B,

@@ -787,7 +787,7 @@ def test_embed_out_of_range_ids_and_determinism():
     assert float(grad_fr[lo:hi].abs().max()) == 0.0 and float(grad_fr[:lo].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("B", [1, 333, 1000, 4096, 8192])
+@pytest.mark.parametrize("B", [1, 333, 1000, 2000, 4096, 5000, 8192])
 def test_embed_sort_fields_is_a_stable_sort_within_each_field(B):
     """fil_embed_sort_fields (one launch, a bitonic network per field in LDS) against torch's stable sort of the same field: the same
     (row id, position) sequence, skipped entries (-1: out of range / frozen field) first."""
