@@ -298,11 +298,9 @@ constexpr int kRunShort = 8;
 __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restrict__ g, const int64_t* __restrict__ perm,
                                                             const int64_t* __restrict__ sorted_ids, float* __restrict__ dtable, long R,
                                                             int K) {
-  __shared__ float red[4][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int KQ = (K + 3) / 4, C = 64 / KQ;
   const int c = lane / KQ, kq = lane - c * KQ;
-  float* my = red[wave];
   for (long j0 = ((long)blockIdx.x * 4 + wave) * C; j0 < R; j0 += (long)gridDim.x * 4 * C) {
     const long j = j0 + c;
     const bool have = c < C && j < R;
@@ -344,10 +342,19 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
       const int ll = __builtin_ctzll(pending);          // first lane of the group that found the run
       pending &= pending - 1;
       const long js = j0 + ll / KQ;
-      const int64_t rl = sorted_ids[js];
-      // the end of the run first, 64 ids per look (one ballot): the sums below then run over a KNOWN range, so that their loads do
-      // not hang on an id compare per element -- a field of 10 values in a batch of 4096 is ten runs of ~400, and a loop of three
-      // dependent loads per 64 / KQ elements was ~25 us of the 29 us launch
+      // the run's id from the lane that found it (a reload was one more L2 round trip per run)
+      const int64_t rl = ((int64_t)__shfl((int)(row >> 32), ll, 64) << 32) | (unsigned)__shfl((int)(unsigned)row, ll, 64);
+      // The end of the run, 64 ids per look (one ballot), and -- requested together with the first look, before its answer -- the
+      // permutation entries of the first 4 C elements: a run of up to 4 C elements (most of the "long" ones: 9 ... 64) is then two
+      // dependent round trips (ids | perm, rows) instead of four.  The sums run over a KNOWN range (a compare per element would
+      // hang every load on an id: a field of 10 values in a batch of 4096 is ten runs of ~400).
+      const long jj0 = js + c;
+      long pr0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long q = jj0 + (long)u * C;
+        pr0[u] = perm[(c < C && q < R) ? q : js];
+      }
       long je = js + 1;
       for (;;) {
         const long pp = je + lane;
@@ -367,7 +374,16 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc4[u][i] = 0.f;
       if (c < C) {
-        for (long jj = js + c; jj < je; jj += 4L * C) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* src = g + pr0[u] * K + kq * 4;
+          const bool on = jj0 + (long)u * C < je;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (on && kq * 4 + i < K) acc4[u][i] += src[i];
+        }
+        // (the next batch's permutation entries requested in front of this batch's rows: 62 -> 90 registers, 20.9 -> 21.9 us)
+        for (long jj = jj0 + 4L * C; jj < je; jj += 4L * C) {
           long pr[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) pr[u] = perm[jj + (long)u * C < je ? jj + (long)u * C : jj];
@@ -384,19 +400,22 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
       float acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = (acc4[0][i] + acc4[1][i]) + (acc4[2][i] + acc4[3][i]);
+      // the C partial sums meet in a fixed tree of lane exchanges (group c takes group c + s, s = 1, 2, 4, ...): through LDS, lane
+      // group 0 adding the others one by one, the fold was C - 1 dependent LDS reads per run
+      for (int sft = 1; sft < C; sft <<= 1) {
+        float o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) my[lane * 4 + i] = acc[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < 4; ++i) o[i] = __shfl(acc[i], (lane + sft * KQ) & 63, 64);
+        if (c < C && (c & (2 * sft - 1)) == 0 && c + sft < C) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += o[i];
+        }
+      }
       if (c == 0) {
-        for (int cc = 1; cc < C; ++cc)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] += my[(cc * KQ + kq) * 4 + i];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (kq * 4 + i < K) dtable[rl * K + kq * 4 + i] = acc[i];
       }
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }
