@@ -129,6 +129,32 @@ __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, c
   __shared__ float red[4][64][MO];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * kMergeRows, nrow = min(kMergeRows, B - b0), D = mp.D;
+  // blockIdx.y = the 64-column chunk of the concatenated input this workgroup takes (round 6: one workgroup walked all chunks of
+  // its rows one after the other -- three dependent rounds of loads behind the dz prologue on 64 CUs: 24.8 us for 2.4 MB)
+  int pi = 0, dc = 0, d0 = 0;
+  {
+    int ch = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nci = (mp.w[i] + 63) >> 6;
+      if (pi == i && ch >= nci) {
+        ch -= nci;
+        d0 += mp.w[i];
+        pi = i + 1;
+      }
+    }
+    dc = ch * 64;
+  }
+  if (pi >= 4) return;
+  const int w = mp.w[pi];
+  const int d = dc + lane;
+  const int r0 = wave * 16;     // this wave's rows of the block
+  // the wave's sixteen rows of its column and the weights, requested before the dz prologue's loads are waited for
+  float xs[16], wr[MO];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) xs[s] = (d < w && r0 + s < nrow) ? merge_ld(mp.p[pi], (long)(b0 + r0 + s) * w + d, mp.bf[pi]) : 0.f;
+#pragma unroll
+  for (int o = 0; o < MO; ++o) wr[o] = (d < w && o < O) ? W[(long)(d0 + d) * O + o] : 0.f;
   for (int s = tid; s < kMergeRows; s += 256) {
     float dot = 0.f, p[MO], g[MO];
 #pragma unroll
@@ -142,49 +168,29 @@ __global__ __launch_bounds__(256) void merge_softmax_bwd_kernel(MergeParts mp, c
   }
   __syncthreads();
   float* mypart = part + (long)blockIdx.x * (D + 1) * O;
-  const int r0 = wave * 16;     // this wave's rows of the block
-  int d0 = 0;
+  float acc[MO];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int w = mp.w[i];
-    for (int dc = 0; dc < w; dc += 64) {   // (uniform over the workgroup: barriers inside)
-      const int d = dc + lane;
-      float wr[MO], acc[MO];
+  for (int o = 0; o < MO; ++o) acc[o] = 0.f;
+  if (d < w) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int rr = r0 + s;
+      float dx = 0.f;
 #pragma unroll
       for (int o = 0; o < MO; ++o) {
-        wr[o] = (d < w && o < O) ? W[(long)(d0 + d) * O + o] : 0.f;
-        acc[o] = 0.f;
+        acc[o] = fmaf(xs[s], dz[rr][o], acc[o]);
+        dx = fmaf(dz[rr][o], wr[o], dx);
       }
-      if (d < w) {
-#pragma unroll
-        for (int h = 0; h < 1; ++h) {
-          float xs[16];     // sixteen rows of this column: all loads in flight before the first store
-#pragma unroll
-          for (int s = 0; s < 16; ++s) xs[s] = r0 + 16 * h + s < nrow ? merge_ld(mp.p[i], (long)(b0 + r0 + 16 * h + s) * w + d, mp.bf[i]) : 0.f;
-#pragma unroll
-          for (int s = 0; s < 16; ++s) {
-            const int rr = r0 + 16 * h + s;
-            float dx = 0.f;
-#pragma unroll
-            for (int o = 0; o < MO; ++o) {
-              acc[o] = fmaf(xs[s], dz[rr][o], acc[o]);
-              dx = fmaf(dz[rr][o], wr[o], dx);
-            }
-            if (rr < nrow && mp.dp[i] != nullptr) merge_st(mp.dp[i], (long)(b0 + rr) * w + d, dx, mp.bf[i]);
-          }
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < MO; ++o) red[wave][lane][o] = acc[o];
-      __syncthreads();
-      if (wave == 0 && d < w) {
-        for (int o = 0; o < O; ++o) mypart[(long)(d0 + d) * O + o] = (red[0][lane][o] + red[1][lane][o]) + (red[2][lane][o] + red[3][lane][o]);
-      }
-      __syncthreads();
+      if (rr < nrow && mp.dp[pi] != nullptr) merge_st(mp.dp[pi], (long)(b0 + rr) * w + d, dx, mp.bf[pi]);
     }
-    d0 += w;
   }
-  if (tid < O) {
+#pragma unroll
+  for (int o = 0; o < MO; ++o) red[wave][lane][o] = acc[o];
+  __syncthreads();
+  if (wave == 0 && d < w) {
+    for (int o = 0; o < O; ++o) mypart[(long)(d0 + d) * O + o] = (red[0][lane][o] + red[1][lane][o]) + (red[2][lane][o] + red[3][lane][o]);
+  }
+  if (blockIdx.y == 0 && tid < O) {
     float t = 0.f;
     for (int s = 0; s < nrow; ++s) t += dz[s][tid];
     mypart[(long)D * O + tid] = t;
@@ -385,8 +391,10 @@ extern "C" int fil_merge_softmax_bwd(const void* const* parts, const int* widths
   float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);   // block partials [nblk][(D + 1) O]
   ProfScope ps("merge_softmax_bwd", st, (double)B * (2.0 * mp.D * 4.0 + 2.0 * O * 4.0));
   const int nblk = cdiv(B, kMergeRows), n = (mp.D + 1) * O;
-  if (O <= 2) hipLaunchKernelGGL(merge_softmax_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, B, O);
-  else hipLaunchKernelGGL(merge_softmax_bwd_kernel<kMergeMaxO>, dim3(nblk), dim3(256), 0, st, mp, W, out, dout, part, B, O);
+  int nch = 0;   // 64-column chunks of the parts: a workgroup per (block of rows, chunk)
+  for (int i = 0; i < 4; ++i) nch += (mp.w[i] + 63) / 64;
+  if (O <= 2) hipLaunchKernelGGL(merge_softmax_bwd_kernel<2>, dim3(nblk, nch), dim3(256), 0, st, mp, W, out, dout, part, B, O);
+  else hipLaunchKernelGGL(merge_softmax_bwd_kernel<kMergeMaxO>, dim3(nblk, nch), dim3(256), 0, st, mp, W, out, dout, part, B, O);
   hipLaunchKernelGGL(block_partials_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, nblk, n, dW, mp.D * O, db);
   FIL_CHECK_LAUNCH();
   return FIL_OK;

@@ -26,7 +26,9 @@ def pack_linear(inputs, batch):
     if isinstance(inputs, (list, tuple)):
         if len(inputs) == 0:
             return None
-        return torch.cat([t.reshape(batch, -1) for t in inputs], dim=1)
+        # (the F [B,1,1] views of one packed [B,F,1] block: a slice of it, no F-way concatenation -- two copy launches, 14 us per DeepFM step)
+        ts = [t.reshape(batch, -1) for t in merge_packed_views([t for t in inputs])]
+        return ts[0] if len(ts) == 1 else torch.cat(ts, dim=1)
     return inputs.reshape(batch, -1)
 
 
