@@ -15,6 +15,7 @@
 // reduction order inside a stage is permuted so that a wave half's k values are contiguous -- free in a GEMM, the same for A and B).
 // Global -> registers two stages ahead, registers -> the other LDS buffer behind the MFMAs, one barrier per stage.
 #include "common.h"
+#include <cstdlib>
 
 namespace fil {
 
@@ -72,14 +73,20 @@ struct GemmStage {
 // iteration) -- one stage of 16 MFMAs per wave is ~0.5 us, less than a round trip to L2; stage s+1 sits in the other LDS buffer.
 // BN = 64: 4 waves, a 64 x 64 tile;  BN = 32: 2 waves, a 64 x 32 tile -- twice the workgroups, so that shapes with few tiles still put
 // two or more INDEPENDENT workgroups on a CU (one's stores and barrier under the other's MFMAs).
-template <bool TA, bool TB, int BN>
-__global__ __launch_bounds__(4 * BN) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                          const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc, int epi,
-                                                          int kchunk, float* __restrict__ part) {
-  constexpr int T = 4 * BN;
+// KW = 2: twice the waves -- waves w and w + T/128 share an output tile and take the two halves of every stage's k range (8 MFMAs each),
+// the upper one's accumulators joining the lower one's through LDS after the loop (lower + upper: a fixed order).  With ONE wave per
+// SIMD a stage was load -> LDS -> barrier -> LDS reads -> a chain of 16 dependent MFMAs with nothing beside it; two waves per SIMD
+// cover each other's barriers and LDS round trips, and each thread stages half the pieces (the MLP's twelve GEMMs 180 -> 164 us).
+template <bool TA, bool TB, int BN, int KW>
+__global__ __launch_bounds__(4 * BN * KW) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                               const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
+                                                               int epi, int kchunk, float* __restrict__ part) {
+  constexpr int T = 4 * BN * KW;
   __shared__ __attribute__((aligned(16))) float As[2][kGemmBM * kGemmLd];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * kGemmLd];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
+  constexpr int NWT = BN == 64 ? 4 : 2;          // waves per output tile set
+  const int wave = wave0 % NWT, kw = wave0 / NWT;   // kw: which half of a stage's k range (KW = 2)
   const int i = lane & 31, half = lane >> 5;
   // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin, each XCD has its own L2 -- workgroup id of XCD id % 8 takes
   // tile (id % 8) (ntiles / 8) + id / 8 of the row-block-major list, so the column tiles of one block of A's rows (and their
@@ -107,7 +114,8 @@ __global__ __launch_bounds__(4 * BN) void gemm_f32_kernel(const float* __restric
     const float* as = As[cur] + (wm + i) * kGemmLd + 4 * half;
     const float* bs = Bs[cur] + (wn + i) * kGemmLd + 4 * half;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t0 = 0; t0 < 4 / KW; ++t0) {
+      const int t = KW == 1 ? t0 : 2 * kw + t0;
       const gf32x4 a4 = *reinterpret_cast<const gf32x4*>(as + 8 * t);
       const gf32x4 b4 = *reinterpret_cast<const gf32x4*>(bs + 8 * t);
 #pragma unroll
@@ -132,6 +140,18 @@ __global__ __launch_bounds__(4 * BN) void gemm_f32_kernel(const float* __restric
     sa[0].store(As[0]);
     sb[0].store(Bs[0]);
     __syncthreads();
+  }
+  if constexpr (KW == 2) {   // the upper half's accumulators through LDS ([register][lane]: conflict-free; the stage buffers are done with)
+    __syncthreads();
+    float* xch = &As[0][0] + (wave * 16) * 64;
+    if (kw == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kw == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += xch[r * 64 + lane];
   }
   // accumulator register r of lane (i, half): row (r & 3) + 8 (r >> 2) + 4 half, column i of the wave's 32 x 32 tile
   const int col = n0 + wn + i;
@@ -202,14 +222,21 @@ extern "C" int fil_gemm_f32(const float* A, const float* B, float* C, const floa
   const int bn = gemm_bn(M, N);
   const dim3 grid(cdiv(cdiv(N, bn) * cdiv(M, kGemmBM), 8) * 8, 1, ns);   // (tiles in XCD-aware order: a multiple of 8 workgroups)
   ProfScope ps("gemm_f32", st, 2.0 * M * N * K);
-#define FIL_GEMM(TAV, TBV)                                                                                                                        \
-  do {                                                                                                                                            \
-    if (bn == 64)                                                                                                                                 \
-      hipLaunchKernelGGL((gemm_f32_kernel<TAV, TBV, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, (long)lda, (long)ldb, (long)ldc, epilogue, \
-                         kchunk, part);                                                                                                           \
-    else                                                                                                                                          \
-      hipLaunchKernelGGL((gemm_f32_kernel<TAV, TBV, 32>), grid, dim3(128), 0, st, A, B, C, bias, M, N, K, (long)lda, (long)ldb, (long)ldc, epilogue, \
-                         kchunk, part);                                                                                                           \
+  static const int kw_env = [] {   // FIL_GEMM_KW=1: one wave per output tile (A/B)
+    const char* e = getenv("FIL_GEMM_KW");
+    return e != nullptr && e[0] == '1' ? 1 : 2;
+  }();
+  const int kw = kw_env;
+#define FIL_GEMM_L(TAV, TBV, BNV, KWV)                                                                                                  \
+  hipLaunchKernelGGL((gemm_f32_kernel<TAV, TBV, BNV, KWV>), grid, dim3(4 * BNV * KWV), 0, st, A, B, C, bias, M, N, K, (long)lda, (long)ldb, \
+                     (long)ldc, epilogue, kchunk, part)
+#define FIL_GEMM(TAV, TBV)                                                    \
+  do {                                                                        \
+    if (bn == 64) {                                                           \
+      if (kw == 2) FIL_GEMM_L(TAV, TBV, 64, 2); else FIL_GEMM_L(TAV, TBV, 64, 1); \
+    } else {                                                                  \
+      if (kw == 2) FIL_GEMM_L(TAV, TBV, 32, 2); else FIL_GEMM_L(TAV, TBV, 32, 1); \
+    }                                                                         \
   } while (0)
   if (trans_a) {
     if (trans_b) FIL_GEMM(true, true); else FIL_GEMM(true, false);
@@ -217,6 +244,7 @@ extern "C" int fil_gemm_f32(const float* A, const float* B, float* C, const floa
     if (trans_b) FIL_GEMM(false, true); else FIL_GEMM(false, false);
   }
 #undef FIL_GEMM
+#undef FIL_GEMM_L
   FIL_CHECK_LAUNCH();
   if (ns > 1) {
     const long n = (long)M * N;
