@@ -51,7 +51,7 @@ struct GemmStage {
       }
     }
   }
-  __device__ __forceinline__ void store(float* S) const {   // S: [ROWS][kGemmLd]
+  __device__ __forceinline__ void store(float* S) const {   // S: [ROWS][kGemmLd] (TR = false) or [32 k][ROWS + 4] (TR = true)
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int idx = threadIdx.x + u * T;
@@ -59,10 +59,8 @@ struct GemmStage {
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = (keep >> (4 * u + e)) & 1u ? v[u][e] : 0.f;
       if constexpr (!TR) *reinterpret_cast<gf32x4*>(S + (idx >> 3) * kGemmLd + 4 * (idx & 7)) = w;
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) S[(4 * (idx % (ROWS / 4)) + e) * kGemmLd + idx / (ROWS / 4)] = w[e];
-      }
+      else *reinterpret_cast<gf32x4*>(S + (idx / (ROWS / 4)) * (ROWS + 4) + 4 * (idx % (ROWS / 4))) = w;   // [k][ROWS + 4]: one 16-byte store
+      // (k-contiguous like the other operand, this piece was four 4-byte stores 144 floats apart: 4 banks for 16 lanes)
     }
   }
 };
@@ -111,13 +109,25 @@ __global__ __launch_bounds__(4 * BN * KW) void gemm_f32_kernel(const float* __re
     sb[set].load(rb, ldb, n0, kb + s * kGemmBK, N, ke);
   };
   auto compute = [&](int cur) {
-    const float* as = As[cur] + (wm + i) * kGemmLd + 4 * half;
-    const float* bs = Bs[cur] + (wn + i) * kGemmLd + 4 * half;
+    // an operand staged k-contiguous is read as one 16-byte word per four steps; one staged row-contiguous ([k][rows + 4]) as four dwords
+    const float* as = TA ? As[cur] + (4 * half) * (kGemmBM + 4) + wm + i : As[cur] + (wm + i) * kGemmLd + 4 * half;
+    const float* bs = !TB ? Bs[cur] + (4 * half) * (BN + 4) + wn + i : Bs[cur] + (wn + i) * kGemmLd + 4 * half;
 #pragma unroll
     for (int t0 = 0; t0 < 4 / KW; ++t0) {
       const int t = KW == 1 ? t0 : 2 * kw + t0;
-      const gf32x4 a4 = *reinterpret_cast<const gf32x4*>(as + 8 * t);
-      const gf32x4 b4 = *reinterpret_cast<const gf32x4*>(bs + 8 * t);
+      gf32x4 a4, b4;
+      if constexpr (TA) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a4[e] = as[(8 * t + e) * (kGemmBM + 4)];
+      } else {
+        a4 = *reinterpret_cast<const gf32x4*>(as + 8 * t);
+      }
+      if constexpr (!TB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = bs[(8 * t + e) * (BN + 4)];
+      } else {
+        b4 = *reinterpret_cast<const gf32x4*>(bs + 8 * t);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
     }
