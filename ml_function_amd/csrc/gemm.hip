@@ -3,9 +3,9 @@
 // at these shapes (4096 x 637 x 256 and smaller) hipBLASLt's fp32 kernels run at ~0.15 of the fp32 matrix rate (170 us of a 1.25 ms
 // xDeepFM step for 5 GFLOP: profiles/r06_xdeepfm_model.txt), so they are hand-written too: one LDS-tiled v_mfma_f32_32x32x2_f32 kernel,
 // exact fp32 chains, fixed summation order (split-K partials are summed in slice order by a second launch: deterministic).  Where it
-// stands: the nine GEMMs of the xDeepFM MLP 156 us against the library's 167 (the small ones 1.3-2x faster, the three 1.3-GFLOP ones
-// 23-35 us = 0.24-0.36 of the matrix rate, level with the library) -- a 64 x 64 tile stages 16 KB through registers into LDS per 64
-// MFMAs, and at 4096 x 256 there are not enough tiles for bigger ones.
+// stands (tools/gemm_bench.py, replayed): the twelve GEMMs of the xDeepFM MLP incl. its logit head 151 us (180 before the two-waves-per-tile
+// form and the row-contiguous LDS layout below; the library: ~190), the three 1.3-GFLOP ones 22-27 us = 0.3-0.4 of the matrix rate -- a 64 x 64
+// tile stages 16 KB through registers into LDS per 64 MFMAs, and at 4096 x 256 there are not enough tiles for bigger ones.
 //
 //   C [M][N] = op(A) [M][K] . op(B) [K][N]  (+ bias[n], ReLU)
 //   TA = 0: A is [M][K] row-major (k contiguous);  1: A is [K][M] (the transposed operand of dW = x^T dz)
