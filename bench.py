@@ -113,7 +113,8 @@ def deepfm_benchmark(args):
     vocab = [int(v) for v in np.exp(rng.uniform(np.log(10), np.log(1e5), 39))]
     xd = args.workload == "xdeepfm"
     fi = models.FeatureInput(sparseInfo=models.make_sparse_info(vocab, embed_dim=16), useLinear=True, useAddLinear=xd,
-                             useFlattenLinear=xd, emitXT=xd)   # (xDeepFM: the gather also emits the layout the CIN kernels read)
+                             useFlattenLinear=xd, emitXT=xd,   # (xDeepFM: the gather also emits the layout the CIN kernels read)
+                             embedDtype=None if xd else torch.bfloat16)   # (DeepFM c2: the embedding block in bf16 straight out of the gather)
     body = models.XDeepFM(conv_size=[128, 128, 128]) if xd else models.DeepFM(hidden_units=[256, 128])
 
     class Bf16Body(torch.nn.Module):
@@ -123,9 +124,10 @@ def deepfm_benchmark(args):
 
         def forward(self, fea):
             from ml_function_amd.layers.base import merge_packed_views
-            blk = merge_packed_views(list(fea.sparse_embed))   # the F views of the packed gather output: one cast, no copies
-            fea.sparse_embed = (list(blk[0].bfloat16().split(1, dim=1)) if len(blk) == 1
-                                else [e.bfloat16() for e in fea.sparse_embed])
+            if fea.sparse_embed[0].dtype != torch.bfloat16:   # (a gather that emits fp32: one cast of the packed block, no copies)
+                blk = merge_packed_views(list(fea.sparse_embed))
+                fea.sparse_embed = (list(blk[0].bfloat16().split(1, dim=1)) if len(blk) == 1
+                                    else [e.bfloat16() for e in fea.sparse_embed])
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 return self.inner(fea).float()
 

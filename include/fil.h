@@ -39,7 +39,7 @@ typedef enum { FIL_F32 = 0, FIL_BF16 = 1 } fil_dtype;
 /* ABI version: bumped on EVERY change of an entry point's argument list or semantics.  fil_version() returns the value the
  * library was compiled with; the ctypes binding (ml_function_amd/_lib.py) refuses a library whose value differs from this
  * header's, so a stale prebuilt .so can never be called with shifted arguments. */
-#define FIL_ABI_VERSION 214
+#define FIL_ABI_VERSION 215
 int fil_version(void);                 /* == FIL_ABI_VERSION of the header the library was built from */
 const char* fil_last_error(void);      /* thread-local, never NULL */
 
@@ -230,6 +230,10 @@ int fil_pattn_bwd(const float* q, const float* k, const float* v, const float* m
  */
 int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
                      int* oob_count, int B, int F, int K, void* stream);
+/* the same with the block's storage type chosen (out_dtype FIL_F32 / FIL_BF16: the rows leave rounded to bf16 -- what a bf16 model
+ * would otherwise do to the block in a cast launch of its own; the table stays fp32) */
+int fil_embed_gather_dt(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, void* out,
+                        int* oob_count, int B, int F, int K, int out_dtype, void* stream);
 /* the same gather emitting BOTH the packed block out [B,F,K] and its transposed rows out_t [B*K][F] (out_t[(b*K+k)*F+f] =
  * out[b,f,k]) -- the layout the CIN kernels read: hand out_t to fil_cin_fwd / fil_cin_bwd as `x` with FIL_CIN_X_TRANSPOSED and
  * the consumer's input transpose is gone (gather fused into the consumer). */
@@ -252,6 +256,9 @@ int fil_embed_sort_fields(const int64_t* offsets, const int64_t* sizes, const un
 /* the same sums without any data-dependent size (HIP-graph capturable): sorted_ids [R] = the stably sorted row ids, perm [R]
  * the sorting permutation; the run of every distinct id >= 0 is summed in sorted order into the (pre-zeroed) dense dtable. */
 int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, void* stream);
+/* the same for a gradient block stored as g_dtype (FIL_F32 / FIL_BF16: converted on load, summed in fp32 into the fp32 dtable) */
+int fil_embed_run_sum_dt(const void* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, int g_dtype,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N2  The score head and the loss behind the interaction layers (all tensors fp32, n = batch rows).

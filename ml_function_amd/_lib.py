@@ -59,12 +59,14 @@ SIGNATURES = {
     "fil_pattn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_pattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "fil_embed_gather": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fil_embed_gather_dt": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fil_embed_gather_xt": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_scatter_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fil_embed_row_ids": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "fil_embed_sort_fields": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _c.c_int64, _P]),
     "fil_embed_segment_sum": (_I, [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _P]),
     "fil_embed_run_sum": (_I, [_P, _P, _P, _P, _c.c_long, _I, _P]),
+    "fil_embed_run_sum_dt": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _P]),
     "fil_score_add_sigmoid_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "fil_score_add_sigmoid_bwd": (_I, [_P, _P, _P, _I, _P]),
     "fil_bce_mean_fwd": (_I, [_P, _P, _F, _P, _P, _I, _P]),

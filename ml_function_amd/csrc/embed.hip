@@ -15,14 +15,16 @@
 // the dense table or hands them out as (rows, values) -- no atomics, no dense zero table needed.  The fp32-atomic
 // scatter-add (order of additions not fixed) stays available as fil_embed_scatter_add.
 #include "common.h"
+#include <hip/hip_bf16.h>
 #include <cstdlib>
 
 namespace fil {
 
-template <int VEC>
+// OT = __hip_bfloat16: the rows leave rounded to bf16 (the block a bf16 model would otherwise cast in a launch of its own)
+template <int VEC, typename OT = float>
 __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ offsets,
                                                            const int64_t* __restrict__ sizes, const int64_t* __restrict__ idx,
-                                                           float* __restrict__ out, int* __restrict__ oob_count, long rows, int F,
+                                                           OT* __restrict__ out, int* __restrict__ oob_count, long rows, int F,
                                                            int K) {
   const int KV = K / VEC;
   const long total = rows * KV;
@@ -37,9 +39,17 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
     if constexpr (VEC == 4) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) v = *reinterpret_cast<const float4*>(table + src);
-      *reinterpret_cast<float4*>(out + row * K + kv * 4) = v;
+      if constexpr (sizeof(OT) == 4) {
+        *reinterpret_cast<float4*>(out + row * K + kv * 4) = v;
+      } else {
+        OT* o = out + row * K + kv * 4;
+        o[0] = (OT)v.x;
+        o[1] = (OT)v.y;
+        o[2] = (OT)v.z;
+        o[3] = (OT)v.w;
+      }
     } else {
-      out[row * K + kv] = ok ? table[src] : 0.f;
+      out[row * K + kv] = (OT)(ok ? table[src] : 0.f);
     }
   }
 }
@@ -295,7 +305,8 @@ __global__ __launch_bounds__(256) void embed_segment_sum_kernel(const float* __r
 // table; id -1 (out-of-range / frozen) is skipped.  (Round 2 first had one wave per position: 60 us for 160 k positions.)
 constexpr int kRunShort = 8;
 
-__global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restrict__ g, const int64_t* __restrict__ perm,
+template <typename GT>   // GT = __hip_bfloat16: the incoming gradient rows are bf16 (converted on load, summed in fp32)
+__global__ __launch_bounds__(256) void embed_run_sum_kernel(const GT* __restrict__ g, const int64_t* __restrict__ perm,
                                                             const int64_t* __restrict__ sorted_ids, float* __restrict__ dtable, long R,
                                                             int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -327,10 +338,10 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < kRunShort; ++t) {
-        const float* src = g + pr[t] * K + kq * 4;
+        const GT* src = g + pr[t] * K + kq * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (t < n && kq * 4 + i < K) acc[i] += src[i];
+          if (t < n && kq * 4 + i < K) acc[i] += (float)src[i];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -376,11 +387,11 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
       if (c < C) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float* src = g + pr0[u] * K + kq * 4;
+          const GT* src = g + pr0[u] * K + kq * 4;
           const bool on = jj0 + (long)u * C < je;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (on && kq * 4 + i < K) acc4[u][i] += src[i];
+            if (on && kq * 4 + i < K) acc4[u][i] += (float)src[i];
         }
         // (the next batch's permutation entries requested in front of this batch's rows: 62 -> 90 registers, 20.9 -> 21.9 us)
         for (long jj = jj0 + 4L * C; jj < je; jj += 4L * C) {
@@ -389,11 +400,11 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
           for (int u = 0; u < 4; ++u) pr[u] = perm[jj + (long)u * C < je ? jj + (long)u * C : jj];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const float* src = g + pr[u] * K + kq * 4;
+            const GT* src = g + pr[u] * K + kq * 4;
             const bool on = jj + (long)u * C < je;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (on && kq * 4 + i < K) acc4[u][i] += src[i];
+              if (on && kq * 4 + i < K) acc4[u][i] += (float)src[i];
           }
         }
       }
@@ -424,32 +435,54 @@ __global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restr
 
 using namespace fil;
 
-extern "C" int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K,
-                                 void* stream) {
+extern "C" int fil_embed_run_sum_dt(const void* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, int g_dtype,
+                                    void* stream) {
   FIL_CHECK_ARG(R >= 0 && K >= 1);
+  if (g_dtype != FIL_F32 && g_dtype != FIL_BF16) return fail(FIL_ERR_ARG, "fil_embed_run_sum_dt: g_dtype %d (f32 or bf16)", g_dtype);
   if (K > 256) return fail(FIL_ERR_UNSUPPORTED, "fil_embed_run_sum: K=%d > 256", K);
   if (R == 0) return FIL_OK;
   FIL_CHECK_ARG(g && perm && sorted_ids && dtable);
   const int C = 64 / ((K + 3) / 4);   // positions per wave and iteration
-  hipLaunchKernelGGL(embed_run_sum_kernel, dim3((int)std::min<long>((R + 4 * C - 1) / (4 * C), 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, perm,
-                     sorted_ids, dtable, R, K);
+  const dim3 grid((int)std::min<long>((R + 4 * C - 1) / (4 * C), 256 * 32));
+  if (g_dtype == FIL_F32)
+    hipLaunchKernelGGL(embed_run_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(g), perm, sorted_ids, dtable, R, K);
+  else
+    hipLaunchKernelGGL(embed_run_sum_kernel<__hip_bfloat16>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const __hip_bfloat16*>(g), perm,
+                       sorted_ids, dtable, R, K);
   FIL_CHECK_LAUNCH();
   return FIL_OK;
 }
 
-extern "C" int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
-                                int* oob_count, int B, int F, int K, void* stream) {
+extern "C" int fil_embed_run_sum(const float* g, const int64_t* perm, const int64_t* sorted_ids, float* dtable, long R, int K, void* stream) {
+  return fil_embed_run_sum_dt(g, perm, sorted_ids, dtable, R, K, FIL_F32, stream);
+}
+
+extern "C" int fil_embed_gather_dt(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, void* out,
+                                   int* oob_count, int B, int F, int K, int out_dtype, void* stream) {
   FIL_CHECK_ARG(B >= 0 && F >= 1 && K >= 1);
+  if (out_dtype != FIL_F32 && out_dtype != FIL_BF16) return fail(FIL_ERR_ARG, "fil_embed_gather_dt: out_dtype %d (f32 or bf16)", out_dtype);
   if (B == 0) return FIL_OK;
   FIL_CHECK_ARG(table && offsets && idx && out);
   const long rows = (long)B * F;
   const bool vec = (K % 4 == 0);
   const long total = rows * (vec ? K / 4 : K);
   const int grid = (int)std::min<long>((total + 255) / 256, 256 * 8);
-  if (vec) hipLaunchKernelGGL((embed_gather_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, sizes, idx, out, oob_count, rows, F, K);
-  else hipLaunchKernelGGL((embed_gather_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table, offsets, sizes, idx, out, oob_count, rows, F, K);
+  hipStream_t st = (hipStream_t)stream;
+#define FIL_GATHER(VECV, OTV) \
+  hipLaunchKernelGGL((embed_gather_kernel<VECV, OTV>), dim3(grid), dim3(256), 0, st, table, offsets, sizes, idx, static_cast<OTV*>(out), oob_count, rows, F, K)
+  if (out_dtype == FIL_F32) {
+    if (vec) FIL_GATHER(4, float); else FIL_GATHER(1, float);
+  } else {
+    if (vec) FIL_GATHER(4, __hip_bfloat16); else FIL_GATHER(1, __hip_bfloat16);
+  }
+#undef FIL_GATHER
   FIL_CHECK_LAUNCH();
   return FIL_OK;
+}
+
+extern "C" int fil_embed_gather(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,
+                                int* oob_count, int B, int F, int K, void* stream) {
+  return fil_embed_gather_dt(table, offsets, sizes, idx, out, oob_count, B, F, K, FIL_F32, stream);
 }
 
 extern "C" int fil_embed_gather_xt(const float* table, const int64_t* offsets, const int64_t* sizes, const int64_t* idx, float* out,

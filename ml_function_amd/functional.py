@@ -806,7 +806,7 @@ def embed_grad_rows(offsets, sizes, idx, g, frozen=None, layout_key=None, n_rows
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key=None, xt_out=None):
+    def forward(ctx, table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key=None, xt_out=None, out_dtype=None):
         _require_cuda(table, offsets, idx)
         table = _f32c(table)
         idx = idx.to(torch.int64).contiguous()
@@ -814,13 +814,16 @@ class _EmbedFn(torch.autograd.Function):
         B, F = idx.shape
         K = table.shape[1]
         del _SORT_CACHE[:]
-        out = torch.empty((B, F, K), dtype=torch.float32, device=table.device)
+        out_dtype = out_dtype or torch.float32
+        if out_dtype not in (torch.float32, torch.bfloat16) or (xt_out is not None and out_dtype != torch.float32):
+            raise FilError("embed_gather: out_dtype %s (float32, or bfloat16 without emit_xt)" % out_dtype)
+        out = torch.empty((B, F, K), dtype=out_dtype, device=table.device)
         if xt_out is not None:     # both layouts in one pass: the packed block and its [B*K, F] transpose (fil.h)
             check(_lib.load().fil_embed_gather_xt(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(xt_out), ptr(oob_count),
                                                   B, F, K, stream_ptr()), "fil_embed_gather_xt")
         else:
-            check(_lib.load().fil_embed_gather(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(oob_count), B, F, K,
-                                               stream_ptr()), "fil_embed_gather")
+            check(_lib.load().fil_embed_gather_dt(ptr(table), ptr(offsets), ptr(sizes), ptr(idx), ptr(out), ptr(oob_count), B, F, K,
+                                                  FIL_F32 if out_dtype == torch.float32 else FIL_BF16, stream_ptr()), "fil_embed_gather_dt")
         ctx.save_for_backward(offsets, idx, *[t for t in (sizes, frozen) if t is not None])
         ctx.cfg = (tuple(table.shape), sizes is not None, frozen is not None, bool(sparse_grad), bool(atomic), layout_key)
         return out
@@ -835,7 +838,9 @@ class _EmbedFn(torch.autograd.Function):
         frozen = rest.pop(0) if has_frozen else None
         B, F = idx.shape
         K = table_shape[1]
-        g = _f32c(g)
+        # (a bf16 block's gradient arrives as bf16: the dense deterministic path reads it as it is, the others take fp32)
+        g_bf16 = g.dtype == torch.bfloat16 and not atomic and not sparse_grad
+        g = g.contiguous() if g_bf16 else _f32c(g)
         if atomic:      # opt-in: fp32 atomics into a zeroed dense table (order of additions not fixed)
             dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
             check(_lib.load().fil_embed_scatter_add(ptr(offsets), ptr(sizes), ptr(idx), ptr(g), ptr(dtable), B, F, K, stream_ptr()),
@@ -849,18 +854,19 @@ class _EmbedFn(torch.autograd.Function):
             lib = _lib.load()
             sorted_ids, perm = _sorted_row_ids(offsets, sizes, frozen, idx, layout_key, table_shape[0], per_field=True)
             dtable = torch.zeros(table_shape, dtype=torch.float32, device=g.device)
-            check(lib.fil_embed_run_sum(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, stream_ptr()), "fil_embed_run_sum")
-        return dtable, None, None, None, None, None, None, None, None, None
+            check(lib.fil_embed_run_sum_dt(ptr(g), ptr(perm), ptr(sorted_ids), ptr(dtable), B * F, K, FIL_BF16 if g_bf16 else FIL_F32,
+                                           stream_ptr()), "fil_embed_run_sum_dt")
+        return dtable, None, None, None, None, None, None, None, None, None, None
 
 
 def embed_gather(table, offsets, idx, sizes=None, frozen=None, sparse_grad=False, atomic=False, oob_count=None, layout_key=None,
-                 emit_xt=False):
+                 emit_xt=False, out_dtype=None):
     """table [sum V_f, K] (all fields concatenated), offsets [F], idx [B,F] -> packed [B,F,K].
     sizes [F] int64: ids outside [0, V_f) give zero rows (counted in oob_count, an int32 device scalar) and no gradient.
     The gradient is deterministic (sorted segment sums); sparse_grad=True returns it as a sparse COO tensor over the touched
     rows instead of a dense table; atomic=True selects the fp32-atomic scatter-add instead."""
-    if not emit_xt:
-        return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key)
+    if not emit_xt:   # (out_dtype=torch.bfloat16: the block leaves the gather rounded to bf16 and its gradient is read as bf16 -- no cast launches)
+        return _EmbedFn.apply(table, offsets, sizes, idx, frozen, sparse_grad, atomic, oob_count, layout_key, None, out_dtype)
     # emit_xt: the same launch also writes the block transposed to [B*K, F], the layout the CIN kernels read; it rides on the
     # result as `_fil_xt` (the CIN layer picks it up: no second pass over the block)
     B, F = idx.shape

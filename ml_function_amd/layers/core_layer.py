@@ -49,7 +49,7 @@ class Dense(Layer):
 
     def call(self, inputs, **kwargs):
         if (inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32 and self.kernel.dtype == torch.float32
-                and not torch.is_autocast_enabled() and inputs.shape[0] > 0):
+                and not torch.is_autocast_enabled("cuda") and inputs.shape[0] > 0):
             y = F.dense(inputs, self.kernel, self.bias)     # fp32 on the GPU: the library's own GEMM both ways (functional._DenseFn)
         else:
             y = torch.matmul(inputs, self.kernel) + self.bias
@@ -79,10 +79,10 @@ class StackLayer(Layer):
             inputs = [t.reshape(t.shape[0], -1) for t in inputs]
         if len(inputs) == 1:
             return inputs[0]
-        if inputs[0].is_cuda and torch.is_autocast_enabled():
+        if inputs[0].is_cuda and torch.is_autocast_enabled("cuda"):
             # under autocast `cat` promotes mixed inputs to the widest type (fp32) and the layer behind it casts the result down
             # again: cast the wide pieces first instead -- the same values, one narrow concatenation instead of a wide one + a cast
-            lo = torch.get_autocast_gpu_dtype()
+            lo = torch.get_autocast_dtype("cuda")
             if any(t.dtype == lo for t in inputs) and all(t.dtype in (lo, torch.float32) for t in inputs):
                 inputs = [t.to(lo) for t in inputs]
         return torch.cat(inputs, dim=self.axis)

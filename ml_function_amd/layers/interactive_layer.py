@@ -336,7 +336,7 @@ class SparseEmbed(Layer):
     instead of a dense table; either way it is deterministic (sorted segment sums, no atomics)."""
 
     def __init__(self, sparse_info: list, is_linear=False, use_flatten=True, use_add=False, seed=2020, support_masking=True,
-                 mask_zero=False, packed=False, check_ids=None, sparse_grad=False, emit_xt=False):
+                 mask_zero=False, packed=False, check_ids=None, sparse_grad=False, emit_xt=False, out_dtype=None):
         super().__init__()
         self.sparse_info = sparse_info
         self.is_linear = is_linear
@@ -349,6 +349,7 @@ class SparseEmbed(Layer):
         self.check_ids = _CHECK_IDS if check_ids is None else bool(check_ids)
         self.sparse_grad = sparse_grad
         self.emit_xt = emit_xt      # extension: also emit the block transposed to [B*K, F] for a CIN consumer (fil_embed_gather_xt)
+        self.out_dtype = out_dtype  # extension: torch.bfloat16 = the block in bf16 straight out of the gather (a bf16 model's cast, fused)
 
     def build(self, input_shape):
         dims = {int(i.linear_unit if self.is_linear else i.cross_unit) for i in self.sparse_info}
@@ -406,7 +407,7 @@ class SparseEmbed(Layer):
         oob = torch.zeros((), dtype=torch.int32, device=idx.device) if self.check_ids else None
         block = Fn.embed_gather(self.embeddings, self.offsets, idx, sizes=self.sizes, frozen=self.frozen,
                                 sparse_grad=self.sparse_grad, oob_count=oob, layout_key=self._layout_key,
-                                emit_xt=self.emit_xt)  # [B,F,K]
+                                emit_xt=self.emit_xt, out_dtype=self.out_dtype)  # [B,F,K]
         if oob is not None and int(oob) > 0:
             bad = ((idx < 0) | (idx >= self.sizes)).nonzero()[0].tolist()
             raise IndexError("SparseEmbed: %d ids outside their vocabulary, first at sample %d, field %s (id %d, word_size %d)"

@@ -49,13 +49,15 @@ class FeatureInput(Layer):
     optional linear embeddings) and passes the dense columns through as F_d tensors [B,1]."""
 
     def __init__(self, sparseInfo=None, denseInfo=None, useLinear=False, useAddLinear=False, useFlattenLinear=False,
-                 useFlattenSparse=False, emitXT=False):
+                 useFlattenSparse=False, emitXT=False, embedDtype=None):
         super().__init__()
         self.sparse_info = sparseInfo or []
         self.dense_info = denseInfo or []
         self.use_linear = useLinear
         # emitXT (extension): the embedding gather also writes the block in the layout the CIN kernels read (XDeepFM)
-        self.sparse_embed = SparseEmbed(self.sparse_info, use_flatten=useFlattenSparse, emit_xt=emitXT) if self.sparse_info else None
+        # embedDtype (extension): torch.bfloat16 = the cross embeddings leave the gather as bf16 (a bf16 model's cast of the block, fused)
+        self.sparse_embed = (SparseEmbed(self.sparse_info, use_flatten=useFlattenSparse, emit_xt=emitXT, out_dtype=embedDtype)
+                             if self.sparse_info else None)
         self.linear_embed = (SparseEmbed(self.sparse_info, use_flatten=useFlattenLinear, is_linear=True, use_add=useAddLinear)
                              if (useLinear and self.sparse_info) else None)
 

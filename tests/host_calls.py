@@ -119,6 +119,10 @@ def run(lib):
     expect(lib.fil_embed_sort_fields(one_ptr, None, None, one_ptr, one_ptr, one_ptr, 9000, 3, 0, None), -4, b"8192")
     expect(lib.fil_embed_segment_sum(None, None, None, None, None, None, 5, 300, None), -4)
     expect(lib.fil_embed_run_sum(None, None, None, None, 0, 8, None), 0)
+    expect(lib.fil_embed_run_sum_dt(None, None, None, None, 0, 8, 1, None), 0)
+    expect(lib.fil_embed_run_sum_dt(None, None, None, None, 0, 8, 7, None), -1, b"g_dtype")
+    expect(lib.fil_embed_gather_dt(None, None, None, None, None, None, 0, 3, 8, 1, None), 0)
+    expect(lib.fil_embed_gather_dt(None, None, None, None, None, None, 4, 3, 8, 5, None), -1, b"out_dtype")
     expect(lib.fil_embed_gather_xt(None, None, None, None, None, None, None, 4, 3, 8, None), -1)
     expect(lib.fil_embed_gather_xt(None, None, None, None, None, None, None, 0, 3, 8, None), 0)
     one = ctypes.c_void_p(8)   # (never dereferenced: the LDS limit is checked before the launch)

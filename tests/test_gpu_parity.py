@@ -787,6 +787,30 @@ def test_embed_out_of_range_ids_and_determinism():
     assert float(grad_fr[lo:hi].abs().max()) == 0.0 and float(grad_fr[:lo].abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("B,K", [(4096, 16), (333, 7), (64, 1)])
+def test_embed_gather_in_bf16_is_the_rounded_fp32_block_and_takes_a_bf16_gradient(B, K):
+    """embed_gather(out_dtype=bfloat16) (fil_embed_gather_dt / fil_embed_run_sum_dt): the block is the fp32 gather rounded to bf16, bit for
+    bit; its gradient, arriving as bf16, gives exactly the table gradient of the fp32 path fed the same values (converted on load, summed
+    in fp32, in the same order)."""
+    from ml_function_amd import functional as Fn
+    rng = np.random.default_rng(B + K)
+    vocab = [7, 500, 3, 12000]
+    F = len(vocab)
+    table = dev(rng.standard_normal((sum(vocab), K)).astype(np.float32)).requires_grad_()
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(vocab)[:-1]]), device="cuda")
+    sizes = torch.tensor(vocab, device="cuda")
+    idx = torch.tensor(np.stack([rng.integers(0, v, B) for v in vocab], 1), device="cuda")
+    g = dev(rng.standard_normal((B, F, K)).astype(np.float32)).bfloat16()
+    out32 = Fn.embed_gather(table, offsets, idx, sizes=sizes)
+    out16 = Fn.embed_gather(table, offsets, idx, sizes=sizes, out_dtype=torch.bfloat16)
+    assert out16.dtype == torch.bfloat16 and torch.equal(out16, out32.detach().bfloat16())
+    out16.backward(g)
+    g16 = table.grad.clone()
+    table.grad = None
+    out32.backward(g.float())
+    assert torch.equal(g16, table.grad)
+
+
 @pytest.mark.parametrize("B", [1, 333, 1000, 2000, 4096, 5000, 8192])
 def test_embed_sort_fields_is_a_stable_sort_within_each_field(B):
     """fil_embed_sort_fields (one launch, a bitonic network per field in LDS) against torch's stable sort of the same field: the same
