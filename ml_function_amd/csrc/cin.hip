@@ -64,14 +64,15 @@ static int env_int(const char* name, int dflt) {
 //   FIL_CIN_FWDQ=0        ... its forward as two 128-column launches + the pool kernel instead of the 256-column launch with fused pools
 //   FIL_CIN_HEADFOLD=0    ... the pooled relayout + Dense(1) head as their own launch instead of the 256-column launch's epilogue
 //   FIL_CIN_PACKFOLD=0    ... T's two operand layouts by a pack launch instead of by the T workgroups themselves (exact mode)
+//   FIL_CIN_DWFOLD4=0     ... the merged weight-gradient launch folds PAIRS of row splits (4 tiles x 2 splits per workgroup) instead of quads
 // Results are identical up to summation order whatever they say.  Per-call overrides for tests travel in `mode`
 // (FIL_CIN_MB2, FIL_CIN_NOSYM), not through the environment.
 struct Knobs {
-  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq, headfold, packfold;
+  int mb, sym, dw_mb, dw_splits, dz_mb, tail_splits, tail_settle, tail_dz_mode, ksplit, dzs_mb, qtail, qmerge, dz2, fwdq, headfold, packfold, dwfold4;
 };
 static const Knobs& knobs() {
   static const Knobs k = {env_int("FIL_CIN_MB", 0), env_int("FIL_CIN_SYM", 1), env_int("FIL_CIN_DW_MB", 1), env_int("FIL_CIN_DW_SPLITS", 0),
-                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1), env_int("FIL_CIN_HEADFOLD", 1), env_int("FIL_CIN_PACKFOLD", 1)};
+                          env_int("FIL_CIN_DZ_MB", 1), env_int("FIL_CIN_TAIL_SPLITS", 0), env_int("FIL_CIN_TAIL_SETTLE", 0), env_int("FIL_CIN_TAIL_DZ_MODE", 0), env_int("FIL_CIN_KSPLIT", -1), env_int("FIL_CIN_DZS_MB", 0), env_int("FIL_CIN_QTAIL", 1), env_int("FIL_CIN_QMERGE", 1), env_int("FIL_CIN_DZ2", 1), env_int("FIL_CIN_FWDQ", 1), env_int("FIL_CIN_HEADFOLD", 1), env_int("FIL_CIN_PACKFOLD", 1), env_int("FIL_CIN_DWFOLD4", 1)};
   return k;
 }
 // per-call view of the knobs: the process defaults with the call's mode bits applied
@@ -866,9 +867,14 @@ extern "C" int fil_cin_bwd(const float* x, const float* const* W, const float* c
         cin_launch_dwq_b(st, bp, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD);
         dw_parts = bp.splits;
       } else {
-        const DwqPlan dp = cin_dwq_plan(M, Cl + F, cu_count());
-        hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth>), dim3((dp.wgs + 7) / 8 * 8), dim3(kDwqThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F, symD,
-                           dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
+        const bool f4 = knobs().dwfold4 != 0;
+        const DwqPlan dp = f4 ? cin_dwq_plan4(M, Cl + F, cu_count()) : cin_dwq_plan(M, Cl + F, cu_count());
+        if (f4)
+          hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth, 4>), dim3((dp.wgs + 7) / 8 * 8), dim3(kDwqThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F,
+                             symD, dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
+        else
+          hipLaunchKernelGGL((cin_dwq_kernel<kDwqDepth, 2>), dim3((dp.wgs + 7) / 8 * 8), dim3(kDwqThreads), 0, st, Gbuf[cur], xpT, HS0, xe, XE, part, (int)M, F,
+                             symD, dp.rows_per_split, dp.splits, dp.ncol_full, dp.rem, dp.wgs_full, dp.wgs);
         dw_parts = dp.pairs;
       }
     }

@@ -59,7 +59,31 @@ inline DwqPlan cin_dwq_plan(long M, int C, int cus) {
   return p;
 }
 
-template <int DEPTH = kDwqDepth>
+// FOLD = 4: a workgroup = 2 channel tiles x the FOUR row splits of a quad; the quad's accumulators meet through LDS in two rounds --
+// (s0 + s1) + (s2 + s3) -- and ONE partial leaves per quad: half the partial-sum traffic again (written here, read by the reduce launch).
+// Two waves instead of four share a split's B rows through L1.  Leftover tile (odd tile count): workgroups of their own, two quads each.
+inline DwqPlan cin_dwq_plan4(long M, int C, int cus) {
+  DwqPlan p;
+  p.tiles = (C + 31) / 32;
+  p.ncol_full = p.tiles / 2;   // tile pairs
+  p.rem = p.tiles % 2;
+  const long unit = 2 * kDwqDepth;
+  int best = 1;                // quads
+  for (int q = 1; q <= 256; ++q) {
+    if ((long)p.ncol_full * q + (p.rem ? (q + 1) / 2 : 0) > cus) break;
+    best = q;
+  }
+  long want = std::max<long>(4L * best, (M + (1L << 20) - 1) >> 20);
+  long rows = std::max(unit, ((M + want - 1) / want + unit - 1) / unit * unit);
+  p.rows_per_split = (int)rows;
+  p.splits = (int)std::max<long>(1, (M + rows - 1) / rows);
+  p.pairs = (p.splits + 3) / 4;   // (quads: the partials this launch leaves)
+  p.wgs_full = p.ncol_full * p.pairs;
+  p.wgs = p.wgs_full + (p.rem ? (p.pairs + 1) / 2 : 0);
+  return p;
+}
+
+template <int DEPTH = kDwqDepth, int FOLD = 2>
 __global__ __launch_bounds__(kDwqThreads, 2) void cin_dwq_kernel(const float* __restrict__ gT, const float* __restrict__ x1T, int HS, const float* __restrict__ xe,
                                                                 int XE, float* __restrict__ part, int M, int F, int symD, int rows_per_split, int splits,
                                                                 int ncol_full, int rem, int wgs_full, int wgs) {
@@ -73,10 +97,18 @@ __global__ __launch_bounds__(kDwqThreads, 2) void cin_dwq_kernel(const float* __
   // XCD-aware work mapping (as cin_dw3_kernel): workgroup i of XCD i%8 takes item (i%8)*(grid/8) + i/8 of the split-major list
   const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (item >= wgs) return;   // (whole workgroup)
-  const int wl = wave & 3, up = wave >> 2;
+  const int wl = FOLD == 4 ? (wave & 1) : (wave & 3), up = FOLD == 4 ? (wave >> 1) : (wave >> 2);
   int tile, pair;
   bool idle = false;
-  if (item < wgs_full) {
+  if constexpr (FOLD == 4) {   // (pair = the quad of row splits)
+    if (item < wgs_full) {
+      tile = (item % ncol_full) * 2 + wl;
+      pair = item / ncol_full;
+    } else {
+      tile = ncol_full * 2;
+      pair = 2 * (item - wgs_full) + wl;
+    }
+  } else if (item < wgs_full) {
     tile = (item % ncol_full) * 4 + wl;
     pair = item / ncol_full;
   } else {
@@ -95,8 +127,8 @@ __global__ __launch_bounds__(kDwqThreads, 2) void cin_dwq_kernel(const float* __
   }
   tile = __builtin_amdgcn_readfirstlane(tile);
   pair = __builtin_amdgcn_readfirstlane(pair);
-  const int split = 2 * pair + up;
-  const int npairs = (splits + 1) >> 1;
+  const int split = FOLD * pair + up;
+  const int npairs = (splits + FOLD - 1) / FOLD;
   const int c0 = tile * 32;
   const int m_lo = split * rows_per_split;
   const int m_hi = min(M, m_lo + rows_per_split);
@@ -167,18 +199,49 @@ __global__ __launch_bounds__(kDwqThreads, 2) void cin_dwq_kernel(const float* __
     }
   }
   // hand-over: the upper wave's 128 accumulator registers through LDS ([register][lane]: conflict-free), then lower + upper
-  if (up == 1) {
+  if constexpr (FOLD == 4) {
+    // round 1: split 1 -> split 0 and split 3 -> split 2 (four slots); round 2: split 2 -> split 0
+    const int slot = (up >> 1) * 2 + wl;
+    if (up & 1) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fold[slot][nb * 16 + i][lane] = acc[nb][i];
+    }
+    __syncthreads();
+    if (!(up & 1)) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] += fold[slot][nb * 16 + i][lane];
+    }
+    __syncthreads();
+    if (up == 2) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fold[wl][nb * 16 + i][lane] = acc[nb][i];
+    }
+    __syncthreads();
+    if (up != 0 || pair >= npairs) return;
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) fold[wl][nb * 16 + i][lane] = acc[nb][i];
+      for (int i = 0; i < 16; ++i) acc[nb][i] += fold[wl][nb * 16 + i][lane];
+  } else {
+    if (up == 1) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fold[wl][nb * 16 + i][lane] = acc[nb][i];
+    }
+    __syncthreads();
+    if (up == 1 || idle || pair >= npairs) return;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][i] += fold[wl][nb * 16 + i][lane];
   }
-  __syncthreads();
-  if (up == 1 || idle || pair >= npairs) return;
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] += fold[wl][nb * 16 + i][lane];
   float* pout = part + (long)pair * C * 256;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["FIL_CIN_PACKFOLD", "FIL_CIN_HEADFOLD", "FIL_CIN_FWDQ", "FIL_CIN_DZ2", "FIL_CIN_QMERGE", "FIL_CIN_QTAIL"])
+@pytest.mark.parametrize("knob", ["FIL_CIN_DWFOLD4", "FIL_CIN_PACKFOLD", "FIL_CIN_HEADFOLD", "FIL_CIN_FWDQ", "FIL_CIN_DZ2", "FIL_CIN_QMERGE", "FIL_CIN_QTAIL"])
 def test_cin_parity_subset_with_one_knob_off(knob):
     env = dict(os.environ)
     env[knob] = "0"
